@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- stitched frames/s of the MI355X compositor on BASELINE.json configs[1]
+(6x1080p synthetic views -> 3840x1920 equirect, CPW off, 5-band multiband blend).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = ONE ms_stitch call over a batch of F frames (F = --frames, default 8: 6 views x F frames,
+inputs already resident in HBM).  Weak scaling: every rank stitches its own F frames per step (frame-parallel,
+round-robin ownership); with N>1 the finished pano slabs are gathered on rank 0 over RCCL, overlapped with
+the next step.  value = N*F*K / max-over-ranks wall time.
+
+Also printed on the same JSON line:
+  roofline     -- dominant kernel: SURVEY 8(d) algorithmic bytes per launch / mean launch duration
+                  (hipEvents on the launch stream, instrumented pass right after the timed region), peak 8 TB/s
+  cpu_baseline -- the CPU oracle (a port of the reference's kernel arithmetic) on a bounded sample, rank 0 / N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "video-stitcher_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def kernel_bytes(comp, cfg, n_frames, cpw):
+    """Per-launch algorithmic bytes, SURVEY 8(d) accounting applied to the exact level sizes:
+    source read once; every Gaussian level written once (6 B/px, 16SC3) and read twice (next-level reduce,
+    Laplacian+accumulate); weights read once (4 B); dst Laplacian read-modify-write per view rect (12 B);
+    collapse reads level + coarser level and writes level (6 B each); output 8UC3 canvas written once."""
+    nb = comp.pano_geom().num_bands
+    P = []
+    A = 0
+    for i in range(cfg["n"]):
+        g = comp.view_geom(i)
+        P.append((g.roi.width + g.left + g.right) * (g.roi.height + g.top + g.bottom))
+        A += g.roi.width * g.roi.height
+    pg = comp.pano_geom()
+    Q = pg.dst_roi.width * pg.dst_roi.height
+    sumP = float(sum(P))
+    kb = {}
+    kb["k_warp"] = cfg["n"] * 3.0 * cfg["w"] * cfg["h"] + 6.0 * sumP
+    if cpw:
+        kb["k_remap_gain"] = 6.0 * A           # second gather: 3 B read + 3 B write per warped pixel
+    for l in range(nb):
+        kb["k_down_l%d" % l] = 6.0 * sumP / 4 ** l + 6.0 * sumP / 4 ** (l + 1)
+    for l in range(nb + 1):
+        b = (6.0 + 4.0 + 12.0) * sumP / 4 ** l
+        if l < nb:
+            b += (12.0 + 1.5) * Q / 4 ** l
+        if l == 0:
+            b += 3.0 * cfg["out_w"] * cfg["out_h"]
+        kb["k_blend_l%d" % l] = b
+    return {k: v * n_frames for k, v in kb.items()}, sumP, Q, A
+
+
+def cpu_baseline(cfg, gains, comp, budget_s=12.0):
+    """Time the oracle (oracle/ = CPU restatement of the reference's per-frame kernels) on config-2 frames."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    import synth
+    ncpu = os.cpu_count() or 1
+    rois = [comp.view_geom(i).roi.tuple() for i in range(cfg["n"])]
+    b = O.Blender([r[:2] for r in rois], [r[2:] for r in rois], cfg["num_bands"])
+    maps = []
+    for i in range(cfg["n"]):
+        b.init_view(i, comp.mask(i).cpu().numpy())
+        xm, ym = comp.maps(i)
+        maps.append((xm.cpu().numpy(), ym.cpu().numpy()))
+    frames = [synth.frame(cfg["w"], cfg["h"], i, 0) for i in range(cfg["n"])]
+
+    def one():
+        for i in range(cfg["n"]):
+            b.stitch_online(i, frames[i], maps[i][0], maps[i][1], gains[i])
+        b.blend()
+    O.set_num_threads(1)
+    one()                                   # warm-up (page-in)
+    t1 = time.perf_counter(); one(); one_thread = time.perf_counter() - t1
+    # the port is OpenMP-parallel over rows; pick the thread count that is fastest on this host
+    best, cores = one_thread, 1
+    for th in (8, 16, 32, 64):
+        if th > ncpu:
+            break
+        O.set_num_threads(th)
+        t1 = time.perf_counter(); one(); el = time.perf_counter() - t1
+        if el < best:
+            best, cores = el, th
+    O.set_num_threads(cores)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(); n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    fps_all = n / el
+    b.close()
+    return {"value": round(fps_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d config-2 frames (6x1080p -> 3839x627 pano ROI, 5 bands) in %.1f s with %d OpenMP threads "
+                      "(best of 1/8/16/32/64 on a %d-CPU host); 1 thread: %.0f ms/frame" % (n, el, cores, ncpu, one_thread * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=8, help="frames per ms_stitch call (1 = live mode)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU: libmsstitch has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import msstitch as ms
+    import synth
+    import dist_frames as df
+
+    cpw = args.config == "cfg3"
+    cfg = synth.CONFIGS["cfg5" if args.config == "cfg5" else "cfg2"]
+    F = args.frames
+    comp = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]),
+                         num_bands=cfg["num_bands"], enable_cpw=cpw, out_size=(cfg["out_w"], cfg["out_h"]), max_frames=F)
+    gains = synth.gains(cfg["n"])
+    for i in range(cfg["n"]):
+        K, R = synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i)
+        comp.set_camera(i, K, R)
+        comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    if cpw:
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 40, 40, phase=0.1 * i))
+
+    # synthetic input: 8 distinct frames per view, cycled; frame t of the global sequence -> rank t mod G
+    n_distinct = 8
+    pool = [[torch.from_numpy(synth.frame(cfg["w"], cfg["h"], i, t)).to(dev) for i in range(cfg["n"])] for t in range(n_distinct)]
+    frames = [pool[(rank + j * world) % n_distinct] for j in range(F)]
+    pg = comp.pano_geom()
+    fh = pg.dst_roi_final.height
+    outs = [[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(F)] for _ in range(2)]
+    slabs = [torch.zeros((F, fh, cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    runs = [comp.prepared(frames, out8u=outs[b]) for b in range(2)]
+    gather = world > 1 and not args.no_gather
+    gl = [[torch.empty_like(slabs[0]) for _ in range(world)] for _ in range(2)] if (gather and rank == 0) else [None, None]
+    pending = [None, None]
+    y0 = pg.canvas_y
+
+    def step(s):
+        b = s & 1
+        if pending[b] is not None:
+            pending[b].wait(); pending[b] = None
+        runs[b]()
+        if gather:
+            for j in range(F):   # the pano ROI rows of each canvas are one contiguous slab
+                slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
+            pending[b], _ = df.gather_slabs(slabs[b], rank, world, dst=0, async_op=True, out=gl[b])
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait(); pending[b] = None
+
+    for s in range(args.warmup):
+        step(s)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(s)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- instrumented pass: per-kernel hipEvent durations on the launch stream ------------------
+    acc = {}
+    reps = max(5, min(50, args.steps))
+    for _ in range(reps):
+        for name, ms_t in comp.stitch_timed(frames, out8u=outs[0]):
+            acc.setdefault(name, []).append(ms_t)
+    kmean = {k: float(np.mean(v)) for k, v in acc.items()}
+    kb, sumP, Q, A = kernel_bytes(comp, cfg, F, cpw)
+    dom = max(kmean, key=kmean.get)
+    achieved = kb[dom] / (kmean[dom] * 1e-3) / 1e9          # GB/s
+    b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), [0], 0, (cfg["out_w"], cfg["out_h"]))  # placeholder, replaced below
+    P_list = []
+    for i in range(cfg["n"]):
+        g = comp.view_geom(i)
+        P_list.append((g.roi.width + g.left + g.right) * (g.roi.height + g.top + g.bottom))
+    b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), P_list, Q, (cfg["out_w"], cfg["out_h"]), warped_px=A, cpw=cpw)
+    gpu_ms_step = float(sum(kmean.values()))
+
+    if rank == 0:
+        total_frames = world * F * args.steps
+        res = {
+            "metric": "stitched frames/sec, 6x1080p->4K equirect (ms/frame = 1000/value*n_gpus)",
+            "value": round(total_frames / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_frame": round(elapsed / args.steps / F * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 in / int16+fp32 pyramid arithmetic", "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, spherical, %d bands, CPW %s; "
+                                   "%d frames per step per GPU, inputs resident in HBM"
+                                   % (args.config, cfg["n"], cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"],
+                                      pg.num_bands, "on (40x40 mesh)" if cpw else "off", F),
+                       "frames_per_step": F, "parallelism": "frame-parallel x%d%s" % (world, ", RCCL gather of pano slabs on rank 0" if gather else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "alg_bytes_per_launch": int(kb[dom]), "mean_launch_ms": round(kmean[dom], 5)},
+            "frame_roofline": {"alg_bytes_per_frame": int(b_alg_frame), "gpu_ms_per_frame": round(gpu_ms_step / F, 5),
+                               "achieved_GBps": round(b_alg_frame * F / (gpu_ms_step * 1e-3) / 1e9, 1),
+                               "frac": round(b_alg_frame * F / (gpu_ms_step * 1e-3) / 8e12, 4)},
+            "kernels_ms_per_step": {k: round(v, 5) for k, v in kmean.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, gains, comp)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

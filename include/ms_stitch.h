@@ -1,0 +1,246 @@
+/*
+ * ms_stitch.h -- C-ABI of libmsstitch.so: the MI355X-native (gfx950, hand-written HIP) per-frame
+ * 360-degree stitching compositor.  Drop-in boundary for the hot path of ultravideo/video-stitcher
+ * (360_stitcher/timed.cpp stitch_online/stitch_one -> OpenCV-3.4-fork MultiBandBlender
+ * feed_online/blend and the cv::cuda:: image ops underneath).
+ *
+ * The reference has no FFI layer; its seam is (1) the host<->.cu launcher boundary -- free functions
+ * taking POD PtrStepSz<T> {data, step, cols, rows} + cudaStream_t -- and (2) the C++ API of
+ * cv::cuda::* / detail::MultiBandBlender / detail::*WarperGpu.  This header restates both as plain C:
+ * every entry point cites the reference interface it replaces (paths relative to the reference
+ * repo; OCV = sources/modules, APP = 360_stitcher).  INTEGRATION.md shows the C++ shim a
+ * maintainer adds so that timed.cpp-style callers compile unchanged.
+ *
+ * Conventions
+ *   - ms_image is bit-compatible with cv::cuda::PtrStepSz<T> + the OpenCV type code, i.e. it can be
+ *     filled from a cv::cuda::GpuMat without copying: {m.data, m.step, m.rows, m.cols, m.type()}.
+ *     All ms_image pointers are DEVICE pointers unless a parameter says "host".
+ *   - ms_stream is a hipStream_t (NULL = the default stream).  Calls only enqueue work.
+ *   - Every function returns MS_OK (0) or a negative ms_status; ms_last_error() returns the
+ *     message of the calling thread's most recent failure (cf. sts_net_get_last_error, APP/netlib.h:74).
+ *     Nothing throws across this boundary (the reference throws cv::Exception: OCV/core/include/
+ *     opencv2/core/cuda/common.hpp:66-75).
+ *   - There is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     MS_ERR_NO_DEVICE (the reference's no-CUDA build does throw_no_cuda(), OCV/cudawarping/src/remap.cpp:47).
+ */
+#ifndef MS_STITCH_H
+#define MS_STITCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_API __attribute__((visibility("default")))
+
+typedef enum ms_status {
+    MS_OK = 0,
+    MS_ERR_INVALID = -1,      /* bad argument (CV_Assert in the reference)          */
+    MS_ERR_UNSUPPORTED = -2,  /* type/flag combination the hot path never uses      */
+    MS_ERR_HIP = -3,          /* HIP runtime error (cudaSafeCall in the reference)  */
+    MS_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                           */
+    MS_ERR_STATE = -5,        /* call order violated (e.g. stitch before calibrate) */
+    MS_ERR_NOMEM = -6
+} ms_status;
+
+/* OpenCV type codes CV_MAKETYPE(depth, cn) = depth + ((cn-1) << 3)  (OCV/core/include/opencv2/core/hal/interface.h) */
+enum { MS_8UC1 = 0, MS_8UC3 = 16, MS_16SC1 = 3, MS_16SC3 = 19, MS_32FC1 = 5 };
+/* cv::BorderTypes / cv::InterpolationFlags values used on the path */
+enum { MS_BORDER_CONSTANT = 0, MS_BORDER_REFLECT = 2 };
+enum { MS_INTER_NEAREST = 0, MS_INTER_LINEAR = 1 };
+/* warper kinds: detail::{Plane,Cylindrical,Spherical}WarperGpu (OCV/stitching/include/opencv2/stitching/detail/warpers.hpp:435-550) */
+enum { MS_PROJ_PLANE = 0, MS_PROJ_CYLINDRICAL = 1, MS_PROJ_SPHERICAL = 2 };
+
+typedef struct ms_image {   /* == PtrStepSz<T> (OCV/core/include/opencv2/core/cuda_types.hpp:95-120) + type */
+    void *data;
+    size_t step;            /* row pitch in bytes */
+    int rows, cols;
+    int type;
+} ms_image;
+
+typedef struct ms_rect { int x, y, width, height; } ms_rect;   /* cv::Rect */
+typedef void *ms_stream;                                        /* hipStream_t */
+
+MS_API const char *ms_last_error(void);
+MS_API const char *ms_version(void);
+MS_API int ms_device_count(void);       /* cuda::getCudaEnabledDeviceCount (blenders.cpp:226) */
+
+/* =============================================================================================
+ * 1. Image-op entry points: one per cv::cuda:: call / device launcher on the hot path
+ * ============================================================================================= */
+
+/* cuda::remap(src, dst, xmap, ymap, INTER_LINEAR|INTER_NEAREST, BORDER_CONSTANT, Scalar(0), stream)
+ * OCV/cudawarping/src/remap.cpp:61-102 -> device::imgproc::remap_gpu<uchar3|uchar> (cuda/remap.cu:56-86).
+ * 8UC3 (linear) and 8UC1 (linear, nearest); dst.size == xmap.size == ymap.size. */
+MS_API int ms_remap(const ms_image *src, const ms_image *xmap, const ms_image *ymap, ms_image *dst,
+                    int interpolation, ms_stream stream);
+
+/* cuda::resize(src, dst, Size(), fx, fy, INTER_LINEAR, stream)  OCV/cudawarping/src/resize.cpp:57-106
+ * -> device::resize<uchar3|uchar> (cuda/resize.cu:71-106).  Two call forms, as resize.cpp:72-81:
+ *   fx > 0 && fy > 0  (the app's form, Size() + compose_scale, APP/timed.cpp:77): dst must be
+ *                     saturate_cast<int>(cols*fx) x saturate_cast<int>(rows*fy); the kernel gets 1/fx, 1/fy;
+ *   fx == 0 && fy == 0: dsize = dst size; fx = dsize.width / src.cols, fy likewise. */
+MS_API int ms_resize_linear(const ms_image *src, ms_image *dst, double fx, double fy, ms_stream stream);
+
+/* GpuMat::convertTo(dst, same type, alpha)  OCV/core/src/cuda/gpu_mat.cu:488-512 (exposure gain,
+ * APP/timed.cpp:94 / GainCompensator::apply_gpu exposure_compensate.cpp:155-160).  8U any channels, in place ok. */
+MS_API int ms_convert_scale_8u(const ms_image *src, ms_image *dst, double alpha, ms_stream stream);
+
+/* GpuMat::convertTo(dst, rtype[, alpha], stream) for the depth changes the path uses:
+ * 8U->16S (blenders.cpp:713), 16S->8U (APP/timed.cpp:251), 8U->32F with alpha (blenders.cpp:412). */
+MS_API int ms_convert(const ms_image *src, ms_image *dst, double alpha, ms_stream stream);
+
+/* cuda::copyMakeBorder(src, dst, top, bottom, left, right, borderType, Scalar(), stream)
+ * OCV/cudaarithm/src/cuda/copy_make_border.cu:126-157.  BORDER_REFLECT for 8UC3/8UC1 (blenders.cpp:711),
+ * BORDER_CONSTANT(0) for 32FC1 (blenders.cpp:420). */
+MS_API int ms_copy_make_border(const ms_image *src, ms_image *dst, int top, int bottom, int left, int right,
+                               int border_type, ms_stream stream);
+
+/* cuda::pyrDown(src, dst, stream)  OCV/cudawarping/src/pyramids.cpp:66-92 -> pyrDown_gpu<short3|float>
+ * (cuda/pyr_down.cu:55-188).  16SC3, 16SC1, 32FC1; dst must be ((rows+1)/2, (cols+1)/2). */
+MS_API int ms_pyr_down(const ms_image *src, ms_image *dst, ms_stream stream);
+
+/* cuda::pyrUp(src, dst, stream)  OCV/cudawarping/src/pyramids.cpp:106-132 -> pyrUp_gpu<short3>
+ * (cuda/pyr_up.cu:55-157).  16SC3 / 16SC1; dst must be (2*rows, 2*cols). */
+MS_API int ms_pyr_up(const ms_image *src, ms_image *dst, ms_stream stream);
+
+/* cuda::subtract / cuda::add on CV_16S, no mask  OCV/cudaarithm/src/element_operations.cpp:182,170
+ * -> SubOp1/AddOp1<short> (cuda/sub_mat.cu:59-65, cuda/add_mat.cu:59-65).  dst may alias a or b. */
+MS_API int ms_subtract_16s(const ms_image *a, const ms_image *b, ms_image *dst, ms_stream stream);
+MS_API int ms_add_16s(const ms_image *a, const ms_image *b, ms_image *dst, ms_stream stream);
+
+/* device::blend::addSrcWeightGpu32F(src, src_weight, dst, dst_weight, rc)
+ * OCV/stitching/src/blenders.cpp:54-55 -> cuda/multiband_blend.cu:36-60.  dst/dst_weight are the
+ * already-offset ROI views (dst(rc)), rc_width x rc_height is the rect size. */
+MS_API int ms_add_src_weight_32f(const ms_image *src, const ms_image *src_weight, ms_image *dst,
+                                 ms_image *dst_weight, int rc_width, int rc_height, ms_stream stream);
+
+/* device::blend::normalizeUsingWeightMapGpu32F(weight, src, width, height)
+ * blenders.cpp:58-59 -> cuda/multiband_blend.cu:85-108. */
+MS_API int ms_normalize_using_weight_32f(const ms_image *weight, ms_image *src, int width, int height,
+                                         ms_stream stream);
+
+/* cuda::compare(src32F, eps, dst8U, CMP_GT) / cuda::compare(src8U, 0, dst8U, CMP_EQ)
+ * OCV/cudaarithm/src/element_operations.cpp:292 -> cuda/cmp_scalar.cu:59-82 (blenders.cpp:803,808). */
+MS_API int ms_compare_gt_32f(const ms_image *src, float thr, ms_image *dst, ms_stream stream);
+MS_API int ms_compare_eq_8u(const ms_image *src, int val, ms_image *dst, ms_stream stream);
+
+/* GpuMat::setTo(Scalar::all(0), mask, stream) on 16SC3  gpu_mat.cu:369-374,431 (blenders.cpp:810) */
+MS_API int ms_set_zero_masked_16sc3(ms_image *img, const ms_image *mask, ms_stream stream);
+
+/* cuda::bitwise_and 8UC1 (APP/calibration.cpp:237) and the 3x3 dilation of APP/calibration.cpp:209,232 */
+MS_API int ms_bitwise_and_8u(const ms_image *a, const ms_image *b, ms_image *dst, ms_stream stream);
+MS_API int ms_dilate3x3_8u(const ms_image *src, ms_image *dst, ms_stream stream);
+
+/* device::imgproc::buildWarp{Plane,Spherical,Cylindrical}Maps(tl_u, tl_v, map_x, map_y, k_rinv, r_kinv[, t], scale, stream)
+ * OCV/stitching/src/warpers_cuda.cpp:51-67 -> cuda/build_warp_maps.cu:155-216.  k_rinv, r_kinv: 9 floats
+ * (HOST), t: 3 floats (HOST, plane only, may be NULL). */
+MS_API int ms_build_warp_maps(int projection, int tl_u, int tl_v, ms_image *map_x, ms_image *map_y,
+                              const float *k_rinv, const float *r_kinv, const float *t, float scale,
+                              ms_stream stream);
+
+/* custom_resize(GpuMat &in, GpuMat &out, Size t_size)  APP/resize.cu:30-45, APP/calibration.h:15.
+ * out->rows/cols give t_size.  32FC1. */
+MS_API int ms_custom_resize_32f(const ms_image *in, ms_image *out, ms_stream stream);
+
+/* =============================================================================================
+ * 2. Host geometry (integer/fp32 host code in the reference too)
+ * ============================================================================================= */
+
+/* RotationWarper::warpRoi(src_size, K, R)  OCV/stitching/include/opencv2/stitching/detail/warpers_inl.hpp:136-146
+ * incl. the per-warper detectResultRoi (warpers.cpp:277-318, warpers.hpp:287-290).  K, R: 9 floats row-major. */
+MS_API int ms_warp_roi(int projection, const float *K, const float *R, float scale, int src_w, int src_h,
+                       ms_rect *roi);
+/* detail::resultRoi(corners, sizes)  OCV/stitching/src/util.cpp:125-138 */
+MS_API int ms_result_roi(int n, const ms_rect *view_rois, ms_rect *roi);
+
+/* =============================================================================================
+ * 3. The compositor context: calibration tables once, then one fused launch sequence per frame
+ * ============================================================================================= */
+
+typedef struct ms_ctx ms_ctx;
+
+typedef struct ms_config {
+    int num_views;          /* NUM_IMAGES (APP/defs.h:37)                                             */
+    int src_width, src_height;   /* camera frame size (after the optional compose_scale resize)       */
+    int projection;         /* MS_PROJ_*: the app ships cylindrical (APP/calibration.cpp:100,156)     */
+    float warp_scale;       /* warper scale = warped_image_scale * compose_work_aspect (calibration.cpp:156) */
+    int num_bands;          /* MultiBandBlender num_bands (blenders.hpp:129 default 5; calibration.cpp:193) */
+    int enable_cpw;         /* enable_local (APP/defs.h:27): second remap through the mesh maps       */
+    int out_width, out_height;   /* equirect canvas (0,0 = emit the pano ROI only)                     */
+    int max_frames;         /* frames batched per ms_stitch call (1 = live; >1 amortises launches)    */
+    int reserved[8];
+} ms_config;
+
+MS_API int ms_create(const ms_config *cfg, ms_ctx **out);
+MS_API void ms_destroy(ms_ctx *ctx);
+
+/* cameras[i].K() / cameras[i].R as fp32 row-major 3x3 (APP/calibration.cpp:28-68,217-221) */
+MS_API int ms_set_camera(ms_ctx *ctx, int view, const float *K, const float *R);
+/* GainCompensator::gains()[view]  (exposure_compensate.cpp:164-170, APP/timed.cpp:94) */
+MS_API int ms_set_gain(ms_ctx *ctx, int view, double gain);
+
+/* warper->warpRoi + gpu_warper->buildMaps per view (APP/calibration.cpp:168-181,221) and
+ * blender->prepare(corners, sizes) (calibration.cpp:196 -> blenders.cpp:82-85,237-295). */
+MS_API int ms_build_maps(ms_ctx *ctx, ms_stream stream);
+
+/* Compose-size blend masks (APP/calibration.cpp:224-237).  mode 0: warp(255, NEAREST) only;
+ * mode 1: AND with Voronoi seams (VoronoiSeamFinder, seam_finders.cpp:85-160) computed at compose size
+ * (the app computes them at seam scale and resizes up: stated simplification). */
+MS_API int ms_build_masks(ms_ctx *ctx, int mode, ms_stream stream);
+/* Or hand a mask over, as init_gpu(img, mask, tl) receives it (blenders.cpp:344): HOST 8UC1, view-ROI sized. */
+MS_API int ms_set_mask(ms_ctx *ctx, int view, const uint8_t *mask_host, size_t step);
+/* mb->init_gpu(_, mask, corner) for every view, in view order (calibration.cpp:240 -> blenders.cpp:344-461),
+ * plus the frame-invariant weight sums the reference re-accumulates every frame (blenders.cpp:736, :775). */
+MS_API int ms_init_blender(ms_ctx *ctx, ms_stream stream);
+
+/* MeshWarper::convertMeshesToMap for one view (APP/meshwarper.cpp:823-886): N x M vertex mesh (HOST fp32,
+ * forward positions in view-ROI pixels) -> dense backward maps x_mesh/y_mesh, double-buffered; takes
+ * effect at the next ms_stitch.  Thread-safe against ms_stitch (recalibration thread, APP/timed.cpp:414-463). */
+MS_API int ms_set_mesh(ms_ctx *ctx, int view, const float *mesh_x, const float *mesh_y, int N, int M,
+                       ms_stream stream);
+/* Or supply the dense maps directly (x_mesh[i], y_mesh[i] GpuMats, APP/timed.cpp:100). DEVICE 32FC1. */
+MS_API int ms_set_mesh_maps(ms_ctx *ctx, int view, const ms_image *x_mesh, const ms_image *y_mesh, ms_stream stream);
+
+/* stitch_one (APP/timed.cpp:123-152): for each of n_frames frames, views[f*num_views + i] is the 8UC3
+ * camera frame (DEVICE; full_imgs[i] after upload, timed.cpp:68).  Writes per frame:
+ *   out8u[f]  8UC3 out_width x out_height equirect canvas (pano ROI placed at its spherical position;
+ *             = consume()'s convertTo(CV_8U), timed.cpp:251) -- may be NULL;
+ *   out16s[f] 16SC3 pano ROI (dst_roi_final sized) = blend()'s gpuOut (blenders.cpp:811) -- may be NULL.
+ * No allocation, no host sync. */
+MS_API int ms_stitch(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
+                     ms_stream stream);
+/* gpu_dst_mask_ (blenders.cpp:803): frame-invariant; 8UC1 pano-ROI sized DEVICE image owned by ctx. */
+MS_API int ms_get_result_mask(ms_ctx *ctx, ms_image *mask);
+
+/* geometry read-back (top_/left_/bottom_/right_, x_tl_.., dst_roi_: blenders.hpp:143-175) */
+typedef struct ms_view_geom {
+    ms_rect roi;                        /* corner + size of the warped view (warpRoi)        */
+    int top, left, bottom, right;       /* reflect border (blenders.cpp:378-381)             */
+    int x_tl, y_tl, x_br, y_br;         /* padded rect inside the padded pano (blenders.cpp:425-428) */
+} ms_view_geom;
+typedef struct ms_pano_geom {
+    int num_bands;
+    ms_rect dst_roi_final, dst_roi;     /* unpadded / padded pano ROI                         */
+    int canvas_x, canvas_y;             /* where pano (0,0) lands in the out8u canvas         */
+} ms_pano_geom;
+MS_API int ms_get_view_geom(const ms_ctx *ctx, int view, ms_view_geom *g);
+MS_API int ms_get_pano_geom(const ms_ctx *ctx, ms_pano_geom *g);
+/* device-resident static tables, for parity tests: x_maps[i]/y_maps[i] (32FC1), masks (8UC1),
+ * weight pyramid level (32FC1). Borrowed pointers owned by ctx. */
+MS_API int ms_get_maps(const ms_ctx *ctx, int view, ms_image *xmap, ms_image *ymap);
+MS_API int ms_get_mask(const ms_ctx *ctx, int view, ms_image *mask);
+MS_API int ms_get_weight_level(const ms_ctx *ctx, int view, int level, ms_image *w);
+MS_API int ms_get_mesh_maps(const ms_ctx *ctx, int view, ms_image *xmesh, ms_image *ymesh);
+
+/* per-kernel GPU time of the last ms_stitch_timed call (hipEvents on `stream`), for bench.py's roofline.
+ * names/ms: arrays of `cap` entries; returns the number of kernels recorded. */
+MS_API int ms_stitch_timed(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
+                           ms_stream stream, int cap, const char **names, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MS_STITCH_H */

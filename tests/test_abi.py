@@ -1,0 +1,62 @@
+"""The C-ABI library loads, exports exactly what include/ms_stitch.h declares, and refuses to compute
+without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ms_stitch.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"MS_API\s+[\w\s\*]+?\b(ms_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(ms):
+    lib = ms.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), "libmsstitch.so does not export %s" % n
+    assert sorted(ms.EXPORTS) == names, "msstitch.EXPORTS out of sync with include/ms_stitch.h"
+
+
+def test_no_oracle_in_product():
+    """The shipped library must not reference the CPU oracle (nor may the python binding import it)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", os.path.join(ROOT, "video-stitcher_amd", "libmsstitch.so")], capture_output=True, text=True).stdout
+    assert "orc_" not in out
+    for f in ("msstitch.py", "synth.py", "dist_frames.py"):
+        src = open(os.path.join(ROOT, "video-stitcher_amd", f)).read()
+        assert "oracle" not in src.replace("no oracle", "").lower() or f == "synth.py" and "import oracle" not in src
+    for f in os.listdir(os.path.join(ROOT, "video-stitcher_amd", "csrc")):
+        src = open(os.path.join(ROOT, "video-stitcher_amd", "csrc", f)).read()
+        assert "ms_oracle.h" not in src and "orc_" not in src
+
+
+def test_compute_without_device_fails_loudly(ms):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on the CPU-only container")
+    lib = ms.load()
+    assert lib.ms_device_count() == 0
+    ctx = C.c_void_p()
+    cfg = ms.Config(2, 64, 48, ms.PROJ_SPHERICAL, 50.0, 2, 0, 0, 0, 1)
+    rc = lib.ms_create(C.byref(cfg), C.byref(ctx))
+    assert rc == -4 and b"no CPU fallback" in lib.ms_last_error()
+    buf = (C.c_uint8 * 64)()
+    im = ms.Image(C.cast(buf, C.c_void_p), 8, 8, 8, ms.MS_8UC1)
+    assert lib.ms_dilate3x3_8u(C.byref(im), C.byref(im), None) == -4
+    with pytest.raises(ms.MsError):
+        ms.Compositor(2, (64, 48), ms.PROJ_SPHERICAL, 50.0)
+
+
+def test_status_and_version(ms):
+    lib = ms.load()
+    assert b"gfx950" in lib.ms_version()
+    r = ms.Rect()
+    assert lib.ms_warp_roi(7, None, None, C.c_float(1.0), 10, 10, C.byref(r)) == -1
+    assert b"ms_warp_roi" in lib.ms_last_error()

@@ -1,0 +1,127 @@
+"""Parity of the fused per-frame path (ms_stitch) with the oracle's restatement of
+stitch_online x N + MultiBandBlender::blend (APP/timed.cpp:56-152, blenders.cpp:700-832).
+
+Integer outputs (16SC3 pano, 8UC3 canvas, 8UC1 mask) must be BIT-EXACT given identical maps and masks;
+the device-built maps/weights themselves are compared with a float tolerance in test_tables_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import host, make_rig, oracle_blender_from, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def run_oracle(O, comp, cfg, gains, frames_np, meshes=None):
+    b, rois = oracle_blender_from(O, comp, cfg)
+    for i in range(cfg["n"]):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        mx = my = None
+        if meshes is not None:
+            mx, my = meshes[i]
+        b.stitch_online(i, frames_np[i], xm, ym, gains[i], mx, my)
+    out, mask = b.blend()
+    b.close()
+    return out, mask
+
+
+def canvas_from(out16, pg, out_w, out_h):
+    ref = np.zeros((out_h, out_w, 3), np.uint8)
+    fh, fw = out16.shape[:2]
+    x0, y0 = pg.canvas_x, pg.canvas_y
+    xs0, ys0 = max(0, -x0), max(0, -y0)
+    xs1, ys1 = min(fw, out_w - x0), min(fh, out_h - y0)
+    ref[y0 + ys0:y0 + ys1, x0 + xs0:x0 + xs1] = np.clip(out16[ys0:ys1, xs0:xs1], 0, 255).astype(np.uint8)
+    return ref
+
+
+@pytest.mark.parametrize("rig", ["mini6", "mini4"])
+@pytest.mark.parametrize("mask_mode", [0, 1])
+def test_stitch_matches_oracle(ms, cuda, oracle, rig, mask_mode):
+    comp, cfg, gains = make_rig(ms, rig, mask_mode=mask_mode)
+    frames_np = [synth.frame(cfg["w"], cfg["h"], i, 0) for i in range(cfg["n"])]
+    pg = comp.pano_geom()
+    fw, fh = pg.dst_roi_final.width, pg.dst_roi_final.height
+    out16 = torch.full((fh, fw, 3), -7, dtype=torch.int16, device=cuda)
+    out8 = torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames_np]], out8u=[out8], out16s=[out16])
+    torch.cuda.synchronize()
+    ref16, refmask = run_oracle(oracle, comp, cfg, gains, frames_np)
+    got16 = host(out16)
+    assert np.array_equal(host(comp.result_mask()), refmask), "integer mask must be pixel-for-pixel"
+    bad = np.argwhere(got16 != ref16)
+    assert bad.size == 0, "first mismatches (y,x,c): %s got %s want %s" % (bad[:5], got16[tuple(bad[:5].T)], ref16[tuple(bad[:5].T)])
+    assert np.array_equal(host(out8), canvas_from(ref16, pg, cfg["out_w"], cfg["out_h"]))
+    comp.close()
+
+
+def test_stitch_cpw_matches_oracle(ms, cuda, oracle):
+    comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
+    frames_np = [synth.frame(cfg["w"], cfg["h"], i, 3) for i in range(cfg["n"])]
+    meshes = []
+    for i in range(cfg["n"]):
+        r = comp.view_geom(i).roi
+        mx, my = synth.mesh(r.width, r.height, 10, 12, phase=0.3 * i, amp=4.0)
+        comp.set_mesh(i, mx, my)
+        dmx, dmy = comp.mesh_maps(i)
+        meshes.append((host(dmx), host(dmy)))
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames_np]], out16s=[out16])
+    torch.cuda.synchronize()
+    ref16, _ = run_oracle(oracle, comp, cfg, gains, frames_np, meshes)
+    assert np.array_equal(host(out16), ref16)
+    comp.close()
+
+
+def test_batched_frames_equal_single_frames(ms, cuda):
+    comp, cfg, gains = make_rig(ms, "mini6", max_frames=3)
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(3)]
+    batch = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(3)]
+    comp.stitch(frames, out16s=batch)
+    for t in range(3):
+        single = torch.zeros(shape, dtype=torch.int16, device=cuda)
+        comp.stitch([frames[t]], out16s=[single])
+        assert torch.equal(single, batch[t])
+    assert not torch.equal(batch[0], batch[1])
+    comp.close()
+
+
+def test_full_size_config2_matches_oracle(ms, cuda, oracle):
+    """BASELINE.json configs[1] at full size: 6x1080p -> 3840x1920, 5 bands, one frame, bit-exact."""
+    comp, cfg, gains = make_rig(ms, "cfg2")
+    frames_np = [synth.frame(cfg["w"], cfg["h"], i, 0) for i in range(cfg["n"])]
+    pg = comp.pano_geom()
+    assert pg.dst_roi.tuple() == (-1919, 646, 3840, 640) and pg.num_bands == 5
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    out8 = torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames_np]], out8u=[out8], out16s=[out16])
+    torch.cuda.synchronize()
+    oracle.set_num_threads(8)
+    ref16, refmask = run_oracle(oracle, comp, cfg, gains, frames_np)
+    assert np.array_equal(host(comp.result_mask()), refmask)
+    assert np.array_equal(host(out16), ref16)
+    # size-independent properties: zero outside the mask, canvas = saturate(pano) at its spherical position
+    got = host(out16)
+    assert not got[refmask == 0].any()
+    assert np.array_equal(host(out8), canvas_from(ref16, pg, cfg["out_w"], cfg["out_h"]))
+    assert (refmask[313] == 255).all(), "the 6 views cover the full circle along the equator row"
+    comp.close()
+
+
+def test_state_errors(ms, cuda):
+    comp = ms.Compositor(2, (64, 48), ms.PROJ_SPHERICAL, 50.0, num_bands=2, out_size=(0, 0))
+    with pytest.raises(ms.MsError, match="camera 0 not set"):
+        comp.build_maps()
+    K, R = synth.camera(2, 64, 48, 90.0, 0)
+    comp.set_camera(0, K, R)
+    comp.set_camera(1, *synth.camera(2, 64, 48, 90.0, 1))
+    with pytest.raises(ms.MsError, match="ms_build_maps first"):
+        comp.build_masks(0)
+    comp.build_maps()
+    with pytest.raises(ms.MsError, match="must be built first"):
+        comp.init_blender()
+    comp.close()

@@ -1,0 +1,217 @@
+"""Per-primitive parity: every cv::cuda:: image op on the hot path (include/ms_stitch.h section 1) against
+the oracle's restatement of the same CUDA kernel.  Method follows the reference's own tests
+(OCV/cudawarping/test/test_remap.cpp, test_pyramids.cpp, test_resize.cpp; OCV/cudaarithm/test/
+test_element_operations.cpp): random data, sizes incl. odd 113 and 128 (cuda_test.hpp:212 DIFFERENT_SIZES),
+ROI sub-matrices with padded steps (cuda_test.cpp:92-104).  Bar: bit-exact (integer outputs), i.e. tighter
+than the reference's tolerance of 1.0."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import host, to_dev, to_dev_roi
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(128, 128), (113, 113), (37, 251), (1, 9), (5, 2)]   # (rows, cols)
+
+
+def rng_for(*k):
+    return np.random.default_rng(abs(hash(k)) % (2 ** 32))
+
+
+def rot_maps(rows, cols, src_rows, src_cols):
+    """45-degree rotation maps of test_remap.cpp:138-154, plus out-of-range and NaN entries."""
+    M = np.array([[math.cos(math.pi / 4), -math.sin(math.pi / 4), src_cols / 2.0],
+                  [math.sin(math.pi / 4), math.cos(math.pi / 4), 0.0]])
+    x, y = np.meshgrid(np.arange(cols), np.arange(rows))
+    mx = (M[0, 0] * x + M[0, 1] * y + M[0, 2]).astype(np.float32)
+    my = (M[1, 0] * x + M[1, 1] * y + M[1, 2]).astype(np.float32)
+    return mx, my
+
+
+@pytest.mark.parametrize("size", SIZES)
+@pytest.mark.parametrize("use_roi", [False, True])
+def test_remap_linear_8uc3(ms, cuda, oracle, size, use_roi):
+    rng = rng_for("remap3", size, use_roi)
+    src = rng.integers(0, 256, size=(size[0] + 3, size[1] + 7, 3), dtype=np.uint8)
+    mx, my = rot_maps(size[0], size[1], src.shape[0], src.shape[1])
+    mx += rng.uniform(-0.5, 0.5, mx.shape).astype(np.float32)
+    if mx.size > 20:
+        mx.flat[3] = np.nan; my.flat[7] = np.inf; mx.flat[11] = -1.0; my.flat[11] = -1.0; mx.flat[13] = 3e9
+    up = (lambda a: to_dev_roi(a, rng)) if use_roi else to_dev
+    got = ms.remap(up(src), up(mx), up(my), ms.INTER_LINEAR)
+    assert np.array_equal(host(got), oracle.remap_linear_8uc3(src, mx, my))
+
+
+@pytest.mark.parametrize("interp", ["linear", "nearest"])
+def test_remap_8uc1(ms, cuda, oracle, interp):
+    rng = rng_for("remap1", interp)
+    src = rng.integers(0, 256, size=(97, 131), dtype=np.uint8)
+    mx, my = rot_maps(113, 120, 97, 131)
+    fn = oracle.remap_linear_8uc1 if interp == "linear" else oracle.remap_nearest_8uc1
+    got = ms.remap(to_dev(src), to_dev(mx), to_dev(my), ms.INTER_LINEAR if interp == "linear" else ms.INTER_NEAREST)
+    assert np.array_equal(host(got), fn(src, mx, my))
+
+
+@pytest.mark.parametrize("scale", [0.82, 0.5, 0.3, 1.0, 1.7])
+@pytest.mark.parametrize("cn", [1, 3])
+def test_resize_linear(ms, cuda, oracle, scale, cn):
+    rng = rng_for("resize", scale, cn)
+    src = rng.integers(0, 256, size=(113, 128) + ((3,) if cn == 3 else ()), dtype=np.uint8)
+    got = ms.resize_linear(to_dev_roi(src, rng), fx=scale, fy=scale)
+    assert np.array_equal(host(got), oracle.resize_linear_8u(src, fx=scale, fy=scale))
+
+
+@pytest.mark.parametrize("alpha", [0.95, 1.0, 1.05, 1.37, 0.0])
+def test_convert_scale_8u(ms, cuda, oracle, alpha):
+    src = np.arange(256, dtype=np.uint8).repeat(3).reshape(16, 16, 3)
+    assert np.array_equal(host(ms.convert_scale_8u(to_dev(src), alpha)), oracle.convert_scale_8u(src, alpha))
+    d = to_dev(src)
+    ms.convert_scale_8u(d, alpha, inplace=True)          # the reference converts in place (timed.cpp:94)
+    assert np.array_equal(host(d), oracle.convert_scale_8u(src, alpha))
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_copy_make_border_reflect(ms, cuda, oracle, size):
+    rng = rng_for("border", size)
+    src = rng.integers(0, 256, size=size + (3,), dtype=np.uint8)
+    for (t, b, l, r) in [(0, 13, 127, 97), (3, 0, 0, 1), (2 * size[0] + 1, 1, 2 * size[1] + 3, 0)]:
+        got = ms.copy_make_border(to_dev_roi(src, rng), t, b, l, r, ms.BORDER_REFLECT)
+        assert np.array_equal(host(got), oracle.copy_make_border_reflect(src, t, b, l, r))
+
+
+def test_copy_make_border_const_32f(ms, cuda, oracle):
+    rng = rng_for("borderf")
+    src = rng.random((57, 33), dtype=np.float32)
+    got = ms.copy_make_border(to_dev(src), 5, 9, 31, 0, ms.BORDER_CONSTANT)
+    assert np.array_equal(host(got), oracle.copy_make_border_const_32f(src, 5, 9, 31, 0))
+
+
+def test_convert_depths(ms, cuda, oracle):
+    rng = rng_for("cvt")
+    u8 = rng.integers(0, 256, size=(33, 65, 3), dtype=np.uint8)
+    assert np.array_equal(host(ms.convert(to_dev(u8), torch.int16)), u8.astype(np.int16))
+    s16 = rng.integers(-400, 700, size=(33, 65, 3), dtype=np.int16)
+    assert np.array_equal(host(ms.convert(to_dev(s16), torch.uint8)), oracle.convert_16s_8u(s16))
+    m = rng.integers(0, 256, size=(33, 65), dtype=np.uint8)
+    assert np.array_equal(host(ms.convert(to_dev(m), torch.float32, 1.0 / 255.0)), oracle.convert_8u_32f_scale(m, 1.0 / 255.0))
+
+
+@pytest.mark.parametrize("size", SIZES + [(640, 1184)])
+@pytest.mark.parametrize("cn", [1, 3])
+def test_pyr_down_16s(ms, cuda, oracle, size, cn):
+    rng = rng_for("pd", size, cn)
+    lo, hi = (-32768, 32768) if size[0] % 2 else (-300, 300)
+    src = rng.integers(lo, hi, size=size + ((3,) if cn == 3 else ()), dtype=np.int16)
+    got = ms.pyr_down(to_dev_roi(src, rng))
+    assert np.array_equal(host(got), oracle.pyr_down_16s(src))
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_pyr_down_32f(ms, cuda, oracle, size):
+    rng = rng_for("pdf", size)
+    src = (rng.integers(0, 256, size=size).astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float32)
+    got = ms.pyr_down(to_dev_roi(src, rng))
+    assert np.array_equal(host(got), oracle.pyr_down_32f(src))
+
+
+@pytest.mark.parametrize("size", SIZES + [(320, 592)])
+@pytest.mark.parametrize("cn", [1, 3])
+def test_pyr_up_16s(ms, cuda, oracle, size, cn):
+    rng = rng_for("pu", size, cn)
+    lo, hi = (-32768, 32768) if size[1] % 2 else (-300, 300)
+    src = rng.integers(lo, hi, size=size + ((3,) if cn == 3 else ()), dtype=np.int16)
+    got = ms.pyr_up(to_dev_roi(src, rng))
+    assert np.array_equal(host(got), oracle.pyr_up_16s(src))
+
+
+def test_add_subtract_16s_saturate(ms, cuda, oracle):
+    rng = rng_for("addsub")
+    a = rng.integers(-32768, 32768, size=(113, 128, 3), dtype=np.int16)
+    b = rng.integers(-32768, 32768, size=(113, 128, 3), dtype=np.int16)
+    assert np.array_equal(host(ms.subtract(to_dev(a), to_dev(b))), oracle.sub_16s(a, b))
+    assert np.array_equal(host(ms.add(to_dev(a), to_dev(b))), oracle.add_16s(a, b))
+    da = to_dev(a)
+    ms.subtract(da, to_dev(b), dst=da)                   # in place, as blenders.cpp:719
+    assert np.array_equal(host(da), oracle.sub_16s(a, b))
+
+
+def test_add_src_weight_and_normalize(ms, cuda, oracle):
+    rng = rng_for("asw")
+    src = rng.integers(-600, 600, size=(64, 96, 3), dtype=np.int16)
+    w = rng.random((64, 96), dtype=np.float32)
+    w[rng.random(w.shape) < 0.2] = 0.0
+    dst = rng.integers(-32768, 32768, size=(128, 160, 3), dtype=np.int16)   # int16 accumulation wraps
+    dw = rng.random((128, 160), dtype=np.float32)
+    d_dst, d_dw = to_dev(dst), to_dev(dw)
+    ms.add_src_weight_32f(to_dev(src), to_dev(w), d_dst[32:96, 16:112], d_dw[32:96, 16:112])   # dst(rc)
+    oracle.add_src_weight_32f(src, w, dst[32:96, 16:112], dw[32:96, 16:112])
+    assert np.array_equal(host(d_dst), dst) and np.array_equal(host(d_dw), dw)
+    dw[::7, ::5] = 0.0
+    d_dw = to_dev(dw)
+    ms.normalize_using_weight_32f(d_dw, d_dst)
+    oracle.normalize_32f(dw, dst)
+    assert np.array_equal(host(d_dst), dst)
+
+
+def test_mask_ops(ms, cuda, oracle):
+    rng = rng_for("mask")
+    w = rng.random((40, 77), dtype=np.float32) * 2e-5
+    m = host(ms.compare_gt(to_dev(w), 1e-5))
+    assert np.array_equal(m, np.where(w > np.float32(1e-5), 255, 0).astype(np.uint8))
+    inv = host(ms.compare_eq(to_dev(m), 0))
+    assert np.array_equal(inv, np.where(m == 0, 255, 0).astype(np.uint8))
+    img = rng.integers(-500, 500, size=(40, 77, 3), dtype=np.int16)
+    d = to_dev(img)
+    ms.set_zero_masked(d, to_dev(inv))
+    img[inv != 0] = 0
+    assert np.array_equal(host(d), img)
+    a = rng.integers(0, 2, size=(40, 77), dtype=np.uint8) * 255
+    assert np.array_equal(host(ms.bitwise_and(to_dev(a), to_dev(m))), a & m)
+    assert np.array_equal(host(ms.dilate3x3(to_dev(a))), oracle.dilate3x3_8u(a))
+
+
+@pytest.mark.parametrize("proj", ["plane", "cylindrical", "spherical"])
+def test_build_warp_maps(ms, cuda, oracle, proj):
+    """ocl/test_warpers.cpp:85-165: K = I-ish intrinsics, 30-degree roll, scale 2 -> tolerance 1e-4 (the reference's
+    own device-vs-CPU bound; device sinf/cosf are not glibc's)."""
+    import synth
+    pid = {"plane": ms.PROJ_PLANE, "cylindrical": ms.PROJ_CYLINDRICAL, "spherical": ms.PROJ_SPHERICAL}[proj]
+    K = np.eye(3, dtype=np.float32)
+    a = math.radians(30)
+    R = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]], np.float32)
+    k_rinv = oracle.k_rinv_gpu(K, R)
+    mx, my = ms.build_warp_maps(pid, -3, 2, 64, 97, k_rinv, 2.0, t=(0.1, 0.0, 0.2) if proj == "plane" else None)
+    rx, ry = oracle.build_warp_maps(pid, -3, 2, 64, 97, k_rinv, 2.0, t=(0.1, 0.0, 0.2) if proj == "plane" else (0, 0, 0))
+    for g, r in ((host(mx), rx), (host(my), ry)):
+        ok = np.isclose(g, r, rtol=1e-4, atol=1e-4) | ((np.abs(r) > 1e3) & np.isclose(g, r, rtol=1e-2))
+        assert ok.all(), float(np.abs(g - r)[~ok].max())
+    # the hot-path rig (f=960, scale 611): sub-1e-3 px agreement with the glibc-evaluated oracle maps
+    K, R = synth.camera(6, 1920, 1080, 90.0, 1)
+    k_rinv = oracle.k_rinv_gpu(K, R)
+    mx, my = ms.build_warp_maps(ms.PROJ_SPHERICAL, 160, 646, 627, 960, k_rinv, synth.warp_scale(3840))
+    rx, ry = oracle.build_warp_maps(ms.PROJ_SPHERICAL, 160, 646, 627, 960, k_rinv, synth.warp_scale(3840))
+    assert np.abs(host(mx) - rx).max() < 2e-3 and np.abs(host(my) - ry).max() < 2e-3
+
+
+def test_custom_resize(ms, cuda, oracle):
+    rng = rng_for("cres")
+    src = (rng.random((10, 12), dtype=np.float32) * 900).astype(np.float32)
+    src[3, 4] = np.nan
+    got = host(ms.custom_resize(to_dev(src), 961, 627))
+    ref = oracle.custom_resize_32f(src, 961, 627)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+
+
+def test_argument_errors(ms, cuda):
+    a = torch.zeros((8, 8, 3), dtype=torch.uint8, device=cuda)
+    f = torch.zeros((8, 8), dtype=torch.float32, device=cuda)
+    with pytest.raises(ms.MsError, match="size mismatch"):
+        ms.remap(a, f, f[:4], ms.INTER_LINEAR)
+    with pytest.raises(ms.MsError, match="not on the hot path"):
+        ms.copy_make_border(f, 1, 1, 1, 1, ms.BORDER_REFLECT)
+    with pytest.raises(ms.MsError, match="at least 2x2"):
+        ms.custom_resize(f[:1], 8, 8)

@@ -1,0 +1,82 @@
+// common.hpp -- shared host/device helpers of libmsstitch (gfx950 only; no CPU fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/ms_stitch.h"
+
+namespace ms {
+
+// ---- error plumbing: status code + thread-local message (never throw across the C ABI) ----------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+int require_device();
+
+#define MS_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return ::ms::fail(MS_ERR_HIP, "%s: %s (%s:%d)", #expr,              \
+                                                hipGetErrorString(e_), __FILE__, __LINE__);       \
+    } while (0)
+
+#define MS_CHECK(cond, ...)                                                                       \
+    do { if (!(cond)) return ::ms::fail(MS_ERR_INVALID, __VA_ARGS__); } while (0)
+
+#define MS_LAUNCH_CHECK() MS_HIP(hipGetLastError())
+
+static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+static inline hipStream_t as_stream(ms_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device arithmetic with the reference's rounding semantics ----------------------------------
+// saturate_cast<uchar>(float) == cvt.rni.sat.u8.f32 (round-half-even, clamp, NaN -> 0)
+__device__ __forceinline__ uint8_t sat_u8(float v)
+{
+    float r = __builtin_rintf(v);
+    r = __builtin_fminf(__builtin_fmaxf(r, 0.f), 255.f);   // fmax(NaN, 0) = 0
+    return (uint8_t)(int)r;
+}
+// saturate_cast<short>(float) == cvt.rni.sat.s16.f32
+__device__ __forceinline__ int16_t sat_s16(float v)
+{
+    float r = __builtin_rintf(v);
+    r = __builtin_fminf(__builtin_fmaxf(r, -32768.f), 32767.f);
+    return (int16_t)(int)r;
+}
+__device__ __forceinline__ int16_t sat_s16(int v)
+{
+    return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+}
+// static_cast<short>(float) == cvt.rzi.s32.f32, low 16 bits (v_cvt_i32_f32: rtz, saturating, NaN -> 0)
+__device__ __forceinline__ int16_t trunc_s16(float v) { return (int16_t)(int)v; }
+// __float2int_rd / __float2int_rz
+__device__ __forceinline__ int f2i_rd(float v) { return (int)__builtin_floorf(v); }
+__device__ __forceinline__ int f2i_rz(float v) { return (int)v; }
+
+// BORDER_REFLECT (cudev BrdReflect) and BORDER_REFLECT_101 (BrdReflect101) index maps
+__device__ __forceinline__ int reflect_idx(int i, int len)
+{
+    const int last = len - 1;
+    const int hi = last - abs(last - i) + (i > last);
+    return (abs(hi) - (hi < 0)) % len;
+}
+__device__ __forceinline__ int r101_low(int i, int len) { return abs(i) % len; }
+__device__ __forceinline__ int r101_high(int i, int len) { const int last = len - 1; return abs(last - abs(last - i)) % len; }
+__device__ __forceinline__ int r101(int i, int len) { return r101_low(r101_high(i, len), len); }
+// pyrUp source index: min(n-1, |i|)
+__device__ __forceinline__ int pu_idx(int i, int n) { i = abs(i); return i < n - 1 ? i : n - 1; }
+
+// exact integer forms of the 16S pyramids (the fp32 sums in the CUDA kernels are exact dyadics,
+// so round-half-even of S/2^k reproduces saturate_cast<short>(float) bit for bit)
+__device__ __forceinline__ int rne_shift(int s, int k)
+{
+    return (s + ((1 << (k - 1)) - 1) + ((s >> k) & 1)) >> k;
+}
+
+template <typename T>
+__device__ __forceinline__ T *row_ptr(void *base, size_t step, int y) { return (T *)((char *)base + (size_t)y * step); }
+template <typename T>
+__device__ __forceinline__ const T *row_ptr(const void *base, size_t step, int y) { return (const T *)((const char *)base + (size_t)y * step); }
+
+}  // namespace ms

@@ -1,0 +1,974 @@
+// compositor.hip -- the per-frame fast path: stitch_one (APP/timed.cpp:123-152) as a short sequence of
+// batched HIP launches over ALL views (and all frames of a batch) at once.
+//
+//   reference, per view                                   here, per frame batch
+//   -----------------------------------------------       ------------------------------------------
+//   remap -> convertTo(gain) -> [remap(mesh)]             k_warp: remap+gain(+CPW stage)+reflect pad,
+//   copyMakeBorder(REFLECT) -> convertTo(16S)                     writes Gaussian level 0 (planar u8)
+//   nb x pyrDown                                          k_down x nb (all views x 3 planes)
+//   nb x (pyrUp, subtract), (nb+1) x addSrcWeight         k_blend x (nb+1), coarse -> fine: Laplacian on
+//   (nb+1) x normalize, nb x (pyrUp, add)                         the fly, weighted sum over the views
+//   compare, compare, setTo, convertTo(out), 12 memsets           covering the pixel (gather, no RMW), divide
+//                                                                 by the frame-invariant weight sum, add the
+//                                                                 expanded coarser level, final mask + 8U/16S
+//
+// HBM layout (all planar, per frame): level 0 of every view as u8 (it IS the widened 8U image),
+// levels 1..nb as int16; collapsed pano levels 1..nb as int16; weights/denominators fp32 (static).
+// Results are bit-identical to the reference's kernel sequence (oracle: oracle/ms_oracle_blend.c):
+// the 16S pyramids are evaluated in exact integer arithmetic, accumulate/normalise keep the fp32
+// multiply/divide + truncation, and int16 accumulation wraps exactly like `short +=`.
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+#include "common.hpp"
+#include "launchers.hpp"
+
+namespace ms {
+
+constexpr int MAX_LEVELS = 8;     // num_bands <= 7
+constexpr int MAX_VIEWS = 16;
+constexpr int MAX_SRC = 128;      // frames * views per ms_stitch call
+constexpr int MAX_FRAMES = 32;    // frames per ms_stitch call
+
+struct LevelDesc {
+    int w, h, pitch;              // level size; pitch in elements
+    int x_tl, y_tl;               // position inside the padded pano at this level
+    long long off;                // element offset of plane 0 inside the per-frame pyramid buffer
+    const float *wgt;             // weight pyramid level (static)
+    int wpitch;
+};
+struct ViewDesc {
+    int aw, ah;                   // warped view size (warpRoi)
+    int top, left;                // reflect border
+    int pw, ph;                   // padded size
+    float gain;
+    const float *xmap, *ymap;     // projection maps (static), pitch in elements
+    int map_pitch;
+    long long s1_off;             // byte offset of the CPW stage-1 image inside the per-frame stage buffer
+    LevelDesc lv[MAX_LEVELS];
+};
+struct PanoDesc {
+    int nb, n_views;
+    int qw[MAX_LEVELS], qh[MAX_LEVELS], qpitch[MAX_LEVELS];
+    long long coff[MAX_LEVELS];   // element offset of collapsed level l (l >= 1) in the per-frame buffer
+    const float *den[MAX_LEVELS]; // sum_v w_v + 1e-5f (static)
+    int dpitch[MAX_LEVELS];
+    const uint8_t *mask;          // gpu_dst_mask_ over dst_roi_final
+    int mask_pitch;
+    int fw, fh;                   // dst_roi_final size
+    int canvas_x, canvas_y, out_w, out_h;
+};
+struct SrcTable { const uint8_t *p[MAX_SRC]; unsigned step[MAX_SRC]; };
+struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pitch[MAX_VIEWS]; };
+struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *p16[MAX_FRAMES]; unsigned step16[MAX_FRAMES]; };
+
+// ------------------------------------------------------------------------------------------------
+// bilinear sample of an interleaved 8UC3 image, constant-0 border (remap.cu:56-68 + filters.hpp:90-114)
+__device__ __forceinline__ void sample3(const uint8_t *__restrict__ src, unsigned sstep, int srows, int scols,
+                                        float xc, float yc, float out[3])
+{
+    const int x1 = f2i_rd(xc), y1 = f2i_rd(yc);
+    const int x2 = (int)((unsigned)x1 + 1u), y2 = (int)((unsigned)y1 + 1u);
+    const float wx2 = (float)x2 - xc, wx1 = xc - (float)x1;
+    const float wy2 = (float)y2 - yc, wy1 = yc - (float)y1;
+    const float w[4] = {wx2 * wy2, wx1 * wy2, wx2 * wy1, wx1 * wy1};
+    const int xs[4] = {x1, x2, x1, x2};
+    const int ys[4] = {y1, y1, y2, y2};
+    out[0] = out[1] = out[2] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool inb = xs[t] >= 0 && xs[t] < scols && ys[t] >= 0 && ys[t] < srows;
+        const uint8_t *p = src + (size_t)(inb ? ys[t] : 0) * sstep + (size_t)(inb ? xs[t] : 0) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = __builtin_fmaf(inb ? (float)p[c] : 0.f, w[t], out[c]);
+    }
+}
+
+// CPW stage 1 (only when enable_cpw): images[i] = gain(remap(full_img, x_map, y_map))  timed.cpp:90-94
+__global__ void __launch_bounds__(256) k_remap_gain(const ViewDesc *__restrict__ views, int n_views, SrcTable src,
+                                                    int src_rows, int src_cols, uint8_t *__restrict__ stage, long long stage_stride)
+{
+    const int v = blockIdx.z % n_views, f = blockIdx.z / n_views;
+    const ViewDesc &V = views[v];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= V.aw || y >= V.ah) return;
+    const float xc = V.xmap[(size_t)y * V.map_pitch + x], yc = V.ymap[(size_t)y * V.map_pitch + x];
+    float o[3];
+    sample3(src.p[blockIdx.z], src.step[blockIdx.z], src_rows, src_cols, xc, yc, o);
+    uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + ((size_t)y * V.aw + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+}
+
+// Gaussian level 0 of every view: (remap -> gain) or (remap through the mesh of the stage-1 image),
+// BORDER_REFLECT pad folded into the source index, planar u8 output.
+template <bool CPW>
+__global__ void __launch_bounds__(256) k_warp(const ViewDesc *__restrict__ views, int n_views, SrcTable src, int src_rows, int src_cols,
+                                              MeshTable mesh, const uint8_t *__restrict__ stage, long long stage_stride,
+                                              uint8_t *__restrict__ g0, long long g0_stride)
+{
+    const int v = blockIdx.z % n_views, f = blockIdx.z / n_views;
+    const ViewDesc &V = views[v];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= V.pw || y >= V.ph) return;
+    const int ax = reflect_idx(x - V.left, V.aw), ay = reflect_idx(y - V.top, V.ah);
+    float o[3];
+    uint8_t r[3];
+    if (CPW) {
+        const float xc = mesh.x[v][(size_t)ay * mesh.pitch[v] + ax], yc = mesh.y[v][(size_t)ay * mesh.pitch[v] + ax];
+        sample3(stage + (size_t)f * stage_stride + V.s1_off, (unsigned)(V.aw * 3), V.ah, V.aw, xc, yc, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = sat_u8(o[c]);
+    } else {
+        const float xc = V.xmap[(size_t)ay * V.map_pitch + ax], yc = V.ymap[(size_t)ay * V.map_pitch + ax];
+        sample3(src.p[blockIdx.z], src.step[blockIdx.z], src_rows, src_cols, xc, yc, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+    }
+    const LevelDesc &L = V.lv[0];
+    uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)y * L.pitch + x;
+    const size_t plane = (size_t)L.h * L.pitch;
+    d[0] = r[0]; d[plane] = r[1]; d[2 * plane] = r[2];
+}
+
+// pyrDown of one plane of one view: level l -> l+1 (pyr_down.cu:55-174 in exact integer form)
+template <typename TIN>
+__global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views, int n_views, int l,
+                                              const TIN *__restrict__ gin, long long in_stride,
+                                              int16_t *__restrict__ gout, long long out_stride)
+{
+    const int z = blockIdx.z, c = z % 3, v = (z / 3) % n_views, f = z / (3 * n_views);
+    const LevelDesc &Li = views[v].lv[l], &Lo = views[v].lv[l + 1];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= Lo.w || y >= Lo.h) return;
+    const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
+    const int sy = 2 * y, sx = 2 * x;
+    const int ry[5] = {r101_low(sy - 2, Li.h), r101_low(sy - 1, Li.h), sy, r101_high(sy + 1, Li.h), r101_high(sy + 2, Li.h)};
+    int cx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cx[k] = r101(sx - 2 + k, Li.w);
+    const int wv[5] = {1, 4, 6, 4, 1};
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const TIN *r = in + (size_t)ry[j] * Li.pitch;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc += wv[j] * wv[k] * (int)r[cx[k]];
+    }
+    gout[(size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + x] = sat_s16(rne_shift(acc, 8));
+}
+
+// pyrUp of a 2x2 quad whose top-left fine pixel is (2i, 2j), from a planar int16 coarse level
+// (pyr_up.cu:55-145 in exact integer form).  out[0..3] = (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1).
+__device__ __forceinline__ void up_quad(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j, int out[4])
+{
+    const int r0 = pu_idx(i - 1, ch), r1 = pu_idx(i, ch), r2 = pu_idx(i + 1, ch);
+    const int c0 = pu_idx(j - 1, cw), c1 = pu_idx(j, cw), c2 = pu_idx(j + 1, cw);
+    const int16_t *p0 = cs + (size_t)r0 * cpitch, *p1 = cs + (size_t)r1 * cpitch, *p2 = cs + (size_t)r2 * cpitch;
+    const int a00 = p0[c0], a01 = p0[c1], a02 = p0[c2];
+    const int a10 = p1[c0], a11 = p1[c1], a12 = p1[c2];
+    const int a20 = p2[c0], a21 = p2[c1], a22 = p2[c2];
+    // horizontal: even column (1,6,1), odd column (4,4)
+    const int he0 = a00 + 6 * a01 + a02, ho0 = 4 * (a01 + a02);
+    const int he1 = a10 + 6 * a11 + a12, ho1 = 4 * (a11 + a12);
+    const int he2 = a20 + 6 * a21 + a22, ho2 = 4 * (a21 + a22);
+    out[0] = rne_shift(he0 + 6 * he1 + he2, 6);
+    out[1] = rne_shift(ho0 + 6 * ho1 + ho2, 6);
+    out[2] = rne_shift(4 * (he1 + he2), 6);
+    out[3] = rne_shift(4 * (ho1 + ho2), 6);
+}
+
+// coarsest band: C_nb = trunc( sum_v trunc(G_{v,nb} * w_{v,nb}) / den_nb )   (L_nb = G_nb)
+__global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ views, PanoDesc P,
+                                                   const uint8_t *__restrict__ g0, long long g0_stride,
+                                                   const int16_t *__restrict__ gl, long long gl_stride,
+                                                   int16_t *__restrict__ cl, long long cl_stride)
+{
+    const int l = P.nb, f = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= P.qw[l] || y >= P.qh[l]) return;
+    int16_t acc[3] = {0, 0, 0};
+    for (int v = 0; v < P.n_views; ++v) {
+        const LevelDesc &L = views[v].lv[l];
+        const int lx = x - L.x_tl, ly = y - L.y_tl;
+        if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
+        const float w = L.wgt[(size_t)ly * L.wpitch + lx];
+        const size_t plane = (size_t)L.h * L.pitch, o = (size_t)ly * L.pitch + lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int g = (l == 0) ? (int)g0[(size_t)f * g0_stride + L.off + c * plane + o]
+                                   : (int)gl[(size_t)f * gl_stride + L.off + c * plane + o];
+            acc[c] = (int16_t)(acc[c] + trunc_s16((float)g * w));
+        }
+    }
+    const float den = P.den[l][(size_t)y * P.dpitch[l] + x];
+    const size_t plane = (size_t)P.qh[l] * P.qpitch[l];
+    int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)y * P.qpitch[l] + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c * plane] = trunc_s16((float)acc[c] / den);
+}
+
+// band l < nb, one 2x2 quad per thread:
+//   N_l = trunc( sum_v trunc( sat(G_{v,l} - up(G_{v,l+1})) * w_{v,l} ) / den_l ),  C_l = sat(up(C_{l+1}) + N_l)
+// L0 (l == 0): fine level is the u8 level-0 buffer and the result goes to the outputs
+//   (mask = gpu_dst_mask_, setTo(0, !mask), convertTo 16S out, convertTo 8U canvas).
+template <bool L0>
+__global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ views, PanoDesc P, int l,
+                                               const uint8_t *__restrict__ g0, long long g0_stride,
+                                               const int16_t *__restrict__ gl, long long gl_stride,
+                                               int16_t *__restrict__ cl, long long cl_stride, OutTable out)
+{
+    const int f = blockIdx.z;
+    const int qx = blockIdx.x * 64 + threadIdx.x, qy = blockIdx.y * 4 + threadIdx.y;
+    if (2 * qx >= P.qw[l] || 2 * qy >= P.qh[l]) return;
+    const int x0 = 2 * qx, y0 = 2 * qy;
+    int16_t acc[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
+
+    for (int v = 0; v < P.n_views; ++v) {
+        const LevelDesc &L = views[v].lv[l];
+        const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
+        if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;   // rects are even-aligned below level nb
+        const LevelDesc &C = views[v].lv[l + 1];
+        const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
+        const float w[4] = {wp[0], wp[1], wp[L.wpitch], wp[L.wpitch + 1]};
+        const size_t fplane = (size_t)L.h * L.pitch, cplane = (size_t)C.h * C.pitch;
+        const size_t fo = (size_t)ly * L.pitch + lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int up[4];
+            up_quad(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up);
+            int g[4];
+            if (L0) {
+                const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + c * fplane + fo;
+                g[0] = p[0]; g[1] = p[1]; g[2] = p[L.pitch]; g[3] = p[L.pitch + 1];
+            } else {
+                const int16_t *p = gl + (size_t)f * gl_stride + L.off + c * fplane + fo;
+                g[0] = p[0]; g[1] = p[1]; g[2] = p[L.pitch]; g[3] = p[L.pitch + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lap = sat_s16(g[k] - (int)sat_s16(up[k]));
+                acc[c][k] = (int16_t)(acc[c][k] + trunc_s16((float)lap * w[k]));
+            }
+        }
+    }
+
+    const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
+    const float den[4] = {dp[0], dp[1], dp[P.dpitch[l]], dp[P.dpitch[l] + 1]};
+    const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
+    const int16_t *cc = cl + (size_t)f * cl_stride + P.coff[l + 1];
+    int res[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int up[4];
+        up_quad(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], qy, qx, up);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            res[c][k] = sat_s16((int)sat_s16(up[k]) + (int)trunc_s16((float)acc[c][k] / den[k]));
+    }
+
+    if (!L0) {
+        const size_t plane = (size_t)P.qh[l] * P.qpitch[l];
+        int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)y0 * P.qpitch[l] + x0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            d[c * plane] = (int16_t)res[c][0]; d[c * plane + 1] = (int16_t)res[c][1];
+            d[c * plane + P.qpitch[l]] = (int16_t)res[c][2]; d[c * plane + P.qpitch[l] + 1] = (int16_t)res[c][3];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + (k & 1), y = y0 + (k >> 1);
+            if (x >= P.fw || y >= P.fh) continue;               // dst_rc = unpadded ROI (blenders.cpp:762)
+            const bool m = P.mask[(size_t)y * P.mask_pitch + x] != 0;
+            const int b = m ? res[0][k] : 0, g = m ? res[1][k] : 0, r = m ? res[2][k] : 0;
+            if (out.p16[f]) {
+                int16_t *d = (int16_t *)((char *)out.p16[f] + (size_t)y * out.step16[f]) + 3 * x;
+                d[0] = (int16_t)b; d[1] = (int16_t)g; d[2] = (int16_t)r;
+            }
+            if (out.p8[f]) {
+                const int cx = x + P.canvas_x, cy = y + P.canvas_y;
+                if (cx >= 0 && cx < P.out_w && cy >= 0 && cy < P.out_h) {
+                    uint8_t *d = out.p8[f] + (size_t)cy * out.step8[f] + 3 * cx;
+                    d[0] = (uint8_t)min(max(b, 0), 255); d[1] = (uint8_t)min(max(g, 0), 255); d[2] = (uint8_t)min(max(r, 0), 255);
+                }
+            }
+        }
+    }
+}
+
+// ---- static-table kernels ---------------------------------------------------------------------
+// warp(255-mask, INTER_NEAREST, BORDER_CONSTANT) == "does the truncated map coordinate hit the source"
+__global__ void __launch_bounds__(256) k_valid_mask(const float *__restrict__ mx, const float *__restrict__ my, int pitch, int rows, int cols,
+                                                    int src_rows, int src_cols, uint8_t *__restrict__ mask, int mpitch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const int xx = f2i_rz(mx[(size_t)y * pitch + x]), yy = f2i_rz(my[(size_t)y * pitch + x]);
+    mask[(size_t)y * mpitch + x] = (xx >= 0 && xx < src_cols && yy >= 0 && yy < src_rows) ? 255 : 0;
+}
+// dst_w(rc) += w   (the weight half of addSrcWeightKernel32F, run once: the sums are frame-invariant)
+__global__ void __launch_bounds__(256) k_acc_weight(const float *__restrict__ w, int wpitch, int rows, int cols, float *dst, int dpitch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    dst[(size_t)y * dpitch + x] = dst[(size_t)y * dpitch + x] + w[(size_t)y * wpitch + x];
+}
+// den = sum + WEIGHT_EPS ; mask = sum > WEIGHT_EPS (level 0, unpadded ROI)
+__global__ void __launch_bounds__(256) k_finish_den(float *den, int dpitch, int rows, int cols, uint8_t *mask, int mpitch, int mrows, int mcols)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float s = den[(size_t)y * dpitch + x];
+    if (mask && x < mcols && y < mrows) mask[(size_t)y * mpitch + x] = s > 1e-5f ? 255 : 0;
+    den[(size_t)y * dpitch + x] = s + 1e-5f;
+}
+// CPW mesh -> backward map: scatter-average (APP/meshwarper.cpp:859-875)
+__global__ void __launch_bounds__(256) k_mesh_scatter(const float *__restrict__ bx, const float *__restrict__ by, int pitch, int rows, int cols,
+                                                      float *sx, float *sy, float *cnt, int hw, int hh)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float fx = bx[(size_t)y * pitch + x], fy = by[(size_t)y * pitch + x];
+    if (!(fx > -2147483648.f && fx < 2147483648.f && fy > -2147483648.f && fy < 2147483648.f)) return;
+    const int x_ = (int)fx / 2, y_ = (int)fy / 2;
+    if (x_ >= 0 && y_ >= 0 && x_ < hw && y_ < hh) {
+        atomicAdd(&sx[(size_t)y_ * hw + x_], (float)x);   // integer-valued partial sums: order-independent while < 2^24
+        atomicAdd(&sy[(size_t)y_ * hw + x_], (float)y);
+        atomicAdd(&cnt[(size_t)y_ * hw + x_], 1.f);
+    }
+}
+__global__ void __launch_bounds__(256) k_mesh_mean(float *sx, float *sy, const float *__restrict__ cnt, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    sx[i] = sx[i] / cnt[i];     // 0/0 -> NaN hole, as the reference (remap then yields 0)
+    sy[i] = sy[i] / cnt[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0) n = 16;
+        MS_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return MS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace ms
+
+using namespace ms;
+
+struct ms_ctx {
+    ms_config cfg{};
+    int N = 0;
+    float K[MAX_VIEWS][9], R[MAX_VIEWS][9];
+    bool have_cam[MAX_VIEWS] = {};
+    double gain[MAX_VIEWS];
+    // stage flags
+    bool maps_built = false, masks_built = false, blender_ready = false;
+    // geometry
+    ms_rect roi[MAX_VIEWS];
+    BlendGeom bg{};
+    ViewPad pad[MAX_VIEWS];
+    // static device tables
+    DevBuf maps;                       // per view xmap | ymap
+    size_t map_off[MAX_VIEWS] = {};    // float offset of xmap; ymap follows at + ah*pitch
+    int map_pitch[MAX_VIEWS] = {};
+    DevBuf masks;                      // per view 8UC1 (aw x ah, pitch = aw)
+    size_t mask_off[MAX_VIEWS] = {};
+    DevBuf weights;                    // per view per level fp32
+    size_t w_off[MAX_VIEWS][MAX_LEVELS] = {};
+    DevBuf den;                        // per level fp32 over the padded pano
+    size_t den_off[MAX_LEVELS] = {};
+    DevBuf result_mask;                // 8UC1 fw x fh
+    DevBuf view_tab;                   // ViewDesc[N]
+    std::vector<ViewDesc> h_views;
+    PanoDesc pano{};
+    // per-batch device buffers
+    DevBuf g0, gl, cl, stage;
+    long long g0_stride = 0, gl_stride = 0, cl_stride = 0, stage_stride = 0;
+    int max_pw = 0, max_ph = 0, max_aw = 0, max_ah = 0;
+    // CPW mesh maps, double buffered
+    DevBuf mesh[2];
+    size_t mesh_off[MAX_VIEWS] = {};
+    int mesh_active[MAX_VIEWS] = {};   // which buffer ms_stitch reads for this view
+    bool mesh_set[MAX_VIEWS] = {};
+    DevBuf mesh_tmp;                   // scratch for convertMeshesToMap
+    std::mutex mesh_mu;
+    hipEvent_t last_stitch = nullptr;
+    bool stitch_pending = false;
+    int canvas_x = 0, canvas_y = 0;
+};
+
+namespace ms {
+
+static int ctx_check_view(const ms_ctx *c, int v)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    if (v < 0 || v >= c->N) return fail(MS_ERR_INVALID, "view index %d out of range [0,%d)", v, c->N);
+    return MS_OK;
+}
+
+static ms_image view_map_image(const ms_ctx *c, int v, int which)
+{
+    ms_image m;
+    const int aw = c->roi[v].width, ah = c->roi[v].height;
+    float *base = (float *)c->maps.p + c->map_off[v] + (which ? (size_t)ah * c->map_pitch[v] : 0);
+    m.data = base; m.step = (size_t)c->map_pitch[v] * sizeof(float); m.rows = ah; m.cols = aw; m.type = MS_32FC1;
+    return m;
+}
+
+}  // namespace ms
+
+extern "C" {
+
+int ms_create(const ms_config *cfg, ms_ctx **out)
+{
+    if (!cfg || !out) return fail(MS_ERR_INVALID, "ms_create: null argument");
+    if (int e = require_device()) return e;
+    MS_CHECK(cfg->num_views >= 1 && cfg->num_views <= MAX_VIEWS, "ms_create: num_views %d not in [1,%d]", cfg->num_views, MAX_VIEWS);
+    MS_CHECK(cfg->src_width > 1 && cfg->src_height > 1, "ms_create: bad source size %dx%d", cfg->src_width, cfg->src_height);
+    MS_CHECK(cfg->projection >= MS_PROJ_PLANE && cfg->projection <= MS_PROJ_SPHERICAL, "ms_create: bad projection %d", cfg->projection);
+    MS_CHECK(cfg->warp_scale > 0.f, "ms_create: warp_scale must be positive");
+    MS_CHECK(cfg->num_bands >= 0 && cfg->num_bands < MAX_LEVELS, "ms_create: num_bands %d not in [0,%d)", cfg->num_bands, MAX_LEVELS);
+    const int F = cfg->max_frames > 0 ? cfg->max_frames : 1;
+    MS_CHECK(F <= MAX_FRAMES && F * cfg->num_views <= MAX_SRC, "ms_create: max_frames %d (x %d views) exceeds the per-call limits %d / %d", F, cfg->num_views, MAX_FRAMES, MAX_SRC);
+    ms_ctx *c = new (std::nothrow) ms_ctx();
+    if (!c) return fail(MS_ERR_NOMEM, "ms_create: out of host memory");
+    c->cfg = *cfg;
+    c->cfg.max_frames = F;
+    c->N = cfg->num_views;
+    for (int i = 0; i < MAX_VIEWS; ++i) c->gain[i] = 1.0;
+    if (hipEventCreateWithFlags(&c->last_stitch, hipEventDisableTiming) != hipSuccess) { delete c; return fail(MS_ERR_HIP, "hipEventCreate failed"); }
+    *out = c;
+    return MS_OK;
+}
+
+void ms_destroy(ms_ctx *c)
+{
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    c->maps.release(); c->masks.release(); c->weights.release(); c->den.release(); c->result_mask.release();
+    c->view_tab.release(); c->g0.release(); c->gl.release(); c->cl.release(); c->stage.release();
+    c->mesh[0].release(); c->mesh[1].release(); c->mesh_tmp.release();
+    if (c->last_stitch) (void)hipEventDestroy(c->last_stitch);
+    delete c;
+}
+
+int ms_set_camera(ms_ctx *c, int view, const float *K, const float *R)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    MS_CHECK(K && R, "ms_set_camera: null matrix");
+    memcpy(c->K[view], K, sizeof(float) * 9);
+    memcpy(c->R[view], R, sizeof(float) * 9);
+    c->have_cam[view] = true;
+    c->maps_built = c->masks_built = c->blender_ready = false;
+    return MS_OK;
+}
+
+int ms_set_gain(ms_ctx *c, int view, double gain)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    c->gain[view] = gain;
+    if (c->blender_ready) {   // keep the device table in sync (gains change at recalibration only)
+        c->h_views[view].gain = (float)gain;
+        MS_HIP(hipMemcpy((ViewDesc *)c->view_tab.p + view, &c->h_views[view], sizeof(ViewDesc), hipMemcpyHostToDevice));
+    }
+    return MS_OK;
+}
+
+int ms_build_maps(ms_ctx *c, ms_stream stream)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    hipStream_t st = as_stream(stream);
+    for (int i = 0; i < c->N; ++i)
+        if (!c->have_cam[i]) return fail(MS_ERR_STATE, "ms_build_maps: camera %d not set", i);
+    const int W = c->cfg.src_width, H = c->cfg.src_height;
+    size_t total = 0;
+    for (int i = 0; i < c->N; ++i) {
+        Projector p;
+        set_camera_params(p, c->K[i], c->R[i], nullptr, c->cfg.warp_scale);
+        c->roi[i] = warp_roi(c->cfg.projection, p, W, H);
+        MS_CHECK(c->roi[i].width > 0 && c->roi[i].height > 0, "ms_build_maps: empty ROI for view %d", i);
+        c->map_pitch[i] = round_up(c->roi[i].width, 4);
+        c->map_off[i] = total;
+        total += (size_t)2 * c->roi[i].height * c->map_pitch[i];
+    }
+    if (int e = c->maps.alloc(total * sizeof(float))) return e;
+    for (int i = 0; i < c->N; ++i) {
+        float k_rinv[9];
+        k_rinv_gemm(c->K[i], c->R[i], k_rinv);   // warpers_cuda.cpp:108
+        ms_image mx = view_map_image(c, i, 0), my = view_map_image(c, i, 1);
+        if (int e = launch_build_warp_maps(c->cfg.projection, c->roi[i].x, c->roi[i].y, mx, my, k_rinv, nullptr, c->cfg.warp_scale, st)) return e;
+    }
+    // blender->prepare(corners, sizes)
+    c->bg = blender_prepare(result_roi(c->N, c->roi), c->cfg.num_bands);
+    for (int i = 0; i < c->N; ++i)
+        c->pad[i] = blender_view_pad(c->bg, c->roi[i].x, c->roi[i].y, c->roi[i].width, c->roi[i].height);
+    c->canvas_x = c->bg.dst_roi.x + c->cfg.out_width / 2;
+    c->canvas_y = c->cfg.projection == MS_PROJ_SPHERICAL ? c->bg.dst_roi.y : c->bg.dst_roi.y + c->cfg.out_height / 2;
+    MS_HIP(hipStreamSynchronize(st));
+    c->maps_built = true;
+    c->masks_built = c->blender_ready = false;
+    return MS_OK;
+}
+
+static int alloc_masks(ms_ctx *c)
+{
+    size_t total = 0;
+    for (int i = 0; i < c->N; ++i) { c->mask_off[i] = total; total += (size_t)c->roi[i].width * c->roi[i].height; }
+    return c->masks.bytes >= total && c->masks.p ? MS_OK : c->masks.alloc(total);
+}
+
+int ms_build_masks(ms_ctx *c, int mode, ms_stream stream)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_build_masks: call ms_build_maps first");
+    MS_CHECK(mode == 0 || mode == 1, "ms_build_masks: mode must be 0 or 1");
+    hipStream_t st = as_stream(stream);
+    if (int e = alloc_masks(c)) return e;
+    for (int i = 0; i < c->N; ++i) {
+        const int aw = c->roi[i].width, ah = c->roi[i].height;
+        ms_image mx = view_map_image(c, i, 0), my = view_map_image(c, i, 1);
+        k_valid_mask<<<dim3(div_up(aw, 64), div_up(ah, 4)), dim3(64, 4), 0, st>>>(
+            (const float *)mx.data, (const float *)my.data, c->map_pitch[i], ah, aw, c->cfg.src_height, c->cfg.src_width,
+            (uint8_t *)c->masks.p + c->mask_off[i], aw);
+        MS_LAUNCH_CHECK();
+    }
+    MS_HIP(hipStreamSynchronize(st));
+    if (mode == 1) {   // seams on the host, exactly where the reference runs VoronoiSeamFinder
+        std::vector<std::vector<uint8_t>> hm(c->N);
+        std::vector<uint8_t *> ptr(c->N);
+        for (int i = 0; i < c->N; ++i) {
+            hm[i].resize((size_t)c->roi[i].width * c->roi[i].height);
+            MS_HIP(hipMemcpy(hm[i].data(), (uint8_t *)c->masks.p + c->mask_off[i], hm[i].size(), hipMemcpyDeviceToHost));
+            ptr[i] = hm[i].data();
+        }
+        voronoi_seams(c->N, c->roi, ptr.data());
+        for (int i = 0; i < c->N; ++i)
+            MS_HIP(hipMemcpy((uint8_t *)c->masks.p + c->mask_off[i], hm[i].data(), hm[i].size(), hipMemcpyHostToDevice));
+    }
+    c->masks_built = true;
+    c->blender_ready = false;
+    return MS_OK;
+}
+
+int ms_set_mask(ms_ctx *c, int view, const uint8_t *mask_host, size_t step)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_set_mask: call ms_build_maps first");
+    MS_CHECK(mask_host && step >= (size_t)c->roi[view].width, "ms_set_mask: bad mask/step");
+    if (int e = alloc_masks(c)) return e;
+    MS_HIP(hipMemcpy2D((uint8_t *)c->masks.p + c->mask_off[view], c->roi[view].width, mask_host, step,
+                       c->roi[view].width, c->roi[view].height, hipMemcpyHostToDevice));
+    c->masks_built = true;   // caller is responsible for setting every view
+    c->blender_ready = false;
+    return MS_OK;
+}
+
+int ms_init_blender(ms_ctx *c, ms_stream stream)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    if (!c->maps_built || !c->masks_built) return fail(MS_ERR_STATE, "ms_init_blender: maps and masks must be built first");
+    hipStream_t st = as_stream(stream);
+    const int nb = c->bg.num_bands, N = c->N, F = c->cfg.max_frames;
+
+    // ---- layout of every per-view level -------------------------------------------------------
+    c->h_views.assign(N, ViewDesc{});
+    size_t w_total = 0;
+    long long g0_total = 0, gl_total = 0, stage_total = 0;
+    c->max_pw = c->max_ph = c->max_aw = c->max_ah = 0;
+    for (int v = 0; v < N; ++v) {
+        ViewDesc &V = c->h_views[v];
+        V.aw = c->roi[v].width; V.ah = c->roi[v].height;
+        V.top = c->pad[v].top; V.left = c->pad[v].left;
+        V.pw = V.aw + c->pad[v].left + c->pad[v].right;
+        V.ph = V.ah + c->pad[v].top + c->pad[v].bottom;
+        V.gain = (float)c->gain[v];
+        V.xmap = (const float *)c->maps.p + c->map_off[v];
+        V.ymap = V.xmap + (size_t)V.ah * c->map_pitch[v];
+        V.map_pitch = c->map_pitch[v];
+        V.s1_off = stage_total;
+        stage_total += (long long)round_up(V.aw * V.ah * 3, 16);
+        c->max_pw = std::max(c->max_pw, V.pw); c->max_ph = std::max(c->max_ph, V.ph);
+        c->max_aw = std::max(c->max_aw, V.aw); c->max_ah = std::max(c->max_ah, V.ah);
+        int w = V.pw, h = V.ph, xt = c->pad[v].x_tl, yt = c->pad[v].y_tl;
+        for (int l = 0; l <= nb; ++l) {
+            LevelDesc &L = V.lv[l];
+            L.w = w; L.h = h; L.x_tl = xt; L.y_tl = yt;
+            L.pitch = round_up(w, l == 0 ? 16 : 8);
+            L.wpitch = round_up(w, 4);
+            c->w_off[v][l] = w_total;
+            w_total += (size_t)h * L.wpitch;
+            if (l == 0) { L.off = g0_total; g0_total += 3LL * h * L.pitch; }
+            else        { L.off = gl_total; gl_total += 3LL * h * L.pitch; }
+            w = (w + 1) / 2; h = (h + 1) / 2; xt /= 2; yt /= 2;
+        }
+    }
+    if (int e = c->weights.alloc(w_total * sizeof(float))) return e;
+    MS_HIP(hipMemsetAsync(c->weights.p, 0, w_total * sizeof(float), st));
+    for (int v = 0; v < N; ++v)
+        for (int l = 0; l <= nb; ++l) c->h_views[v].lv[l].wgt = (const float *)c->weights.p + c->w_off[v][l];
+
+    // ---- pano levels ----------------------------------------------------------------------------
+    PanoDesc &P = c->pano;
+    P = PanoDesc{};
+    P.nb = nb; P.n_views = N;
+    size_t den_total = 0;
+    long long cl_total = 0;
+    {
+        int w = c->bg.dst_roi.width, h = c->bg.dst_roi.height;
+        for (int l = 0; l <= nb; ++l) {
+            P.qw[l] = w; P.qh[l] = h; P.qpitch[l] = round_up(w, 8); P.dpitch[l] = round_up(w, 4);
+            c->den_off[l] = den_total; den_total += (size_t)h * P.dpitch[l];
+            P.coff[l] = cl_total;
+            if (l >= 1) cl_total += 3LL * h * P.qpitch[l];
+            w = (w + 1) / 2; h = (h + 1) / 2;
+        }
+    }
+    P.fw = c->bg.dst_roi_final.width; P.fh = c->bg.dst_roi_final.height;
+    P.mask_pitch = P.fw;
+    P.canvas_x = c->canvas_x; P.canvas_y = c->canvas_y; P.out_w = c->cfg.out_width; P.out_h = c->cfg.out_height;
+    if (int e = c->den.alloc(den_total * sizeof(float))) return e;
+    if (int e = c->result_mask.alloc((size_t)P.fw * P.fh)) return e;
+    MS_HIP(hipMemsetAsync(c->den.p, 0, den_total * sizeof(float), st));
+    for (int l = 0; l <= nb; ++l) P.den[l] = (const float *)c->den.p + c->den_off[l];
+    P.mask = (const uint8_t *)c->result_mask.p;
+
+    // ---- init_gpu per view, in view order: weight = mask/255 -> constant border -> nb x pyrDown,
+    //      and the weight sums (the `dst_w += w` of addSrcWeightKernel32F, blenders.cpp:729-746)
+    DevBuf wm;   // scratch weight_map of the largest view
+    if (int e = wm.alloc((size_t)c->max_aw * c->max_ah * sizeof(float))) return e;
+    for (int v = 0; v < N; ++v) {
+        ViewDesc &V = c->h_views[v];
+        ms_image mask{(uint8_t *)c->masks.p + c->mask_off[v], (size_t)V.aw, V.ah, V.aw, MS_8UC1};
+        ms_image wmap{wm.p, (size_t)V.aw * sizeof(float), V.ah, V.aw, MS_32FC1};
+        if (int e = launch_convert(mask, wmap, 1. / 255., st)) return e;                       // blenders.cpp:412
+        auto level_img = [&](int l) {
+            const LevelDesc &L = V.lv[l];
+            return ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.h, L.w, MS_32FC1};
+        };
+        ms_image l0 = level_img(0);
+        if (int e = launch_copy_make_border(wmap, l0, V.top, V.left, MS_BORDER_CONSTANT, st)) return e;   // :420
+        for (int l = 0; l < nb; ++l) {
+            ms_image a = level_img(l), b = level_img(l + 1);
+            if (int e = launch_pyr_down(a, b, st)) return e;                                  // :422-423
+        }
+        for (int l = 0; l <= nb; ++l) {
+            const LevelDesc &L = V.lv[l];
+            float *d = (float *)c->den.p + c->den_off[l] + (size_t)L.y_tl * P.dpitch[l] + L.x_tl;
+            k_acc_weight<<<dim3(div_up(L.w, 64), div_up(L.h, 4)), dim3(64, 4), 0, st>>>(L.wgt, L.wpitch, L.h, L.w, d, P.dpitch[l]);
+            MS_LAUNCH_CHECK();
+        }
+    }
+    for (int l = 0; l <= nb; ++l) {
+        k_finish_den<<<dim3(div_up(P.qw[l], 64), div_up(P.qh[l], 4)), dim3(64, 4), 0, st>>>(
+            (float *)c->den.p + c->den_off[l], P.dpitch[l], P.qh[l], P.qw[l],
+            l == 0 ? (uint8_t *)c->result_mask.p : nullptr, P.mask_pitch, P.fh, P.fw);
+        MS_LAUNCH_CHECK();
+    }
+    MS_HIP(hipStreamSynchronize(st));
+    wm.release();
+
+    // ---- per-batch buffers ----------------------------------------------------------------------
+    c->g0_stride = (g0_total + 255) / 256 * 256;
+    c->gl_stride = (gl_total + 127) / 128 * 128;
+    c->cl_stride = (cl_total + 127) / 128 * 128;
+    c->stage_stride = (stage_total + 255) / 256 * 256;
+    if (int e = c->g0.alloc((size_t)c->g0_stride * F)) return e;
+    if (int e = c->gl.alloc((size_t)c->gl_stride * F * sizeof(int16_t) + 64)) return e;
+    if (int e = c->cl.alloc((size_t)c->cl_stride * F * sizeof(int16_t) + 64)) return e;
+    if (c->cfg.enable_cpw) {
+        if (int e = c->stage.alloc((size_t)c->stage_stride * F)) return e;
+        size_t mtotal = 0;
+        for (int v = 0; v < N; ++v) { c->mesh_off[v] = mtotal; mtotal += (size_t)2 * c->h_views[v].ah * c->map_pitch[v]; }
+        for (int b = 0; b < 2; ++b) if (int e = c->mesh[b].alloc(mtotal * sizeof(float))) return e;
+        for (int v = 0; v < N; ++v) { c->mesh_active[v] = 0; c->mesh_set[v] = false; }
+    }
+    if (int e = c->view_tab.alloc(sizeof(ViewDesc) * N)) return e;
+    MS_HIP(hipMemcpy(c->view_tab.p, c->h_views.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice));
+    c->blender_ready = true;
+    return MS_OK;
+}
+
+// ---- CPW mesh maps ------------------------------------------------------------------------------
+static ms_image mesh_image(const ms_ctx *c, int buf, int v, int which)
+{
+    const int ah = c->roi[v].height, aw = c->roi[v].width;
+    float *base = (float *)c->mesh[buf].p + c->mesh_off[v] + (which ? (size_t)ah * c->map_pitch[v] : 0);
+    return ms_image{base, (size_t)c->map_pitch[v] * sizeof(float), ah, aw, MS_32FC1};
+}
+
+static int mesh_begin_update(ms_ctx *c, int view, int *target)
+{
+    if (!c->blender_ready || !c->cfg.enable_cpw) return fail(MS_ERR_STATE, "mesh update needs enable_cpw and ms_init_blender");
+    *target = c->mesh_set[view] ? 1 - c->mesh_active[view] : c->mesh_active[view];
+    // the inactive buffer may still be read by a stitch enqueued before the previous swap
+    if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
+    return MS_OK;
+}
+
+int ms_set_mesh_maps(ms_ctx *c, int view, const ms_image *xm, const ms_image *ym, ms_stream stream)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    MS_CHECK(xm && ym && xm->data && ym->data, "ms_set_mesh_maps: null image");
+    std::lock_guard<std::mutex> lk(c->mesh_mu);
+    int tgt;
+    if (int e = mesh_begin_update(c, view, &tgt)) return e;
+    const int aw = c->roi[view].width, ah = c->roi[view].height;
+    MS_CHECK(xm->rows == ah && xm->cols == aw && ym->rows == ah && ym->cols == aw && xm->type == MS_32FC1 && ym->type == MS_32FC1,
+             "ms_set_mesh_maps: maps must be 32FC1 %dx%d", aw, ah);
+    hipStream_t st = as_stream(stream);
+    ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
+    MS_HIP(hipMemcpy2DAsync(dx.data, dx.step, xm->data, xm->step, (size_t)aw * 4, ah, hipMemcpyDeviceToDevice, st));
+    MS_HIP(hipMemcpy2DAsync(dy.data, dy.step, ym->data, ym->step, (size_t)aw * 4, ah, hipMemcpyDeviceToDevice, st));
+    MS_HIP(hipStreamSynchronize(st));
+    c->mesh_active[view] = tgt;
+    c->mesh_set[view] = true;
+    return MS_OK;
+}
+
+int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, int N, int M, ms_stream stream)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    MS_CHECK(mesh_x && mesh_y && N >= 2 && M >= 2, "ms_set_mesh: need an N x M (>= 2x2) vertex mesh");
+    std::lock_guard<std::mutex> lk(c->mesh_mu);
+    int tgt;
+    if (int e = mesh_begin_update(c, view, &tgt)) return e;
+    hipStream_t st = as_stream(stream);
+    const int aw = c->roi[view].width, ah = c->roi[view].height, hw = aw / 2, hh = ah / 2;
+    MS_CHECK(hw >= 2 && hh >= 2, "ms_set_mesh: view too small");
+    // scratch: small mesh x|y, big x|y (ah x aw), half-res sum_x|sum_y|cnt
+    const size_t n_small = (size_t)N * M, n_big = (size_t)aw * ah, n_half = (size_t)hw * hh;
+    const size_t need = (2 * n_small + 2 * n_big + 3 * n_half) * sizeof(float);
+    if (c->mesh_tmp.bytes < need) if (int e = c->mesh_tmp.alloc(need)) return e;
+    float *sm_x = (float *)c->mesh_tmp.p, *sm_y = sm_x + n_small, *big_x = sm_y + n_small, *big_y = big_x + n_big;
+    float *sx = big_y + n_big, *sy = sx + n_half, *cnt = sy + n_half;
+    MS_HIP(hipMemcpyAsync(sm_x, mesh_x, n_small * 4, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(sm_y, mesh_y, n_small * 4, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemsetAsync(sx, 0, 3 * n_half * 4, st));
+    ms_image smx{sm_x, (size_t)M * 4, N, M, MS_32FC1}, smy{sm_y, (size_t)M * 4, N, M, MS_32FC1};
+    ms_image bx{big_x, (size_t)aw * 4, ah, aw, MS_32FC1}, by{big_y, (size_t)aw * 4, ah, aw, MS_32FC1};
+    if (int e = launch_custom_resize(smx, bx, st)) return e;            // meshwarper.cpp:838-839
+    if (int e = launch_custom_resize(smy, by, st)) return e;
+    k_mesh_scatter<<<dim3(div_up(aw, 64), div_up(ah, 4)), dim3(64, 4), 0, st>>>(big_x, big_y, aw, ah, aw, sx, sy, cnt, hw, hh);   // :859-869
+    MS_LAUNCH_CHECK();
+    k_mesh_mean<<<div_up((int)n_half, 256), 256, 0, st>>>(sx, sy, cnt, (int)n_half);                                          // :870-875
+    MS_LAUNCH_CHECK();
+    ms_image hx{sx, (size_t)hw * 4, hh, hw, MS_32FC1}, hy{sy, (size_t)hw * 4, hh, hw, MS_32FC1};
+    ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
+    if (int e = launch_custom_resize(hx, dx, st)) return e;             // :880,883
+    if (int e = launch_custom_resize(hy, dy, st)) return e;
+    MS_HIP(hipStreamSynchronize(st));
+    c->mesh_active[view] = tgt;
+    c->mesh_set[view] = true;
+    return MS_OK;
+}
+
+// ---- the per-frame path --------------------------------------------------------------------------
+static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
+                       int cap, const char **names, float *ms_out, int *n_rec)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_stitch: call ms_build_maps / masks / ms_init_blender first");
+    MS_CHECK(n_frames >= 1 && n_frames <= c->cfg.max_frames, "ms_stitch: n_frames %d not in [1,%d]", n_frames, c->cfg.max_frames);
+    MS_CHECK(views != nullptr, "ms_stitch: null views");
+    const int N = c->N, nb = c->pano.nb, F = n_frames;
+    const PanoDesc &P = c->pano;
+    SrcTable src{};
+    for (int i = 0; i < F * N; ++i) {
+        MS_CHECK(views[i].data && views[i].type == MS_8UC3 && views[i].rows == c->cfg.src_height && views[i].cols == c->cfg.src_width,
+                 "ms_stitch: view %d must be 8UC3 %dx%d", i, c->cfg.src_width, c->cfg.src_height);
+        src.p[i] = (const uint8_t *)views[i].data;
+        src.step[i] = (unsigned)views[i].step;
+    }
+    OutTable out{};
+    for (int f = 0; f < F; ++f) {
+        if (out8u && out8u[f].data) {
+            MS_CHECK(out8u[f].type == MS_8UC3 && out8u[f].rows == P.out_h && out8u[f].cols == P.out_w,
+                     "ms_stitch: out8u[%d] must be 8UC3 %dx%d", f, P.out_w, P.out_h);
+            out.p8[f] = (uint8_t *)out8u[f].data; out.step8[f] = (unsigned)out8u[f].step;
+        }
+        if (out16s && out16s[f].data) {
+            MS_CHECK(out16s[f].type == MS_16SC3 && out16s[f].rows == P.fh && out16s[f].cols == P.fw,
+                     "ms_stitch: out16s[%d] must be 16SC3 %dx%d", f, P.fw, P.fh);
+            out.p16[f] = (int16_t *)out16s[f].data; out.step16[f] = (unsigned)out16s[f].step;
+        }
+    }
+    MeshTable mesh{};
+    const bool cpw = c->cfg.enable_cpw != 0;
+    if (cpw) {
+        std::lock_guard<std::mutex> lk(c->mesh_mu);
+        for (int v = 0; v < N; ++v) {
+            if (!c->mesh_set[v]) return fail(MS_ERR_STATE, "ms_stitch: enable_cpw is set but view %d has no mesh", v);
+            ms_image mx = mesh_image(c, c->mesh_active[v], v, 0), my = mesh_image(c, c->mesh_active[v], v, 1);
+            mesh.x[v] = (const float *)mx.data; mesh.y[v] = (const float *)my.data; mesh.pitch[v] = c->map_pitch[v];
+        }
+    }
+
+    const ViewDesc *vt = (const ViewDesc *)c->view_tab.p;
+    const uint8_t *g0 = (const uint8_t *)c->g0.p;
+    int16_t *gl = (int16_t *)c->gl.p, *cl = (int16_t *)c->cl.p;
+    const dim3 blk(64, 4);
+
+    std::vector<hipEvent_t> ev;
+    int rec = 0;
+    auto mark = [&](const char *name) -> int {
+        if (!names) return MS_OK;
+        hipEvent_t e;
+        MS_HIP(hipEventCreate(&e));
+        MS_HIP(hipEventRecord(e, st));
+        ev.push_back(e);
+        if (name && rec < cap) names[rec++] = name;
+        return MS_OK;
+    };
+    if (int e = mark(nullptr)) return e;
+
+    if (cpw) {
+        k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
+            vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
+        MS_LAUNCH_CHECK();
+        if (int e = mark("k_remap_gain")) return e;
+        k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
+            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
+    } else {
+        k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
+            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
+    }
+    MS_LAUNCH_CHECK();
+    if (int e = mark("k_warp")) return e;
+
+    static const char *down_names[MAX_LEVELS] = {"k_down_l0", "k_down_l1", "k_down_l2", "k_down_l3", "k_down_l4", "k_down_l5", "k_down_l6", "k_down_l7"};
+    static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
+    for (int l = 0; l < nb; ++l) {
+        const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
+        const dim3 g(div_up(ow, 64), div_up(oh, 4), F * N * 3);
+        if (l == 0) k_down<uint8_t><<<g, blk, 0, st>>>(vt, N, l, g0, c->g0_stride, gl, c->gl_stride);
+        else        k_down<int16_t><<<g, blk, 0, st>>>(vt, N, l, gl, c->gl_stride, gl, c->gl_stride);
+        MS_LAUNCH_CHECK();
+        if (int e = mark(down_names[l])) return e;
+    }
+    if (nb == 0) {
+        // single band: out = mask ? trunc(sum/den) : 0 -- handled by the top kernel writing level 0 is not
+        // representable in the collapsed buffer; the path requires num_bands >= 1.
+        return fail(MS_ERR_UNSUPPORTED, "ms_stitch: num_bands resolved to 0 (pano smaller than 2 px?)");
+    }
+    k_blend_top<<<dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, 0, st>>>(vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride);
+    MS_LAUNCH_CHECK();
+    if (int e = mark(blend_names[nb])) return e;
+    for (int l = nb - 1; l >= 0; --l) {
+        const dim3 g(div_up(P.qw[l] / 2, 64), div_up(P.qh[l] / 2, 4), F);
+        if (l == 0) k_blend<true><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+        else        k_blend<false><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+        MS_LAUNCH_CHECK();
+        if (int e = mark(blend_names[l])) return e;
+    }
+    MS_HIP(hipEventRecord(c->last_stitch, st));
+    c->stitch_pending = true;
+
+    if (names) {
+        MS_HIP(hipEventSynchronize(ev.back()));
+        for (size_t i = 1; i < ev.size() && (int)i - 1 < cap; ++i) {
+            float t = 0.f;
+            MS_HIP(hipEventElapsedTime(&t, ev[i - 1], ev[i]));
+            ms_out[i - 1] = t;
+        }
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (n_rec) *n_rec = rec;
+    }
+    return MS_OK;
+}
+
+int ms_stitch(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, ms_stream stream)
+{
+    return stitch_impl(c, n_frames, views, out8u, out16s, as_stream(stream), 0, nullptr, nullptr, nullptr);
+}
+
+int ms_stitch_timed(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, ms_stream stream,
+                    int cap, const char **names, float *ms_out)
+{
+    if (!names || !ms_out || cap <= 0) return fail(MS_ERR_INVALID, "ms_stitch_timed: need output arrays");
+    int n = 0;
+    const int e = stitch_impl(c, n_frames, views, out8u, out16s, as_stream(stream), cap, names, ms_out, &n);
+    return e ? e : n;
+}
+
+// ---- read-back -----------------------------------------------------------------------------------
+int ms_get_view_geom(const ms_ctx *c, int view, ms_view_geom *g)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_get_view_geom: call ms_build_maps first");
+    MS_CHECK(g, "null output");
+    g->roi = c->roi[view];
+    const ViewPad &p = c->pad[view];
+    g->top = p.top; g->left = p.left; g->bottom = p.bottom; g->right = p.right;
+    g->x_tl = p.x_tl; g->y_tl = p.y_tl; g->x_br = p.x_br; g->y_br = p.y_br;
+    return MS_OK;
+}
+
+int ms_get_pano_geom(const ms_ctx *c, ms_pano_geom *g)
+{
+    if (!c || !g) return fail(MS_ERR_INVALID, "null argument");
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_get_pano_geom: call ms_build_maps first");
+    g->num_bands = c->bg.num_bands; g->dst_roi_final = c->bg.dst_roi_final; g->dst_roi = c->bg.dst_roi;
+    g->canvas_x = c->canvas_x; g->canvas_y = c->canvas_y;
+    return MS_OK;
+}
+
+int ms_get_maps(const ms_ctx *c, int view, ms_image *xm, ms_image *ym)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_get_maps: call ms_build_maps first");
+    if (xm) *xm = view_map_image(c, view, 0);
+    if (ym) *ym = view_map_image(c, view, 1);
+    return MS_OK;
+}
+
+int ms_get_mask(const ms_ctx *c, int view, ms_image *m)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->masks_built) return fail(MS_ERR_STATE, "ms_get_mask: masks not built");
+    MS_CHECK(m, "null output");
+    *m = ms_image{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)c->roi[view].width, c->roi[view].height, c->roi[view].width, MS_8UC1};
+    return MS_OK;
+}
+
+int ms_get_weight_level(const ms_ctx *c, int view, int level, ms_image *w)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_weight_level: call ms_init_blender first");
+    MS_CHECK(w && level >= 0 && level <= c->pano.nb, "ms_get_weight_level: bad level %d", level);
+    const LevelDesc &L = c->h_views[view].lv[level];
+    *w = ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.h, L.w, MS_32FC1};
+    return MS_OK;
+}
+
+int ms_get_mesh_maps(const ms_ctx *c, int view, ms_image *xm, ms_image *ym)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view]) return fail(MS_ERR_STATE, "ms_get_mesh_maps: no mesh set for view %d", view);
+    if (xm) *xm = mesh_image(c, c->mesh_active[view], view, 0);
+    if (ym) *ym = mesh_image(c, c->mesh_active[view], view, 1);
+    return MS_OK;
+}
+
+int ms_get_result_mask(ms_ctx *c, ms_image *m)
+{
+    if (!c || !m) return fail(MS_ERR_INVALID, "null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_result_mask: call ms_init_blender first");
+    *m = ms_image{c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fh, c->pano.fw, MS_8UC1};
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,532 @@
+// prims.hip -- one HIP kernel per cv::cuda:: image op on the stitching hot path, on GpuMat-layout
+// (row-pitched, interleaved) images.  These are the drop-in replacements of the reference's
+// individual calls (include/ms_stitch.h section 1); the per-frame fast path is compositor.hip.
+// Written for gfx950 wave64: 64 lanes along x (coalesced rows), 4 rows per 256-thread workgroup.
+#include "common.hpp"
+#include "launchers.hpp"
+
+namespace ms {
+
+static constexpr int BX = 64, BY = 4;
+static inline dim3 grid2d(int cols, int rows) { return dim3(div_up(cols, BX), div_up(rows, BY)); }
+#define XY_GUARD(cols, rows)                                   \
+    const int x = blockIdx.x * BX + threadIdx.x;               \
+    const int y = blockIdx.y * BY + threadIdx.y;               \
+    if (x >= (cols) || y >= (rows)) return;
+
+// ------------------------------------------------------------------------------------------------
+// remap, INTER_LINEAR, BORDER_CONSTANT(0): 4 taps in the order (y1,x1),(y1,x2),(y2,x1),(y2,x2),
+// weights (x2-x)(y2-y)..., out = fma(tap, w, out)   [reference: remap.cu:56-68, filters.hpp:90-114]
+template <int CN>
+__device__ __forceinline__ void bilinear_taps(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                              float xc, float yc, float out[CN])
+{
+    const int x1 = f2i_rd(xc), y1 = f2i_rd(yc);
+    const int x2 = (int)((unsigned)x1 + 1u), y2 = (int)((unsigned)y1 + 1u);
+    const float wx2 = (float)x2 - xc, wx1 = xc - (float)x1;
+    const float wy2 = (float)y2 - yc, wy1 = yc - (float)y1;
+    const float w[4] = {wx2 * wy2, wx1 * wy2, wx2 * wy1, wx1 * wy1};
+    const int xs[4] = {x1, x2, x1, x2};
+    const int ys[4] = {y1, y1, y2, y2};
+#pragma unroll
+    for (int c = 0; c < CN; ++c) out[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool inb = xs[t] >= 0 && xs[t] < scols && ys[t] >= 0 && ys[t] < srows;
+        const uint8_t *p = src + (size_t)(inb ? ys[t] : 0) * sstep + (size_t)(inb ? xs[t] : 0) * CN;
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            const float s = inb ? (float)p[c] : 0.f;
+            out[c] = __builtin_fmaf(s, w[t], out[c]);
+        }
+    }
+}
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_remap_linear(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                      const float *__restrict__ mx, size_t mxstep,
+                                                      const float *__restrict__ my, size_t mystep,
+                                                      uint8_t *__restrict__ dst, size_t dstep, int drows, int dcols)
+{
+    XY_GUARD(dcols, drows)
+    const float xc = row_ptr<float>(mx, mxstep, y)[x];
+    const float yc = row_ptr<float>(my, mystep, y)[x];
+    float out[CN];
+    bilinear_taps<CN>(src, sstep, srows, scols, xc, yc, out);
+    uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) d[c] = sat_u8(out[c]);
+}
+
+// remap, INTER_NEAREST (PointFilter: __float2int_rz), BORDER_CONSTANT(0), 8UC1  [filters.hpp:58-77]
+__global__ void __launch_bounds__(256) k_remap_nearest_c1(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                          const float *__restrict__ mx, size_t mxstep,
+                                                          const float *__restrict__ my, size_t mystep,
+                                                          uint8_t *__restrict__ dst, size_t dstep, int drows, int dcols)
+{
+    XY_GUARD(dcols, drows)
+    const int xx = f2i_rz(row_ptr<float>(mx, mxstep, y)[x]);
+    const int yy = f2i_rz(row_ptr<float>(my, mystep, y)[x]);
+    const bool inb = xx >= 0 && xx < scols && yy >= 0 && yy < srows;
+    row_ptr<uint8_t>(dst, dstep, y)[x] = inb ? row_ptr<uint8_t>(src, sstep, yy)[xx] : (uint8_t)0;
+}
+
+int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms_image &dst, int interp, hipStream_t st)
+{
+    const dim3 g = grid2d(dst.cols, dst.rows), b(BX, BY);
+    auto S = (const uint8_t *)src.data; auto D = (uint8_t *)dst.data;
+    auto MX = (const float *)xm.data; auto MY = (const float *)ym.data;
+    if (src.type == MS_8UC3 && interp == MS_INTER_LINEAR)
+        k_remap_linear<3><<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_8UC1 && interp == MS_INTER_LINEAR)
+        k_remap_linear<1><<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_8UC1 && interp == MS_INTER_NEAREST)
+        k_remap_nearest_c1<<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
+    else
+        return fail(MS_ERR_UNSUPPORTED, "ms_remap: type %d / interpolation %d not on the hot path", src.type, interp);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// resize_linear: src = dst * (1/scale), no half-pixel centre, x2/y2 reads clamped  [resize.cu:71-106]
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_linear(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                       uint8_t *__restrict__ dst, size_t dstep, int drows, int dcols,
+                                                       float ify, float ifx)
+{
+    XY_GUARD(dcols, drows)
+    const float sx = (float)x * ifx, sy = (float)y * ify;
+    const int x1 = f2i_rd(sx), y1 = f2i_rd(sy);
+    const int x2 = x1 + 1, y2 = y1 + 1;
+    const int x2r = min(x2, scols - 1), y2r = min(y2, srows - 1);
+    const float w11 = ((float)x2 - sx) * ((float)y2 - sy), w12 = (sx - (float)x1) * ((float)y2 - sy);
+    const float w21 = ((float)x2 - sx) * (sy - (float)y1), w22 = (sx - (float)x1) * (sy - (float)y1);
+    const uint8_t *r1 = row_ptr<uint8_t>(src, sstep, y1), *r2 = row_ptr<uint8_t>(src, sstep, y2r);
+    uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+        float out = 0.f;
+        out = __builtin_fmaf((float)r1[(size_t)x1 * CN + c], w11, out);
+        out = __builtin_fmaf((float)r1[(size_t)x2r * CN + c], w12, out);
+        out = __builtin_fmaf((float)r2[(size_t)x1 * CN + c], w21, out);
+        out = __builtin_fmaf((float)r2[(size_t)x2r * CN + c], w22, out);
+        d[c] = sat_u8(out);
+    }
+}
+
+int launch_resize_linear(const ms_image &src, ms_image &dst, double fx, double fy, hipStream_t st)
+{
+    if (dst.rows == src.rows && dst.cols == src.cols) {   // resize.cpp:86-90: plain copy
+        const size_t wb = (size_t)src.cols * (src.type == MS_8UC3 ? 3 : 1);
+        MS_HIP(hipMemcpy2DAsync(dst.data, dst.step, src.data, src.step, wb, src.rows, hipMemcpyDeviceToDevice, st));
+        return MS_OK;
+    }
+    // resize.cpp:72-81,105: explicit dsize -> fx = dsize.width / src.cols (double); kernel gets static_cast<float>(1.0 / fx)
+    if (!(fx > 0 && fy > 0)) { fx = (double)dst.cols / src.cols; fy = (double)dst.rows / src.rows; }
+    const float ifx = (float)(1.0 / fx), ify = (float)(1.0 / fy);
+    const dim3 g = grid2d(dst.cols, dst.rows), b(BX, BY);
+    if (src.type == MS_8UC3)
+        k_resize_linear<3><<<g, b, 0, st>>>((const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, dst.step, dst.rows, dst.cols, ify, ifx);
+    else if (src.type == MS_8UC1)
+        k_resize_linear<1><<<g, b, 0, st>>>((const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, dst.step, dst.rows, dst.cols, ify, ifx);
+    else
+        return fail(MS_ERR_UNSUPPORTED, "ms_resize_linear: type %d", src.type);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise transforms over a rows x width (elements) extent
+template <typename S, typename D, typename F>
+__global__ void __launch_bounds__(256) k_unary(const S *__restrict__ src, size_t sstep, D *__restrict__ dst, size_t dstep,
+                                               int rows, int width, F f)
+{
+    XY_GUARD(width, rows)
+    row_ptr<D>(dst, dstep, y)[x] = f(row_ptr<S>(src, sstep, y)[x]);
+}
+template <typename A, typename B, typename D, typename F>
+__global__ void __launch_bounds__(256) k_binary(const A *a, size_t astep, const B *b, size_t bstep, D *dst, size_t dstep,
+                                                int rows, int width, F f)
+{
+    XY_GUARD(width, rows)
+    row_ptr<D>(dst, dstep, y)[x] = f(row_ptr<A>(a, astep, y)[x], row_ptr<B>(b, bstep, y)[x]);
+}
+
+struct OpScaleU8 { float a; __device__ uint8_t operator()(uint8_t v) const { return sat_u8(__builtin_fmaf(a, (float)v, 0.f)); } };
+struct OpWiden { __device__ int16_t operator()(uint8_t v) const { return (int16_t)v; } };
+struct OpNarrow { __device__ uint8_t operator()(int16_t v) const { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); } };
+struct OpU8F32 { float a; __device__ float operator()(uint8_t v) const { return __builtin_fmaf(a, (float)v, 0.f); } };
+struct OpGt { float t; __device__ uint8_t operator()(float v) const { return v > t ? 255 : 0; } };
+struct OpEq { uint8_t t; __device__ uint8_t operator()(uint8_t v) const { return v == t ? 255 : 0; } };
+struct OpSub { __device__ int16_t operator()(int16_t a, int16_t b) const { return sat_s16((int)a - (int)b); } };
+struct OpAdd { __device__ int16_t operator()(int16_t a, int16_t b) const { return sat_s16((int)a + (int)b); } };
+struct OpAnd { __device__ uint8_t operator()(uint8_t a, uint8_t b) const { return a & b; } };
+
+static inline int cn_of(int type) { return ((type >> 3) & 7) + 1; }
+
+template <typename S, typename D, typename F>
+static int run_unary(const ms_image &src, ms_image &dst, int width, F f, hipStream_t st)
+{
+    k_unary<S, D, F><<<grid2d(width, src.rows), dim3(BX, BY), 0, st>>>((const S *)src.data, src.step, (D *)dst.data, dst.step, src.rows, width, f);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+template <typename A, typename B, typename D, typename F>
+static int run_binary(const ms_image &a, const ms_image &b, ms_image &dst, int width, F f, hipStream_t st)
+{
+    k_binary<A, B, D, F><<<grid2d(width, a.rows), dim3(BX, BY), 0, st>>>((const A *)a.data, a.step, (const B *)b.data, b.step, (D *)dst.data, dst.step, a.rows, width, f);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+int launch_convert_scale_8u(const ms_image &src, ms_image &dst, double alpha, hipStream_t st)
+{
+    return run_unary<uint8_t, uint8_t>(src, dst, src.cols * cn_of(src.type), OpScaleU8{(float)alpha}, st);
+}
+
+int launch_convert(const ms_image &src, ms_image &dst, double alpha, hipStream_t st)
+{
+    const int sd = src.type & 7, dd = dst.type & 7, w = src.cols * cn_of(src.type);
+    if (sd == 0 && dd == 3) return run_unary<uint8_t, int16_t>(src, dst, w, OpWiden{}, st);
+    if (sd == 3 && dd == 0) return run_unary<int16_t, uint8_t>(src, dst, w, OpNarrow{}, st);
+    if (sd == 0 && dd == 5) return run_unary<uint8_t, float>(src, dst, w, OpU8F32{(float)alpha}, st);
+    if (sd == dd) {  // convertTo same depth == copyTo (gpu_mat.cu:535-543)
+        static const int esz[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+        MS_HIP(hipMemcpy2DAsync(dst.data, dst.step, src.data, src.step, (size_t)w * esz[sd], src.rows, hipMemcpyDeviceToDevice, st));
+        return MS_OK;
+    }
+    return fail(MS_ERR_UNSUPPORTED, "ms_convert: depth %d -> %d not on the hot path", sd, dd);
+}
+
+int launch_sub_16s(const ms_image &a, const ms_image &b, ms_image &dst, hipStream_t st)
+{ return run_binary<int16_t, int16_t, int16_t>(a, b, dst, a.cols * cn_of(a.type), OpSub{}, st); }
+int launch_add_16s(const ms_image &a, const ms_image &b, ms_image &dst, hipStream_t st)
+{ return run_binary<int16_t, int16_t, int16_t>(a, b, dst, a.cols * cn_of(a.type), OpAdd{}, st); }
+int launch_and_8u(const ms_image &a, const ms_image &b, ms_image &dst, hipStream_t st)
+{ return run_binary<uint8_t, uint8_t, uint8_t>(a, b, dst, a.cols, OpAnd{}, st); }
+int launch_compare_gt_32f(const ms_image &src, float thr, ms_image &dst, hipStream_t st)
+{ return run_unary<float, uint8_t>(src, dst, src.cols, OpGt{thr}, st); }
+int launch_compare_eq_8u(const ms_image &src, int val, ms_image &dst, hipStream_t st)
+{ return run_unary<uint8_t, uint8_t>(src, dst, src.cols, OpEq{(uint8_t)val}, st); }
+
+// ------------------------------------------------------------------------------------------------
+// copyMakeBorder: REFLECT for byte pixels of ES bytes, CONSTANT(0) for float  [copy_make_border.cu:61-115]
+template <int ES>
+__global__ void __launch_bounds__(256) k_border_reflect(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                        uint8_t *__restrict__ dst, size_t dstep, int drows, int dcols,
+                                                        int top, int left)
+{
+    XY_GUARD(dcols, drows)
+    const uint8_t *s = row_ptr<uint8_t>(src, sstep, reflect_idx(y - top, srows)) + (size_t)reflect_idx(x - left, scols) * ES;
+    uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + (size_t)x * ES;
+#pragma unroll
+    for (int i = 0; i < ES; ++i) d[i] = s[i];
+}
+__global__ void __launch_bounds__(256) k_border_const_f32(const float *__restrict__ src, size_t sstep, int srows, int scols,
+                                                          float *__restrict__ dst, size_t dstep, int drows, int dcols,
+                                                          int top, int left)
+{
+    XY_GUARD(dcols, drows)
+    const int sx = x - left, sy = y - top;
+    const bool inb = sx >= 0 && sx < scols && sy >= 0 && sy < srows;
+    row_ptr<float>(dst, dstep, y)[x] = inb ? row_ptr<float>(src, sstep, sy)[sx] : 0.f;
+}
+
+int launch_copy_make_border(const ms_image &src, ms_image &dst, int top, int left, int border_type, hipStream_t st)
+{
+    const dim3 g = grid2d(dst.cols, dst.rows), b(BX, BY);
+    if (border_type == MS_BORDER_REFLECT && src.type == MS_8UC3)
+        k_border_reflect<3><<<g, b, 0, st>>>((const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, dst.step, dst.rows, dst.cols, top, left);
+    else if (border_type == MS_BORDER_REFLECT && src.type == MS_8UC1)
+        k_border_reflect<1><<<g, b, 0, st>>>((const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, dst.step, dst.rows, dst.cols, top, left);
+    else if (border_type == MS_BORDER_CONSTANT && src.type == MS_32FC1)
+        k_border_const_f32<<<g, b, 0, st>>>((const float *)src.data, src.step, src.rows, src.cols, (float *)dst.data, dst.step, dst.rows, dst.cols, top, left);
+    else
+        return fail(MS_ERR_UNSUPPORTED, "ms_copy_make_border: type %d with border %d not on the hot path", src.type, border_type);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyrDown: 5x5 [1 4 6 4 1]^2/256, BORDER_REFLECT_101, decimate by 2  [pyr_down.cu:55-174]
+// 16S: exact integer form.  32F: vertical-then-horizontal fma chains in the kernel's order.
+template <int CN>
+__global__ void __launch_bounds__(256) k_pyr_down_16s(const int16_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                      int16_t *__restrict__ dst, size_t dstep, int drows, int dcols)
+{
+    XY_GUARD(dcols, drows)
+    const int sy = 2 * y, sx = 2 * x;
+    const int16_t *r[5] = {row_ptr<int16_t>(src, sstep, r101_low(sy - 2, srows)), row_ptr<int16_t>(src, sstep, r101_low(sy - 1, srows)),
+                           row_ptr<int16_t>(src, sstep, sy), row_ptr<int16_t>(src, sstep, r101_high(sy + 1, srows)),
+                           row_ptr<int16_t>(src, sstep, r101_high(sy + 2, srows))};
+    int cx[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cx[k] = r101(sx - 2 + k, scols) * CN;
+    const int wv[5] = {1, 4, 6, 4, 1};
+    int acc[CN];
+#pragma unroll
+    for (int c = 0; c < CN; ++c) acc[c] = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int c = 0; c < CN; ++c) acc[c] += wv[j] * wv[k] * (int)r[j][cx[k] + c];
+    int16_t *d = row_ptr<int16_t>(dst, dstep, y) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) d[c] = sat_s16(rne_shift(acc[c], 8));
+}
+
+__global__ void __launch_bounds__(256) k_pyr_down_32f(const float *__restrict__ src, size_t sstep, int srows, int scols,
+                                                      float *__restrict__ dst, size_t dstep, int drows, int dcols)
+{
+    XY_GUARD(dcols, drows)
+    const int sy = 2 * y, sx = 2 * x;
+    const float *r[5] = {row_ptr<float>(src, sstep, r101_low(sy - 2, srows)), row_ptr<float>(src, sstep, r101_low(sy - 1, srows)),
+                         row_ptr<float>(src, sstep, sy), row_ptr<float>(src, sstep, r101_high(sy + 1, srows)),
+                         row_ptr<float>(src, sstep, r101_high(sy + 2, srows))};
+    float v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int cx = r101(sx - 2 + k, scols);
+        float s = 0.0625f * r[0][cx];
+        s = __builtin_fmaf(0.25f, r[1][cx], s);
+        s = __builtin_fmaf(0.375f, r[2][cx], s);
+        s = __builtin_fmaf(0.25f, r[3][cx], s);
+        s = __builtin_fmaf(0.0625f, r[4][cx], s);
+        v[k] = s;
+    }
+    float s = 0.0625f * v[0];
+    s = __builtin_fmaf(0.25f, v[1], s);
+    s = __builtin_fmaf(0.375f, v[2], s);
+    s = __builtin_fmaf(0.25f, v[3], s);
+    s = __builtin_fmaf(0.0625f, v[4], s);
+    row_ptr<float>(dst, dstep, y)[x] = s;
+}
+
+int launch_pyr_down(const ms_image &src, ms_image &dst, hipStream_t st)
+{
+    const dim3 g = grid2d(dst.cols, dst.rows), b(BX, BY);
+    if (src.type == MS_16SC3)
+        k_pyr_down_16s<3><<<g, b, 0, st>>>((const int16_t *)src.data, src.step, src.rows, src.cols, (int16_t *)dst.data, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_16SC1)
+        k_pyr_down_16s<1><<<g, b, 0, st>>>((const int16_t *)src.data, src.step, src.rows, src.cols, (int16_t *)dst.data, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_32FC1)
+        k_pyr_down_32f<<<g, b, 0, st>>>((const float *)src.data, src.step, src.rows, src.cols, (float *)dst.data, dst.step, dst.rows, dst.cols);
+    else
+        return fail(MS_ERR_UNSUPPORTED, "ms_pyr_down: type %d", src.type);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyrUp: zero-insert x2, same 5-tap, x4; source index min(n-1, |i|)  [pyr_up.cu:55-145]
+// exact integer form: S = sum over the 3x3 (even/odd phase) taps, result = rne(S / 64).
+template <int CN>
+__device__ __forceinline__ void pyr_up_px(const int16_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                          int x, int y, int out[CN])
+{
+    const int i = y >> 1, j = x >> 1;
+    // vertical phase: even row -> (1,6,1) over i-1,i,i+1 ; odd row -> (4,4) over i,i+1
+    int ry[3], wy[3], rx[3], wx[3];
+    if ((y & 1) == 0) { ry[0] = i - 1; ry[1] = i; ry[2] = i + 1; wy[0] = 1; wy[1] = 6; wy[2] = 1; }
+    else              { ry[0] = i;     ry[1] = i + 1; ry[2] = i; wy[0] = 4; wy[1] = 4; wy[2] = 0; }
+    if ((x & 1) == 0) { rx[0] = j - 1; rx[1] = j; rx[2] = j + 1; wx[0] = 1; wx[1] = 6; wx[2] = 1; }
+    else              { rx[0] = j;     rx[1] = j + 1; rx[2] = j; wx[0] = 4; wx[1] = 4; wx[2] = 0; }
+#pragma unroll
+    for (int c = 0; c < CN; ++c) out[c] = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int16_t *r = row_ptr<int16_t>(src, sstep, pu_idx(ry[a], srows));
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int cx = pu_idx(rx[b], scols) * CN;
+            const int w = wy[a] * wx[b];
+#pragma unroll
+            for (int c = 0; c < CN; ++c) out[c] += w * (int)r[cx + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; ++c) out[c] = rne_shift(out[c], 6);
+}
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_pyr_up_16s(const int16_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                    int16_t *__restrict__ dst, size_t dstep, int drows, int dcols)
+{
+    XY_GUARD(dcols, drows)
+    int out[CN];
+    pyr_up_px<CN>(src, sstep, srows, scols, x, y, out);
+    int16_t *d = row_ptr<int16_t>(dst, dstep, y) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) d[c] = sat_s16(out[c]);
+}
+
+int launch_pyr_up(const ms_image &src, ms_image &dst, hipStream_t st)
+{
+    const dim3 g = grid2d(dst.cols, dst.rows), b(BX, BY);
+    if (src.type == MS_16SC3)
+        k_pyr_up_16s<3><<<g, b, 0, st>>>((const int16_t *)src.data, src.step, src.rows, src.cols, (int16_t *)dst.data, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_16SC1)
+        k_pyr_up_16s<1><<<g, b, 0, st>>>((const int16_t *)src.data, src.step, src.rows, src.cols, (int16_t *)dst.data, dst.step, dst.rows, dst.cols);
+    else
+        return fail(MS_ERR_UNSUPPORTED, "ms_pyr_up: type %d", src.type);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// addSrcWeightKernel32F / normalizeUsingWeightKernel32F  [multiband_blend.cu:36-51, 85-100]
+__global__ void __launch_bounds__(256) k_add_src_weight(const int16_t *__restrict__ src, size_t sstep, const float *__restrict__ w, size_t wstep,
+                                                        int16_t *dst, size_t dstep, float *dstw, size_t dwstep, int rows, int cols)
+{
+    XY_GUARD(cols, rows)
+    const int16_t *s = row_ptr<int16_t>(src, sstep, y) + 3 * x;
+    const float ww = row_ptr<float>(w, wstep, y)[x];
+    int16_t *d = row_ptr<int16_t>(dst, dstep, y) + 3 * x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = (int16_t)(d[c] + trunc_s16((float)s[c] * ww));
+    float *dw = row_ptr<float>(dstw, dwstep, y) + x;
+    *dw = *dw + ww;
+}
+
+__global__ void __launch_bounds__(256) k_normalize(const float *__restrict__ w, size_t wstep, int16_t *src, size_t sstep, int rows, int cols)
+{
+    XY_GUARD(cols, rows)
+    const float den = row_ptr<float>(w, wstep, y)[x] + 1e-5f;
+    int16_t *s = row_ptr<int16_t>(src, sstep, y) + 3 * x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s[c] = trunc_s16((float)s[c] / den);
+}
+
+__global__ void __launch_bounds__(256) k_zero_masked(int16_t *img, size_t step, const uint8_t *__restrict__ mask, size_t mstep, int rows, int cols)
+{
+    XY_GUARD(cols, rows)
+    if (row_ptr<uint8_t>(mask, mstep, y)[x]) {
+        int16_t *p = row_ptr<int16_t>(img, step, y) + 3 * x;
+        p[0] = p[1] = p[2] = 0;
+    }
+}
+
+int launch_add_src_weight(const ms_image &src, const ms_image &w, ms_image &dst, ms_image &dstw, int rcw, int rch, hipStream_t st)
+{
+    k_add_src_weight<<<grid2d(rcw, rch), dim3(BX, BY), 0, st>>>((const int16_t *)src.data, src.step, (const float *)w.data, w.step,
+                                                                (int16_t *)dst.data, dst.step, (float *)dstw.data, dstw.step, rch, rcw);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+int launch_normalize(const ms_image &w, ms_image &src, int width, int height, hipStream_t st)
+{
+    k_normalize<<<grid2d(width, height), dim3(BX, BY), 0, st>>>((const float *)w.data, w.step, (int16_t *)src.data, src.step, height, width);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+int launch_zero_masked(ms_image &img, const ms_image &mask, hipStream_t st)
+{
+    k_zero_masked<<<grid2d(img.cols, img.rows), dim3(BX, BY), 0, st>>>((int16_t *)img.data, img.step, (const uint8_t *)mask.data, mask.step, img.rows, img.cols);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// 3x3 max (replicate border): the dilation of APP/calibration.cpp:209,232
+__global__ void __launch_bounds__(256) k_dilate3(const uint8_t *__restrict__ src, size_t sstep, uint8_t *__restrict__ dst, size_t dstep, int rows, int cols)
+{
+    XY_GUARD(cols, rows)
+    uint8_t m = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const uint8_t *s = row_ptr<uint8_t>(src, sstep, min(max(y + dy, 0), rows - 1));
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) m = max(m, s[min(max(x + dx, 0), cols - 1)]);
+    }
+    row_ptr<uint8_t>(dst, dstep, y)[x] = m;
+}
+int launch_dilate3(const ms_image &src, ms_image &dst, hipStream_t st)
+{
+    k_dilate3<<<grid2d(src.cols, src.rows), dim3(BX, BY), 0, st>>>((const uint8_t *)src.data, src.step, (uint8_t *)dst.data, dst.step, src.rows, src.cols);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// buildWarpMapsKernel<Mapper>  [build_warp_maps.cu:67-152]; k_rinv/t/scale by value (no __constant__ upload)
+struct WarpParams { float k[9]; float t[3]; float scale; };
+
+template <int PROJ>
+__global__ void __launch_bounds__(256) k_build_warp_maps(int tl_u, int tl_v, int cols, int rows, float *__restrict__ mapx, size_t mxstep,
+                                                         float *__restrict__ mapy, size_t mystep, WarpParams P)
+{
+    XY_GUARD(cols, rows)
+    float u = (float)(tl_u + x), v = (float)(tl_v + y);
+    float x_, y_, z_;
+    if (PROJ == MS_PROJ_PLANE) {
+        x_ = u / P.scale - P.t[0];
+        y_ = v / P.scale - P.t[1];
+        z_ = 1.f - P.t[2];
+    } else if (PROJ == MS_PROJ_CYLINDRICAL) {
+        u /= P.scale;
+        x_ = sinf(u);
+        y_ = v / P.scale;
+        z_ = cosf(u);
+    } else {
+        v /= P.scale;
+        u /= P.scale;
+        const float sinv = sinf(v);
+        x_ = sinv * sinf(u);
+        y_ = -cosf(v);
+        z_ = sinv * cosf(u);
+    }
+    float ox = __builtin_fmaf(P.k[2], z_, __builtin_fmaf(P.k[1], y_, P.k[0] * x_));
+    float oy = __builtin_fmaf(P.k[5], z_, __builtin_fmaf(P.k[4], y_, P.k[3] * x_));
+    const float oz = __builtin_fmaf(P.k[8], z_, __builtin_fmaf(P.k[7], y_, P.k[6] * x_));
+    if (PROJ == MS_PROJ_PLANE || oz > 0) { ox /= oz; oy /= oz; }
+    else ox = oy = -1.f;
+    row_ptr<float>(mapx, mxstep, y)[x] = ox;
+    row_ptr<float>(mapy, mystep, y)[x] = oy;
+}
+
+int launch_build_warp_maps(int proj, int tl_u, int tl_v, ms_image &mx, ms_image &my, const float *k_rinv, const float *t, float scale, hipStream_t st)
+{
+    WarpParams P;
+    memcpy(P.k, k_rinv, sizeof(P.k));
+    if (t) memcpy(P.t, t, sizeof(P.t)); else P.t[0] = P.t[1] = P.t[2] = 0.f;
+    P.scale = scale;
+    const dim3 g = grid2d(mx.cols, mx.rows), b(BX, BY);
+    if (proj == MS_PROJ_PLANE)
+        k_build_warp_maps<MS_PROJ_PLANE><<<g, b, 0, st>>>(tl_u, tl_v, mx.cols, mx.rows, (float *)mx.data, mx.step, (float *)my.data, my.step, P);
+    else if (proj == MS_PROJ_CYLINDRICAL)
+        k_build_warp_maps<MS_PROJ_CYLINDRICAL><<<g, b, 0, st>>>(tl_u, tl_v, mx.cols, mx.rows, (float *)mx.data, mx.step, (float *)my.data, my.step, P);
+    else if (proj == MS_PROJ_SPHERICAL)
+        k_build_warp_maps<MS_PROJ_SPHERICAL><<<g, b, 0, st>>>(tl_u, tl_v, mx.cols, mx.rows, (float *)mx.data, mx.step, (float *)my.data, my.step, P);
+    else
+        return fail(MS_ERR_INVALID, "ms_build_warp_maps: unknown projection %d", proj);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// custom_resize  [APP/resize.cu:9-27]
+__global__ void __launch_bounds__(256) k_custom_resize(int tx, int ty, int cols, int rows, const float *__restrict__ in, size_t istep,
+                                                       float *__restrict__ out, size_t ostep)
+{
+    XY_GUARD(tx, ty)
+    const int left = x * (cols - 1) / tx, top = y * (rows - 1) / ty;
+    const float uu = ((float)x) * (float)(cols - 1) / (float)tx - (float)left;
+    const float vv = ((float)y) * (float)(rows - 1) / (float)ty - (float)top;
+    const float *r0 = row_ptr<float>(in, istep, top), *r1 = row_ptr<float>(in, istep, top + 1);
+    float r = ((1.f - uu) * (1.f - vv)) * r0[left];
+    r = __builtin_fmaf(uu * (1.f - vv), r0[left + 1], r);
+    r = __builtin_fmaf((1.f - uu) * vv, r1[left], r);
+    r = __builtin_fmaf(uu * vv, r1[left + 1], r);
+    row_ptr<float>(out, ostep, y)[x] = r;
+}
+int launch_custom_resize(const ms_image &in, ms_image &out, hipStream_t st)
+{
+    if (in.rows < 2 || in.cols < 2) return fail(MS_ERR_INVALID, "ms_custom_resize_32f: input must be at least 2x2");
+    k_custom_resize<<<grid2d(out.cols, out.rows), dim3(BX, BY), 0, st>>>(out.cols, out.rows, in.cols, in.rows, (const float *)in.data, in.step, (float *)out.data, out.step);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+}  // namespace ms

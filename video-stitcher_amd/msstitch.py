@@ -1,0 +1,406 @@
+"""ctypes binding of libmsstitch.so (the HIP compositor) for tests and bench.py.
+
+PyTorch is used only as plumbing: device memory (torch.uint8/int16/float32 tensors stand in for
+cv::cuda::GpuMat) and streams.  There is no CPU fallback: importing works anywhere, but every
+compute call raises MsError without a gfx950 device, and load() raises if the library is missing.
+
+Names mirror the reference: cuda::remap -> remap, cuda::pyrDown -> pyr_down, ...,
+MultiBandBlender::feed_online/blend -> Compositor.stitch (fused) -- see include/ms_stitch.h.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsstitch.so")
+
+MS_8UC1, MS_8UC3, MS_16SC1, MS_16SC3, MS_32FC1 = 0, 16, 3, 19, 5
+BORDER_CONSTANT, BORDER_REFLECT = 0, 2
+INTER_NEAREST, INTER_LINEAR = 0, 1
+PROJ_PLANE, PROJ_CYLINDRICAL, PROJ_SPHERICAL = 0, 1, 2
+
+
+class MsError(RuntimeError):
+    pass
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("step", C.c_size_t), ("rows", C.c_int), ("cols", C.c_int), ("type", C.c_int)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+    def tuple(self):
+        return (self.x, self.y, self.width, self.height)
+
+
+class Config(C.Structure):
+    _fields_ = [("num_views", C.c_int), ("src_width", C.c_int), ("src_height", C.c_int), ("projection", C.c_int),
+                ("warp_scale", C.c_float), ("num_bands", C.c_int), ("enable_cpw", C.c_int),
+                ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int), ("reserved", C.c_int * 8)]
+
+
+class ViewGeom(C.Structure):
+    _fields_ = [("roi", Rect)] + [(n, C.c_int) for n in ("top", "left", "bottom", "right", "x_tl", "y_tl", "x_br", "y_br")]
+
+
+class PanoGeom(C.Structure):
+    _fields_ = [("num_bands", C.c_int), ("dst_roi_final", Rect), ("dst_roi", Rect), ("canvas_x", C.c_int), ("canvas_y", C.c_int)]
+
+
+EXPORTS = [
+    "ms_last_error", "ms_version", "ms_device_count", "ms_remap", "ms_resize_linear", "ms_convert_scale_8u", "ms_convert",
+    "ms_copy_make_border", "ms_pyr_down", "ms_pyr_up", "ms_subtract_16s", "ms_add_16s", "ms_add_src_weight_32f",
+    "ms_normalize_using_weight_32f", "ms_compare_gt_32f", "ms_compare_eq_8u", "ms_set_zero_masked_16sc3",
+    "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
+    "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
+    "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
+    "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
+]
+
+_lib = None
+
+
+def load():
+    """Load libmsstitch.so; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsError("libmsstitch.so not built (run video-stitcher_amd/build.sh or __graft_entry__.build()); "
+                          "there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ms_last_error.restype = C.c_char_p
+        _lib.ms_version.restype = C.c_char_p
+    return _lib
+
+
+def _chk(code):
+    if code < 0:
+        raise MsError("msstitch error %d: %s" % (code, load().ms_last_error().decode()))
+    return code
+
+
+_TYPES = {}
+
+
+def _torch():
+    import torch
+    if not _TYPES:
+        _TYPES.update({(torch.uint8, 1): MS_8UC1, (torch.uint8, 3): MS_8UC3, (torch.int16, 1): MS_16SC1,
+                       (torch.int16, 3): MS_16SC3, (torch.float32, 1): MS_32FC1})
+    return torch
+
+
+def img(t):
+    """torch tensor (H,W) or (H,W,C), last dims contiguous, on the GPU -> ms_image (borrowed)."""
+    torch = _torch()
+    assert t.is_cuda, "msstitch operates on device memory only"
+    cn = 1 if t.dim() == 2 else t.shape[2]
+    if t.dim() == 3:
+        assert t.stride(2) == 1 and t.stride(1) == cn
+    else:
+        assert t.stride(1) == 1
+    return Image(t.data_ptr(), t.stride(0) * t.element_size(), t.shape[0], t.shape[1], _TYPES[(t.dtype, cn)])
+
+
+def tensor_of(image, dtype=None):
+    """Borrowed ms_image (device memory owned by a context) -> torch tensor COPY."""
+    torch = _torch()
+    dt = {MS_8UC1: (torch.uint8, 1), MS_8UC3: (torch.uint8, 3), MS_16SC1: (torch.int16, 1), MS_16SC3: (torch.int16, 3),
+          MS_32FC1: (torch.float32, 1)}[image.type]
+    out = torch.empty((image.rows, image.cols) + ((dt[1],) if dt[1] > 1 else ()), dtype=dt[0], device="cuda")
+    row = image.cols * dt[1] * out.element_size()
+    import ctypes
+    hip = _hip()
+    rc = hip.hipMemcpy2D(C.c_void_p(out.data_ptr()), C.c_size_t(row), C.c_void_p(image.data), C.c_size_t(image.step),
+                         C.c_size_t(row), C.c_size_t(image.rows), 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise MsError("hipMemcpy2D failed: %d" % rc)
+    return out
+
+
+_hiplib = None
+
+
+def _hip():
+    global _hiplib
+    if _hiplib is None:
+        _hiplib = C.CDLL("libamdhip64.so")
+    return _hiplib
+
+
+def _stream():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_count():
+    return load().ms_device_count()
+
+
+# ------------------------------------------------------------------ image ops (allocate dst like the cv::cuda API)
+
+def _new(shape, dtype):
+    return _torch().empty(shape, dtype=dtype, device="cuda")
+
+
+def remap(src, xmap, ymap, interpolation=INTER_LINEAR):
+    dst = _new(tuple(xmap.shape) + tuple(src.shape[2:]), src.dtype)
+    _chk(load().ms_remap(C.byref(img(src)), C.byref(img(xmap)), C.byref(img(ymap)), C.byref(img(dst)), interpolation, _stream()))
+    return dst
+
+
+def resize_linear(src, dsize=None, fx=0.0, fy=0.0):
+    import numpy as np
+    rows, cols = src.shape[:2]
+    if dsize is None:
+        dsize = (int(np.rint(cols * fx)), int(np.rint(rows * fy)))   # saturate_cast<int>(double)
+    else:
+        fx = fy = 0.0
+    dst = _new((dsize[1], dsize[0]) + tuple(src.shape[2:]), src.dtype)
+    _chk(load().ms_resize_linear(C.byref(img(src)), C.byref(img(dst)), C.c_double(fx), C.c_double(fy), _stream()))
+    return dst
+
+
+def convert_scale_8u(src, alpha, inplace=False):
+    dst = src if inplace else _new(src.shape, src.dtype)
+    _chk(load().ms_convert_scale_8u(C.byref(img(src)), C.byref(img(dst)), C.c_double(alpha), _stream()))
+    return dst
+
+
+def convert(src, dtype, alpha=1.0):
+    dst = _new(src.shape, dtype)
+    _chk(load().ms_convert(C.byref(img(src)), C.byref(img(dst)), C.c_double(alpha), _stream()))
+    return dst
+
+
+def copy_make_border(src, top, bottom, left, right, border_type):
+    dst = _new((src.shape[0] + top + bottom, src.shape[1] + left + right) + tuple(src.shape[2:]), src.dtype)
+    _chk(load().ms_copy_make_border(C.byref(img(src)), C.byref(img(dst)), top, bottom, left, right, border_type, _stream()))
+    return dst
+
+
+def pyr_down(src):
+    dst = _new(((src.shape[0] + 1) // 2, (src.shape[1] + 1) // 2) + tuple(src.shape[2:]), src.dtype)
+    _chk(load().ms_pyr_down(C.byref(img(src)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def pyr_up(src):
+    dst = _new((src.shape[0] * 2, src.shape[1] * 2) + tuple(src.shape[2:]), src.dtype)
+    _chk(load().ms_pyr_up(C.byref(img(src)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def subtract(a, b, dst=None):
+    dst = _new(a.shape, a.dtype) if dst is None else dst
+    _chk(load().ms_subtract_16s(C.byref(img(a)), C.byref(img(b)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def add(a, b, dst=None):
+    dst = _new(a.shape, a.dtype) if dst is None else dst
+    _chk(load().ms_add_16s(C.byref(img(a)), C.byref(img(b)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def add_src_weight_32f(src, weight, dst_roi, dst_weight_roi):
+    """dst_roi / dst_weight_roi: views (tensor slices) of the pano level, i.e. dst(rc)."""
+    _chk(load().ms_add_src_weight_32f(C.byref(img(src)), C.byref(img(weight)), C.byref(img(dst_roi)), C.byref(img(dst_weight_roi)),
+                                      dst_roi.shape[1], dst_roi.shape[0], _stream()))
+
+
+def normalize_using_weight_32f(weight, src):
+    _chk(load().ms_normalize_using_weight_32f(C.byref(img(weight)), C.byref(img(src)), src.shape[1], src.shape[0], _stream()))
+
+
+def compare_gt(src, thr):
+    dst = _new(src.shape, _torch().uint8)
+    _chk(load().ms_compare_gt_32f(C.byref(img(src)), C.c_float(thr), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def compare_eq(src, val):
+    dst = _new(src.shape, _torch().uint8)
+    _chk(load().ms_compare_eq_8u(C.byref(img(src)), int(val), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def set_zero_masked(image, mask):
+    _chk(load().ms_set_zero_masked_16sc3(C.byref(img(image)), C.byref(img(mask)), _stream()))
+
+
+def bitwise_and(a, b):
+    dst = _new(a.shape, a.dtype)
+    _chk(load().ms_bitwise_and_8u(C.byref(img(a)), C.byref(img(b)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def dilate3x3(src):
+    dst = _new(src.shape, src.dtype)
+    _chk(load().ms_dilate3x3_8u(C.byref(img(src)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def _fa(v, n):
+    import numpy as np
+    a = np.ascontiguousarray(v, np.float32).reshape(n)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def build_warp_maps(projection, tl_u, tl_v, rows, cols, k_rinv, scale, t=None):
+    torch = _torch()
+    mx = _new((rows, cols), torch.float32); my = _new((rows, cols), torch.float32)
+    ka, kp = _fa(k_rinv, 9)
+    tp = None
+    if t is not None:
+        ta, tp = _fa(t, 3)
+    _chk(load().ms_build_warp_maps(projection, tl_u, tl_v, C.byref(img(mx)), C.byref(img(my)), kp, kp, tp, C.c_float(scale), _stream()))
+    return mx, my
+
+
+def custom_resize(src, tx, ty):
+    dst = _new((ty, tx), src.dtype)
+    _chk(load().ms_custom_resize_32f(C.byref(img(src)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def warp_roi(projection, K, R, scale, src_w, src_h):
+    ka, kp = _fa(K, 9); ra, rp = _fa(R, 9)
+    r = Rect()
+    _chk(load().ms_warp_roi(projection, kp, rp, C.c_float(scale), src_w, src_h, C.byref(r)))
+    return r.tuple()
+
+
+def result_roi(rois):
+    arr = (Rect * len(rois))(*[Rect(*r) for r in rois])
+    r = Rect()
+    _chk(load().ms_result_roi(len(rois), arr, C.byref(r)))
+    return r.tuple()
+
+
+# ------------------------------------------------------------------ compositor context
+
+class Compositor:
+    """stitch_calib tables once (build_maps / build_masks / init_blender), then stitch() per frame batch."""
+
+    def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
+                 out_size=(0, 0), max_frames=1):
+        cfg = Config(num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
+                     out_size[0], out_size[1], max_frames)
+        self._ctx = C.c_void_p()
+        _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
+        self.cfg = cfg
+        self.n = num_views
+
+    def close(self):
+        if self._ctx:
+            load().ms_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, view, K, R):
+        ka, kp = _fa(K, 9); ra, rp = _fa(R, 9)
+        _chk(load().ms_set_camera(self._ctx, view, kp, rp))
+
+    def set_gain(self, view, gain):
+        _chk(load().ms_set_gain(self._ctx, view, C.c_double(gain)))
+
+    def build_maps(self):
+        _chk(load().ms_build_maps(self._ctx, _stream()))
+
+    def build_masks(self, mode=1):
+        _chk(load().ms_build_masks(self._ctx, mode, _stream()))
+
+    def set_mask(self, view, mask_np):
+        import numpy as np
+        m = np.ascontiguousarray(mask_np, np.uint8)
+        _chk(load().ms_set_mask(self._ctx, view, m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(m.strides[0])))
+
+    def init_blender(self):
+        _chk(load().ms_init_blender(self._ctx, _stream()))
+
+    def set_mesh(self, view, mesh_x, mesh_y):
+        ax, px = _fa(mesh_x, mesh_x.size); ay, py = _fa(mesh_y, mesh_y.size)
+        _chk(load().ms_set_mesh(self._ctx, view, px, py, mesh_x.shape[0], mesh_x.shape[1], _stream()))
+
+    def set_mesh_maps(self, view, xm, ym):
+        _chk(load().ms_set_mesh_maps(self._ctx, view, C.byref(img(xm)), C.byref(img(ym)), _stream()))
+
+    def view_geom(self, view):
+        g = ViewGeom()
+        _chk(load().ms_get_view_geom(self._ctx, view, C.byref(g)))
+        return g
+
+    def pano_geom(self):
+        g = PanoGeom()
+        _chk(load().ms_get_pano_geom(self._ctx, C.byref(g)))
+        return g
+
+    def maps(self, view):
+        xm, ym = Image(), Image()
+        _chk(load().ms_get_maps(self._ctx, view, C.byref(xm), C.byref(ym)))
+        return tensor_of(xm), tensor_of(ym)
+
+    def mask(self, view):
+        m = Image()
+        _chk(load().ms_get_mask(self._ctx, view, C.byref(m)))
+        return tensor_of(m)
+
+    def weight_level(self, view, level):
+        m = Image()
+        _chk(load().ms_get_weight_level(self._ctx, view, level, C.byref(m)))
+        return tensor_of(m)
+
+    def mesh_maps(self, view):
+        xm, ym = Image(), Image()
+        _chk(load().ms_get_mesh_maps(self._ctx, view, C.byref(xm), C.byref(ym)))
+        return tensor_of(xm), tensor_of(ym)
+
+    def result_mask(self):
+        m = Image()
+        _chk(load().ms_get_result_mask(self._ctx, C.byref(m)))
+        return tensor_of(m)
+
+    def _tables(self, frames, out8u, out16s):
+        n_frames = len(frames)
+        views = (Image * (n_frames * self.n))()
+        k = 0
+        for fr in frames:
+            assert len(fr) == self.n
+            for t in fr:
+                views[k] = img(t); k += 1
+        o8 = o16 = None
+        if out8u is not None:
+            o8 = (Image * n_frames)(*[img(t) for t in out8u])
+        if out16s is not None:
+            o16 = (Image * n_frames)(*[img(t) for t in out16s])
+        return n_frames, views, o8, o16
+
+    def stitch(self, frames, out8u=None, out16s=None):
+        """frames: list (per frame) of lists (per view) of uint8 HxWx3 cuda tensors."""
+        n, views, o8, o16 = self._tables(frames, out8u, out16s)
+        _chk(load().ms_stitch(self._ctx, n, views, o8, o16, _stream()))
+
+    def prepared(self, frames, out8u=None, out16s=None):
+        """Pre-marshal the descriptor tables once; returns a zero-overhead callable for timed loops."""
+        n, views, o8, o16 = self._tables(frames, out8u, out16s)
+        fn, ctx = load().ms_stitch, self._ctx
+
+        def run(stream=None):
+            _chk(fn(ctx, n, views, o8, o16, stream if stream is not None else _stream()))
+        run.keepalive = (frames, out8u, out16s, views, o8, o16)
+        return run
+
+    def stitch_timed(self, frames, out8u=None, out16s=None):
+        n, views, o8, o16 = self._tables(frames, out8u, out16s)
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        k = _chk(load().ms_stitch_timed(self._ctx, n, views, o8, o16, _stream(), cap, names, ms))
+        return [(names[i].decode(), ms[i]) for i in range(k)]

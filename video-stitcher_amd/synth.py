@@ -1,0 +1,76 @@
+"""Synthetic rig, frames and CPW meshes of SURVEY.md 8(d) -- shared by tests/ and bench.py.
+
+Pure numpy; produces host arrays.  No oracle and no GPU code in here.
+Rig model = the reference's calibrateCameras (APP/calibration.cpp:28-68): view i yaw = 2*pi*i/N about +y,
+principal point at the image centre, focal = (W/2)/tan(hfov/2), aspect 1.
+"""
+import math
+
+import numpy as np
+
+CONFIGS = {
+    # BASELINE.json configs[1]: 6x1080p -> 3840x1920 equirect, multiband, 5 bands
+    "cfg2": dict(n=6, w=1920, h=1080, hfov_deg=90.0, out_w=3840, out_h=1920, num_bands=5),
+    # configs[4]: 12x4K -> 7680x3840
+    "cfg5": dict(n=12, w=3840, h=2160, hfov_deg=60.0, out_w=7680, out_h=3840, num_bands=5),
+    # small rigs for oracle-speed parity tests
+    "mini6": dict(n=6, w=320, h=180, hfov_deg=90.0, out_w=640, out_h=320, num_bands=3),
+    "mini4": dict(n=4, w=200, h=150, hfov_deg=110.0, out_w=512, out_h=256, num_bands=4),
+}
+
+
+def camera(n, w, h, hfov_deg, i, yaw=None):
+    """K, R (fp32 3x3) of view i: rot = static_cast<float>(2.0*PI*float(i)/N) (calibration.cpp:35)."""
+    rot = np.float32(2.0 * math.pi * float(i) / n) if yaw is None else np.float32(yaw)
+    c, s = math.cos(rot), math.sin(rot)   # cos(float) promoted to double, stored as float
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float32)
+    f = (w / 2.0) / math.tan(math.radians(hfov_deg) / 2.0)
+    K = np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1]], np.float32)
+    return K, R
+
+
+def warp_scale(out_w):
+    """scale so that the full circle is exactly out_w columns."""
+    return float(np.float32(out_w / (2.0 * math.pi)))
+
+
+def gains(n):
+    return [1.0 + 0.02 * (i - (n - 1) / 2.0) for i in range(n)]
+
+
+def frame(w, h, i, t, noise=True):
+    """BGR uint8 HxWx3: clip(128 + 60 sin(2pi(x/97 + y/61 + c/3 + i/7)) + 40 checker(x//32, y//32) + U[-8,8])."""
+    x = np.arange(w, dtype=np.float64)[None, :]
+    y = np.arange(h, dtype=np.float64)[:, None]
+    phase = x / 97.0 + y / 61.0 + i / 7.0
+    chk = 40.0 * (((np.arange(w)[None, :] // 32) + (np.arange(h)[:, None] // 32)) & 1)
+    out = np.empty((h, w, 3), np.float64)
+    for c in range(3):
+        out[:, :, c] = 128.0 + 60.0 * np.sin(2.0 * math.pi * (phase + c / 3.0)) + chk
+    if noise:
+        rng = np.random.Generator(np.random.PCG64(1234 + 1000 * i + t))
+        out += rng.uniform(-8.0, 8.0, size=out.shape)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def mesh(aw, ah, n_rows, n_cols, phase=0.0, amp=8.0):
+    """Forward vertex mesh (N x M) in view-ROI pixels: identity + amp*sin(2pi u + phase)*sin(pi v)."""
+    v = np.linspace(0.0, 1.0, n_rows)[:, None]
+    u = np.linspace(0.0, 1.0, n_cols)[None, :]
+    d = amp * np.sin(2.0 * math.pi * u + phase) * np.sin(math.pi * v)
+    mx = (u * (aw - 1) + d).astype(np.float32) * np.ones((n_rows, 1), np.float32)
+    my = (v * (ah - 1) + 0.5 * d).astype(np.float32) * np.ones((1, n_cols), np.float32)
+    return np.ascontiguousarray(mx, np.float32), np.ascontiguousarray(my, np.float32)
+
+
+def algorithmic_bytes(view_src_wh, padded_px, pano_padded_px, out_wh, warped_px=0, cpw=False):
+    """SURVEY.md 8(d) contract figure B_alg (bytes per frame):
+    sum_v[3 W H + 45.33 P_v] + 18 Q + 3 W_out H_out (+ 6 bytes per warped pixel for the CPW gather)."""
+    n = len(padded_px)
+    b = n * 3.0 * view_src_wh[0] * view_src_wh[1]
+    b += (24.0 + 16.0 / 3.0 + 16.0) * float(sum(padded_px))
+    b += 18.0 * pano_padded_px
+    b += 3.0 * out_wh[0] * out_wh[1]
+    if cpw:
+        b += 6.0 * warped_px
+    return b
