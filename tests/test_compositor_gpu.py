@@ -112,6 +112,27 @@ def test_full_size_config2_matches_oracle(ms, cuda, oracle):
     comp.close()
 
 
+@pytest.mark.parametrize("rig,cpw", [("cfg2", False), ("mini6", True), ("mini4", False)])
+def test_tiled_kernels_equal_simple_kernels(ms, cuda, rig, cpw):
+    """The work-list / multi-pixel-per-lane kernels against the one-pixel-per-lane kernels (same library,
+    debug switch): identical 16S panorama, also where whole tiles are skipped as zero-weight."""
+    outs = []
+    for simple in (False, True):
+        comp, cfg, gains = make_rig(ms, rig, enable_cpw=cpw, simple_kernels=simple)
+        if cpw:
+            for i in range(cfg["n"]):
+                r = comp.view_geom(i).roi
+                comp.set_mesh(i, *synth.mesh(r.width, r.height, 8, 9, phase=0.2 * i, amp=3.0))
+        pg = comp.pano_geom()
+        out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+        out8 = torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda)
+        comp.stitch([[to_dev(synth.frame(cfg["w"], cfg["h"], i, 1)) for i in range(cfg["n"])]], out8u=[out8], out16s=[out16])
+        torch.cuda.synchronize()
+        outs.append((out16, out8))
+        comp.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_state_errors(ms, cuda):
     comp = ms.Compositor(2, (64, 48), ms.PROJ_SPHERICAL, 50.0, num_bands=2, out_size=(0, 0))
     with pytest.raises(ms.MsError, match="camera 0 not set"):

@@ -23,45 +23,9 @@
 #include <vector>
 #include "common.hpp"
 #include "launchers.hpp"
+#include "descs.hpp"
 
 namespace ms {
-
-constexpr int MAX_LEVELS = 8;     // num_bands <= 7
-constexpr int MAX_VIEWS = 16;
-constexpr int MAX_SRC = 128;      // frames * views per ms_stitch call
-constexpr int MAX_FRAMES = 32;    // frames per ms_stitch call
-
-struct LevelDesc {
-    int w, h, pitch;              // level size; pitch in elements
-    int x_tl, y_tl;               // position inside the padded pano at this level
-    long long off;                // element offset of plane 0 inside the per-frame pyramid buffer
-    const float *wgt;             // weight pyramid level (static)
-    int wpitch;
-};
-struct ViewDesc {
-    int aw, ah;                   // warped view size (warpRoi)
-    int top, left;                // reflect border
-    int pw, ph;                   // padded size
-    float gain;
-    const float *xmap, *ymap;     // projection maps (static), pitch in elements
-    int map_pitch;
-    long long s1_off;             // byte offset of the CPW stage-1 image inside the per-frame stage buffer
-    LevelDesc lv[MAX_LEVELS];
-};
-struct PanoDesc {
-    int nb, n_views;
-    int qw[MAX_LEVELS], qh[MAX_LEVELS], qpitch[MAX_LEVELS];
-    long long coff[MAX_LEVELS];   // element offset of collapsed level l (l >= 1) in the per-frame buffer
-    const float *den[MAX_LEVELS]; // sum_v w_v + 1e-5f (static)
-    int dpitch[MAX_LEVELS];
-    const uint8_t *mask;          // gpu_dst_mask_ over dst_roi_final
-    int mask_pitch;
-    int fw, fh;                   // dst_roi_final size
-    int canvas_x, canvas_y, out_w, out_h;
-};
-struct SrcTable { const uint8_t *p[MAX_SRC]; unsigned step[MAX_SRC]; };
-struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pitch[MAX_VIEWS]; };
-struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *p16[MAX_FRAMES]; unsigned step16[MAX_FRAMES]; };
 
 // ------------------------------------------------------------------------------------------------
 // bilinear sample of an interleaved 8UC3 image, constant-0 border (remap.cu:56-68 + filters.hpp:90-114)
@@ -96,7 +60,7 @@ __global__ void __launch_bounds__(256) k_remap_gain(const ViewDesc *__restrict__
     const float xc = V.xmap[(size_t)y * V.map_pitch + x], yc = V.ymap[(size_t)y * V.map_pitch + x];
     float o[3];
     sample3(src.p[blockIdx.z], src.step[blockIdx.z], src_rows, src_cols, xc, yc, o);
-    uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + ((size_t)y * V.aw + x) * 3;
+    uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) d[c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
 }
@@ -117,7 +81,7 @@ __global__ void __launch_bounds__(256) k_warp(const ViewDesc *__restrict__ views
     uint8_t r[3];
     if (CPW) {
         const float xc = mesh.x[v][(size_t)ay * mesh.pitch[v] + ax], yc = mesh.y[v][(size_t)ay * mesh.pitch[v] + ax];
-        sample3(stage + (size_t)f * stage_stride + V.s1_off, (unsigned)(V.aw * 3), V.ah, V.aw, xc, yc, o);
+        sample3(stage + (size_t)f * stage_stride + V.s1_off, (unsigned)V.s1_pitch, V.ah, V.aw, xc, yc, o);
 #pragma unroll
         for (int c = 0; c < 3; ++c) r[c] = sat_u8(o[c]);
     } else {
@@ -158,6 +122,99 @@ __global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views
     }
     gout[(size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + x] = sat_s16(rne_shift(acc, 8));
 }
+
+// ---- vectorised pyrDown: 2 output rows x 4 output columns per thread --------------------------------
+// Needs input width % 8 == 0 (true for every level l <= nb-3 because padded views are multiples of 2^nb).
+// One input row contributes columns [8t-2, 8t+8]: a 16-byte (int16) / 8-byte (u8) aligned body plus a
+// 2-pixel left and 1-pixel right halo; BORDER_REFLECT_101 only touches the first/last thread of a row,
+// where the mirrored columns are already inside the body (col -2 -> 2, -1 -> 1, w -> w-2).
+// Raw row fetch: body + halos, all issued unconditionally (clamped addresses) so that the 7 rows' loads are
+// in flight together; the reflect selection happens after, in registers.
+struct Row11u8 { uint2 b; unsigned l; unsigned r; };
+struct Row11s16 { uint4 b; unsigned l; int r; };
+__device__ __forceinline__ Row11u8 fetch_row11(const uint8_t *__restrict__ row, int t, int w)
+{
+    Row11u8 o;
+    o.b = *reinterpret_cast<const uint2 *>(row + 8 * t);
+    o.l = *reinterpret_cast<const uint16_t *>(row + max(8 * t - 2, 0));
+    o.r = row[min(8 * t + 8, w - 1)];
+    return o;
+}
+__device__ __forceinline__ Row11s16 fetch_row11(const int16_t *__restrict__ row, int t, int w)
+{
+    Row11s16 o;
+    o.b = *reinterpret_cast<const uint4 *>(row + 8 * t);
+    o.l = *reinterpret_cast<const unsigned *>(row + max(8 * t - 2, 0));
+    o.r = row[min(8 * t + 8, w - 1)];
+    return o;
+}
+__device__ __forceinline__ void unpack_row11(const Row11u8 &o, int t, int w, int v[11])
+{
+    v[2] = o.b.x & 0xff; v[3] = (o.b.x >> 8) & 0xff; v[4] = (o.b.x >> 16) & 0xff; v[5] = o.b.x >> 24;
+    v[6] = o.b.y & 0xff; v[7] = (o.b.y >> 8) & 0xff; v[8] = (o.b.y >> 16) & 0xff; v[9] = o.b.y >> 24;
+    v[0] = (t == 0) ? v[4] : (int)(o.l & 0xff);            // col -2 -> 2
+    v[1] = (t == 0) ? v[3] : (int)((o.l >> 8) & 0xff);     // col -1 -> 1
+    v[10] = (8 * t + 8 >= w) ? v[8] : (int)o.r;            // col w -> w-2
+}
+__device__ __forceinline__ void unpack_row11(const Row11s16 &o, int t, int w, int v[11])
+{
+    v[2] = (int16_t)(o.b.x & 0xffff); v[3] = (int)o.b.x >> 16; v[4] = (int16_t)(o.b.y & 0xffff); v[5] = (int)o.b.y >> 16;
+    v[6] = (int16_t)(o.b.z & 0xffff); v[7] = (int)o.b.z >> 16; v[8] = (int16_t)(o.b.w & 0xffff); v[9] = (int)o.b.w >> 16;
+    v[0] = (t == 0) ? v[4] : (int)(int16_t)(o.l & 0xffff);
+    v[1] = (t == 0) ? v[3] : ((int)o.l >> 16);
+    v[10] = (8 * t + 8 >= w) ? v[8] : o.r;
+}
+template <typename T> struct Row11 { using type = Row11u8; };
+template <> struct Row11<int16_t> { using type = Row11s16; };
+
+template <typename TIN>
+__global__ void __launch_bounds__(256) k_down_vec(const ViewDesc *__restrict__ views, int n_views, int l,
+                                                  const TIN *__restrict__ gin, long long in_stride,
+                                                  int16_t *__restrict__ gout, long long out_stride)
+{
+    const int z = blockIdx.z, c = z % 3, v = (z / 3) % n_views, f = z / (3 * n_views);
+    const LevelDesc &Li = views[v].lv[l], &Lo = views[v].lv[l + 1];
+    const int t = blockIdx.x * 64 + threadIdx.x;            // group of 4 output columns
+    const int y = 2 * (blockIdx.y * 4 + threadIdx.y);       // first of 2 output rows
+    if (4 * t >= Lo.w || y >= Lo.h) return;
+    const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
+    const bool two = (y + 1) < Lo.h;
+    const int sy = 2 * y, h = Li.h, last = h - 1;
+    // BORDER_REFLECT_101 rows (h >= 3: no modulo needed, |overshoot| <= 2)
+    int ridx[7];
+    ridx[0] = abs(sy - 2); ridx[1] = abs(sy - 1); ridx[2] = sy;
+#pragma unroll
+    for (int j = 3; j < 7; ++j) { const int r = sy + j - 2; ridx[j] = r > last ? 2 * last - r : r; }
+    if (!two) { ridx[5] = ridx[4]; ridx[6] = ridx[4]; }      // unused rows: any valid address
+    typename Row11<TIN>::type raw[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) raw[j] = fetch_row11(in + (size_t)ridx[j] * Li.pitch, t, Li.w);
+    int V0[11], V1[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) V0[k] = V1[k] = 0;
+    const int w0[7] = {1, 4, 6, 4, 1, 0, 0}, w1[7] = {0, 0, 1, 4, 6, 4, 1};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        int r[11];
+        unpack_row11(raw[j], t, Li.w, r);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { V0[k] += w0[j] * r[k]; V1[k] += w1[j] * r[k]; }
+    }
+    int16_t *out = gout + (size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + 4 * t;
+    auto emit = [&](const int *V, int16_t *dst) {
+        unsigned o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = (unsigned)(uint16_t)sat_s16(rne_shift(V[2 * i] + 4 * V[2 * i + 1] + 6 * V[2 * i + 2] + 4 * V[2 * i + 3] + V[2 * i + 4], 8));
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    };
+    emit(V0, out);
+    if (two) emit(V1, out + Lo.pitch);
+}
+
+}  // namespace ms
+#include "tile_kernels.hpp"
+namespace ms {
 
 // pyrUp of a 2x2 quad whose top-left fine pixel is (2i, 2j), from a planar int16 coarse level
 // (pyr_up.cu:55-145 in exact integer form).  out[0..3] = (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1).
@@ -300,6 +357,191 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
     }
 }
 
+// ---- vectorised band kernel: 2 rows x 8 columns per thread ------------------------------------------
+// Valid where every view rect and the pano level are 8-aligned in x and 2-aligned in y (levels l <= nb-3).
+// Same arithmetic as k_blend; views whose 16 weights are all zero are skipped (trunc(L*0) == 0 exactly),
+// which removes most of the work of the +-pi-straddling full-width view.
+__device__ __forceinline__ void unpack8(const uint4 b, int v[8])
+{
+    v[0] = (int16_t)(b.x & 0xffff); v[1] = (int)b.x >> 16; v[2] = (int16_t)(b.y & 0xffff); v[3] = (int)b.y >> 16;
+    v[4] = (int16_t)(b.z & 0xffff); v[5] = (int)b.z >> 16; v[6] = (int16_t)(b.w & 0xffff); v[7] = (int)b.w >> 16;
+}
+__device__ __forceinline__ void unpack8(const uint2 b, int v[8])
+{
+    v[0] = b.x & 0xff; v[1] = (b.x >> 8) & 0xff; v[2] = (b.x >> 16) & 0xff; v[3] = b.x >> 24;
+    v[4] = b.y & 0xff; v[5] = (b.y >> 8) & 0xff; v[6] = (b.y >> 16) & 0xff; v[7] = b.y >> 24;
+}
+// pyrUp of the 2x8 fine block whose top-left is (2i, 2*j0) (j0 % 4 == 0, cw % 4 == 0) from one coarse plane
+__device__ __forceinline__ void up_2x8(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
+                                       int ue[8], int uo[8])
+{
+    const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
+    int he[3][4], ho[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int16_t *row = cs + (size_t)rr[r] * cpitch;
+        const uint2 b = *reinterpret_cast<const uint2 *>(row + j0);
+        int a[6];
+        a[1] = (int16_t)(b.x & 0xffff); a[2] = (int)b.x >> 16; a[3] = (int16_t)(b.y & 0xffff); a[4] = (int)b.y >> 16;
+        a[0] = (j0 == 0) ? a[2] : (int)row[j0 - 1];             // |-1| = 1
+        a[5] = (j0 + 4 >= cw) ? a[4] : (int)row[j0 + 4];        // min(cw-1, .)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { he[r][q] = a[q] + 6 * a[q + 1] + a[q + 2]; ho[r][q] = 4 * (a[q + 1] + a[q + 2]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ue[2 * q] = sat_s16(rne_shift(he[0][q] + 6 * he[1][q] + he[2][q], 6));
+        ue[2 * q + 1] = sat_s16(rne_shift(ho[0][q] + 6 * ho[1][q] + ho[2][q], 6));
+        uo[2 * q] = sat_s16(rne_shift(4 * (he[1][q] + he[2][q]), 6));
+        uo[2 * q + 1] = sat_s16(rne_shift(4 * (ho[1][q] + ho[2][q]), 6));
+    }
+}
+
+template <bool L0>
+__global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
+                                                const uint8_t *__restrict__ g0, long long g0_stride,
+                                                const int16_t *__restrict__ gl, long long gl_stride,
+                                                int16_t *__restrict__ cl, long long cl_stride, OutTable out)
+{
+    const BlendTile T = tiles[blockIdx.x];
+    const int f = blockIdx.z;
+    const int x0 = T.x0 + 8 * (int)threadIdx.x, y0 = T.y0 + 2 * (int)threadIdx.y;   // block 32 x 8 lanes = 256 x 16 px
+    if (x0 >= P.qw[l] || y0 >= P.qh[l]) return;
+    int acc[3][2][8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[c][0][k] = acc[c][1][k] = 0;
+
+    for (unsigned vm = T.view_mask; vm; vm &= vm - 1) {      // only the views with a non-zero weight in this tile
+        const int v = __builtin_ctz(vm);
+        const LevelDesc &L = views[v].lv[l];
+        const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
+        if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
+        const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
+        const float4 wa = *reinterpret_cast<const float4 *>(wp), wb = *reinterpret_cast<const float4 *>(wp + 4);
+        const float4 wc = *reinterpret_cast<const float4 *>(wp + L.wpitch), wd = *reinterpret_cast<const float4 *>(wp + L.wpitch + 4);
+        const float w[2][8] = {{wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w}, {wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z, wd.w}};
+        float wsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wsum += w[0][k] + w[1][k];      // weights are >= 0
+        if (wsum == 0.f) continue;
+        const LevelDesc &C = views[v].lv[l + 1];
+        const size_t fplane = (size_t)L.h * L.pitch, cplane = (size_t)C.h * C.pitch;
+        const size_t fo = (size_t)ly * L.pitch + lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int up[2][8];
+            up_2x8(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up[0], up[1]);
+            int g[2][8];
+            if (L0) {
+                const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + c * fplane + fo;
+                unpack8(*reinterpret_cast<const uint2 *>(p), g[0]);
+                unpack8(*reinterpret_cast<const uint2 *>(p + L.pitch), g[1]);
+            } else {
+                const int16_t *p = gl + (size_t)f * gl_stride + L.off + c * fplane + fo;
+                unpack8(*reinterpret_cast<const uint4 *>(p), g[0]);
+                unpack8(*reinterpret_cast<const uint4 *>(p + L.pitch), g[1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc[c][r][k] += (int)trunc_s16((float)(int)sat_s16(g[r][k] - up[r][k]) * w[r][k]);
+        }
+    }
+
+    const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
+    const float4 da = *reinterpret_cast<const float4 *>(dp), db = *reinterpret_cast<const float4 *>(dp + 4);
+    const float4 dc = *reinterpret_cast<const float4 *>(dp + P.dpitch[l]), dd = *reinterpret_cast<const float4 *>(dp + P.dpitch[l] + 4);
+    const float den[2][8] = {{da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w}, {dc.x, dc.y, dc.z, dc.w, dd.x, dd.y, dd.z, dd.w}};
+    const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
+    const int16_t *cc = cl + (size_t)f * cl_stride + P.coff[l + 1];
+    int res[3][2][8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int up[2][8];
+        up_2x8(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, up[0], up[1]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)   // int16 accumulation wraps: (short)(sum) == successive `short +=`
+                res[c][r][k] = sat_s16(up[r][k] + (int)trunc_s16((float)(int)(int16_t)acc[c][r][k] / den[r][k]));
+    }
+
+    if (!L0) {
+        const size_t plane = (size_t)P.qh[l] * P.qpitch[l];
+        int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)y0 * P.qpitch[l] + x0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                uint4 o;
+                o.x = (unsigned)(uint16_t)res[c][r][0] | ((unsigned)(uint16_t)res[c][r][1] << 16);
+                o.y = (unsigned)(uint16_t)res[c][r][2] | ((unsigned)(uint16_t)res[c][r][3] << 16);
+                o.z = (unsigned)(uint16_t)res[c][r][4] | ((unsigned)(uint16_t)res[c][r][5] << 16);
+                o.w = (unsigned)(uint16_t)res[c][r][6] | ((unsigned)(uint16_t)res[c][r][7] << 16);
+                *reinterpret_cast<uint4 *>(d + c * plane + (size_t)r * P.qpitch[l]) = o;
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + r;
+            if (y >= P.fh) continue;
+            const uint8_t *mrow = P.mask + (size_t)y * P.mask_pitch;
+            int px[8][3];
+            const int nvalid = min(8, P.fw - x0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool m = (k < nvalid) && mrow[x0 + k] != 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[k][c] = m ? res[c][r][k] : 0;
+            }
+            if (out.p16[f]) {
+                int16_t *d = (int16_t *)((char *)out.p16[f] + (size_t)y * out.step16[f]) + 3 * x0;
+                if (nvalid == 8) {
+                    unsigned wds[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        const int e0 = 2 * i, e1 = 2 * i + 1;
+                        wds[i] = (unsigned)(uint16_t)px[e0 / 3][e0 % 3] | ((unsigned)(uint16_t)px[e1 / 3][e1 % 3] << 16);
+                    }
+                    __builtin_memcpy(d, wds, 48);
+                } else {
+                    for (int k = 0; k < nvalid; ++k) { d[3 * k] = (int16_t)px[k][0]; d[3 * k + 1] = (int16_t)px[k][1]; d[3 * k + 2] = (int16_t)px[k][2]; }
+                }
+            }
+            if (out.p8[f]) {
+                const int cy = y + P.canvas_y, cx0 = x0 + P.canvas_x;
+                if (cy >= 0 && cy < P.out_h) {
+                    uint8_t *d = out.p8[f] + (size_t)cy * out.step8[f] + 3 * (size_t)cx0;
+                    if (nvalid == 8 && cx0 >= 0 && cx0 + 8 <= P.out_w) {
+                        unsigned wds[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            unsigned wv = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int e = 4 * i + b;
+                                wv |= (unsigned)min(max(px[e / 3][e % 3], 0), 255) << (8 * b);
+                            }
+                            wds[i] = wv;
+                        }
+                        __builtin_memcpy(d, wds, 24);
+                    } else {
+                        for (int k = 0; k < nvalid; ++k) {
+                            const int cx = cx0 + k;
+                            if (cx < 0 || cx >= P.out_w) continue;
+                            d[3 * k] = (uint8_t)min(max(px[k][0], 0), 255); d[3 * k + 1] = (uint8_t)min(max(px[k][1], 0), 255);
+                            d[3 * k + 2] = (uint8_t)min(max(px[k][2], 0), 255);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- static-table kernels ---------------------------------------------------------------------
 // warp(255-mask, INTER_NEAREST, BORDER_CONSTANT) == "does the truncated map coordinate hit the source"
 __global__ void __launch_bounds__(256) k_valid_mask(const float *__restrict__ mx, const float *__restrict__ my, int pitch, int rows, int cols,
@@ -399,6 +641,13 @@ struct ms_ctx {
     DevBuf g0, gl, cl, stage;
     long long g0_stride = 0, gl_stride = 0, cl_stride = 0, stage_stride = 0;
     int max_pw = 0, max_ph = 0, max_aw = 0, max_ah = 0;
+    bool down_vec[MAX_LEVELS] = {};    // level l -> l+1 may use the vectorised kernel
+    bool blend_vec[MAX_LEVELS] = {};   // band l may use the 2x8 kernel
+    // work lists (tiles that are actually needed)
+    bool warp_tiled = false;
+    DevBuf warp_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
+    int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
+    double plan_fraction = 1.0;        // needed level-0 pixels / padded pixels
     // CPW mesh maps, double buffered
     DevBuf mesh[2];
     size_t mesh_off[MAX_VIEWS] = {};
@@ -427,6 +676,152 @@ static ms_image view_map_image(const ms_ctx *c, int v, int which)
     float *base = (float *)c->maps.p + c->map_off[v] + (which ? (size_t)ah * c->map_pitch[v] : 0);
     m.data = base; m.step = (size_t)c->map_pitch[v] * sizeof(float); m.rows = ah; m.cols = aw; m.type = MS_32FC1;
     return m;
+}
+
+}  // namespace ms
+
+
+// ---- the plan: which tiles of which view/level are needed ------------------------------------------------
+// W_l = {w_{v,l} != 0};  N_l = pixels of Gaussian level l some consumer reads:
+//   band l reads G_l on W_l and G_{l+1} on the 3x3 neighbourhood of W_l/2 (pyrUp taps);
+//   pyrDown reads G_l on the 5x5 neighbourhood of 2*N_{l+1}.
+// Everything outside is multiplied by a weight that is exactly 0, so never producing it is exact.
+namespace ms {
+namespace {
+
+using Bits = std::vector<uint8_t>;
+
+Bits dilate(const Bits &s, int w, int h, int r)
+{
+    Bits t((size_t)w * h, 0), o((size_t)w * h, 0);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint8_t m = 0;
+            for (int k = std::max(0, x - r); k <= std::min(w - 1, x + r) && !m; ++k) m = s[(size_t)y * w + k];
+            t[(size_t)y * w + x] = m;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint8_t m = 0;
+            for (int k = std::max(0, y - r); k <= std::min(h - 1, y + r) && !m; ++k) m = t[(size_t)k * w + x];
+            o[(size_t)y * w + x] = m;
+        }
+    return o;
+}
+Bits half(const Bits &s, int w, int h)        // OR over 2x2 -> ((w+1)/2, (h+1)/2)
+{
+    const int hw = (w + 1) / 2, hh = (h + 1) / 2;
+    Bits o((size_t)hw * hh, 0);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            if (s[(size_t)y * w + x]) o[(size_t)(y / 2) * hw + x / 2] = 1;
+    return o;
+}
+Bits twice(const Bits &s, int w, int h, int W, int H)   // nearest upsample to (W, H)
+{
+    Bits o((size_t)W * H, 0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) o[(size_t)y * W + x] = s[(size_t)std::min(y / 2, h - 1) * w + std::min(x / 2, w - 1)];
+    return o;
+}
+bool any_in(const Bits &s, int w, int h, int x0, int y0, int tw, int th)
+{
+    for (int y = std::max(y0, 0); y < std::min(y0 + th, h); ++y)
+        for (int x = std::max(x0, 0); x < std::min(x0 + tw, w); ++x)
+            if (s[(size_t)y * w + x]) return true;
+    return false;
+}
+
+}  // namespace
+
+static int build_plan(ms_ctx *c)
+{
+    const int N = c->N, nb = c->pano.nb;
+    std::vector<float> hw(c->weights.bytes / sizeof(float));
+    MS_HIP(hipMemcpy(hw.data(), c->weights.p, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<std::vector<Bits>> W(N, std::vector<Bits>(nb + 1)), Nd(N, std::vector<Bits>(nb + 1));
+    for (int v = 0; v < N; ++v)
+        for (int l = 0; l <= nb; ++l) {
+            const LevelDesc &L = c->h_views[v].lv[l];
+            Bits &b = W[v][l];
+            b.assign((size_t)L.w * L.h, 0);
+            const float *p = hw.data() + c->w_off[v][l];
+            for (int y = 0; y < L.h; ++y)
+                for (int x = 0; x < L.w; ++x) b[(size_t)y * L.w + x] = p[(size_t)y * L.wpitch + x] != 0.f;
+        }
+    double need0 = 0, tot0 = 0;
+    for (int v = 0; v < N; ++v) {
+        const ViewDesc &V = c->h_views[v];
+        for (int l = nb; l >= 0; --l) {
+            const LevelDesc &L = V.lv[l];
+            Bits n = W[v][l];
+            if (l >= 1) {   // pyrUp taps of band l-1
+                const LevelDesc &F = V.lv[l - 1];
+                Bits u = dilate(half(W[v][l - 1], F.w, F.h), L.w, L.h, 1);
+                for (size_t i = 0; i < n.size(); ++i) n[i] |= u[i];
+            }
+            if (l < nb) {   // pyrDown taps of level l+1
+                const LevelDesc &C = V.lv[l + 1];
+                Bits d = dilate(twice(Nd[v][l + 1], C.w, C.h, L.w, L.h), L.w, L.h, 2);
+                for (size_t i = 0; i < n.size(); ++i) n[i] |= d[i];
+            }
+            Nd[v][l] = std::move(n);
+        }
+        tot0 += (double)V.pw * V.ph;
+    }
+    // warp tiles (level 0)
+    c->warp_tiled = true;
+    for (int v = 0; v < N; ++v) c->warp_tiled = c->warp_tiled && (c->h_views[v].pw % 4 == 0);
+    {
+        std::vector<WarpTile> tiles;
+        for (int v = 0; v < N; ++v) {
+            const ViewDesc &V = c->h_views[v];
+            for (int y0 = 0; y0 < V.ph; y0 += WARP_TH)
+                for (int x0 = 0; x0 < V.pw; x0 += WARP_TW)
+                    if (any_in(Nd[v][0], V.pw, V.ph, x0, y0, WARP_TW, WARP_TH)) {
+                        WarpTile t{};
+                        t.view = (short)v; t.x0 = (short)x0; t.y0 = (short)y0;
+                        tiles.push_back(t);
+                        need0 += (double)std::min(WARP_TW, V.pw - x0) * std::min(WARP_TH, V.ph - y0);
+                    }
+        }
+        c->n_warp_tiles = (int)tiles.size();
+        if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
+        if (!tiles.empty()) MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
+    }
+    c->plan_fraction = tot0 > 0 ? need0 / tot0 : 1.0;
+    // pyrDown tiles: output tiles of level l+1
+    for (int l = 0; l < nb; ++l) {
+        std::vector<DownTile> tiles;
+        if (c->down_vec[l])
+            for (int v = 0; v < N; ++v) {
+                const LevelDesc &Lo = c->h_views[v].lv[l + 1];
+                for (int y0 = 0; y0 < Lo.h; y0 += DOWN_TH)
+                    for (int x0 = 0; x0 < Lo.w; x0 += DOWN_TW)
+                        if (any_in(Nd[v][l + 1], Lo.w, Lo.h, x0, y0, DOWN_TW, DOWN_TH)) tiles.push_back(DownTile{(short)v, 0, (short)x0, (short)y0});
+            }
+        c->n_down_tiles[l] = (int)tiles.size();
+        if (int e = c->down_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(DownTile))) return e;
+        if (!tiles.empty()) MS_HIP(hipMemcpy(c->down_tiles[l].p, tiles.data(), tiles.size() * sizeof(DownTile), hipMemcpyHostToDevice));
+    }
+    // band tiles: every pano tile, with the views that have a non-zero weight in it
+    for (int l = 0; l < nb; ++l) {
+        std::vector<BlendTile> tiles;
+        if (c->blend_vec[l])
+            for (int y0 = 0; y0 < c->pano.qh[l]; y0 += BLEND_TH)
+                for (int x0 = 0; x0 < c->pano.qw[l]; x0 += BLEND_TW) {
+                    unsigned m = 0;
+                    for (int v = 0; v < N; ++v) {
+                        const LevelDesc &L = c->h_views[v].lv[l];
+                        if (any_in(W[v][l], L.w, L.h, x0 - L.x_tl, y0 - L.y_tl, BLEND_TW, BLEND_TH)) m |= 1u << v;
+                    }
+                    tiles.push_back(BlendTile{(short)x0, (short)y0, m});
+                }
+        c->n_blend_tiles[l] = (int)tiles.size();
+        if (int e = c->blend_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(BlendTile))) return e;
+        if (!tiles.empty()) MS_HIP(hipMemcpy(c->blend_tiles[l].p, tiles.data(), tiles.size() * sizeof(BlendTile), hipMemcpyHostToDevice));
+    }
+    return MS_OK;
 }
 
 }  // namespace ms
@@ -462,6 +857,8 @@ void ms_destroy(ms_ctx *c)
     c->maps.release(); c->masks.release(); c->weights.release(); c->den.release(); c->result_mask.release();
     c->view_tab.release(); c->g0.release(); c->gl.release(); c->cl.release(); c->stage.release();
     c->mesh[0].release(); c->mesh[1].release(); c->mesh_tmp.release();
+    c->warp_tiles.release();
+    for (int l = 0; l < MAX_LEVELS; ++l) { c->down_tiles[l].release(); c->blend_tiles[l].release(); }
     if (c->last_stitch) (void)hipEventDestroy(c->last_stitch);
     delete c;
 }
@@ -600,7 +997,8 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         V.ymap = V.xmap + (size_t)V.ah * c->map_pitch[v];
         V.map_pitch = c->map_pitch[v];
         V.s1_off = stage_total;
-        stage_total += (long long)round_up(V.aw * V.ah * 3, 16);
+        V.s1_pitch = round_up(V.aw * 3, 4);
+        stage_total += (long long)round_up(V.s1_pitch * V.ah + 8, 16);
         c->max_pw = std::max(c->max_pw, V.pw); c->max_ph = std::max(c->max_ph, V.ph);
         c->max_aw = std::max(c->max_aw, V.aw); c->max_ah = std::max(c->max_ah, V.ah);
         int w = V.pw, h = V.ph, xt = c->pad[v].x_tl, yt = c->pad[v].y_tl;
@@ -615,6 +1013,23 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             else        { L.off = gl_total; gl_total += 3LL * h * L.pitch; }
             w = (w + 1) / 2; h = (h + 1) / 2; xt /= 2; yt /= 2;
         }
+    }
+    for (int l = 0; l < nb; ++l) {
+        bool ok = true;
+        for (int v = 0; v < N; ++v) {
+            const LevelDesc &L = c->h_views[v].lv[l];
+            ok = ok && (L.w % 8 == 0) && (L.w >= 8) && (L.h >= 3);
+        }
+        c->down_vec[l] = ok;
+    }
+    for (int l = 0; l < nb; ++l) {
+        int qw = c->bg.dst_roi.width >> l, qh = c->bg.dst_roi.height >> l;
+        bool ok = (qw % 8 == 0) && (qh % 2 == 0);
+        for (int v = 0; v < N; ++v) {
+            const LevelDesc &L = c->h_views[v].lv[l];
+            ok = ok && (L.w % 8 == 0) && (L.x_tl % 8 == 0) && (L.h % 2 == 0) && (L.y_tl % 2 == 0);
+        }
+        c->blend_vec[l] = ok;
     }
     if (int e = c->weights.alloc(w_total * sizeof(float))) return e;
     MS_HIP(hipMemsetAsync(c->weights.p, 0, w_total * sizeof(float), st));
@@ -698,6 +1113,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     }
     if (int e = c->view_tab.alloc(sizeof(ViewDesc) * N)) return e;
     MS_HIP(hipMemcpy(c->view_tab.p, c->h_views.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice));
+    if (int e = build_plan(c)) return e;
     c->blender_ready = true;
     return MS_OK;
 }
@@ -840,8 +1256,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
-        k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
-            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
+        if (c->warp_tiled && c->cfg.reserved[0] == 0)
+            k_warp_t<true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), 0, st>>>(
+                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
+        else
+            k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
+                vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
+    } else if (c->warp_tiled && c->cfg.reserved[0] == 0) {
+        k_warp_t<false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), 0, st>>>(
+            (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
@@ -853,9 +1276,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
     for (int l = 0; l < nb; ++l) {
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
-        const dim3 g(div_up(ow, 64), div_up(oh, 4), F * N * 3);
-        if (l == 0) k_down<uint8_t><<<g, blk, 0, st>>>(vt, N, l, g0, c->g0_stride, gl, c->gl_stride);
-        else        k_down<int16_t><<<g, blk, 0, st>>>(vt, N, l, gl, c->gl_stride, gl, c->gl_stride);
+        if (c->down_vec[l] && c->cfg.reserved[0] == 0) {   // level-l widths are multiples of 8: tile list, 2 rows x 4 cols per lane
+            const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
+            if (l == 0) k_down_t<uint8_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
+            else        k_down_t<int16_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
+        } else {
+            const dim3 g(div_up(ow, 64), div_up(oh, 4), F * N * 3);
+            if (l == 0) k_down<uint8_t><<<g, blk, 0, st>>>(vt, N, l, g0, c->g0_stride, gl, c->gl_stride);
+            else        k_down<int16_t><<<g, blk, 0, st>>>(vt, N, l, gl, c->gl_stride, gl, c->gl_stride);
+        }
         MS_LAUNCH_CHECK();
         if (int e = mark(down_names[l])) return e;
     }
@@ -868,9 +1297,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     MS_LAUNCH_CHECK();
     if (int e = mark(blend_names[nb])) return e;
     for (int l = nb - 1; l >= 0; --l) {
-        const dim3 g(div_up(P.qw[l] / 2, 64), div_up(P.qh[l] / 2, 4), F);
-        if (l == 0) k_blend<true><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
-        else        k_blend<false><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+        if (c->blend_vec[l] && c->cfg.reserved[0] == 0) {
+            const dim3 g(c->n_blend_tiles[l], 1, F), b(32, 8);
+            if (l == 0) k_blend8<true><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+            else        k_blend8<false><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+        } else {
+            const dim3 g(div_up(P.qw[l] / 2, 64), div_up(P.qh[l] / 2, 4), F);
+            if (l == 0) k_blend<true><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+            else        k_blend<false><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+        }
         MS_LAUNCH_CHECK();
         if (int e = mark(blend_names[l])) return e;
     }

@@ -1,0 +1,58 @@
+// descs.hpp -- device-visible descriptor tables of the compositor (static after calibration).
+#pragma once
+#include "common.hpp"
+
+namespace ms {
+
+constexpr int MAX_LEVELS = 8;     // num_bands <= 7
+constexpr int MAX_VIEWS = 16;
+constexpr int MAX_SRC = 128;      // frames * views per ms_stitch call
+constexpr int MAX_FRAMES = 32;    // frames per ms_stitch call
+
+struct LevelDesc {
+    int w, h, pitch;              // level size; pitch in elements
+    int x_tl, y_tl;               // position inside the padded pano at this level
+    long long off;                // element offset of plane 0 inside the per-frame pyramid buffer
+    const float *wgt;             // weight pyramid level (static)
+    int wpitch;
+};
+struct ViewDesc {
+    int aw, ah;                   // warped view size (warpRoi)
+    int top, left;                // reflect border
+    int pw, ph;                   // padded size
+    float gain;
+    const float *xmap, *ymap;     // projection maps (static), pitch in elements
+    int map_pitch;
+    long long s1_off;             // byte offset of the CPW stage-1 image inside the per-frame stage buffer
+    int s1_pitch;                 // its row pitch in bytes (multiple of 4)
+    LevelDesc lv[MAX_LEVELS];
+};
+struct PanoDesc {
+    int nb, n_views;
+    int qw[MAX_LEVELS], qh[MAX_LEVELS], qpitch[MAX_LEVELS];
+    long long coff[MAX_LEVELS];   // element offset of collapsed level l (l >= 1) in the per-frame buffer
+    const float *den[MAX_LEVELS]; // sum_v w_v + 1e-5f (static)
+    int dpitch[MAX_LEVELS];
+    const uint8_t *mask;          // gpu_dst_mask_ over dst_roi_final
+    int mask_pitch;
+    int fw, fh;                   // dst_roi_final size
+    int canvas_x, canvas_y, out_w, out_h;
+};
+struct SrcTable { const uint8_t *p[MAX_SRC]; unsigned step[MAX_SRC]; };
+struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pitch[MAX_VIEWS]; };
+struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *p16[MAX_FRAMES]; unsigned step16[MAX_FRAMES]; };
+
+
+// ---- work lists (built once in ms_init_blender, plan.cpp-style host code in compositor.hip) ----------
+// Every per-frame kernel is driven by a list of tiles that are actually needed: tiles of a view whose
+// weights are zero at every band (most of the +-pi-straddling view, the seam-cut outer parts of the others)
+// are never produced or read.  Skipping them is exact: a zero weight contributes trunc(L * 0) == 0.
+struct WarpTile { short view, flags; short x0, y0; short sx0, sy0, sw, sh; };   // out tile origin + source bbox
+struct DownTile { short view, pad; short x0, y0; };                              // output (level l+1) tile origin
+struct BlendTile { short x0, y0; unsigned view_mask; };                          // pano tile origin + contributing views
+
+constexpr int WARP_TW = 64, WARP_TH = 16;      // k_warp_t tile (4 px per thread, 16 x 16 threads)
+constexpr int DOWN_TW = 128, DOWN_TH = 16;     // k_down_t output tile (4 x 2 px per thread, 32 x 8 threads)
+constexpr int BLEND_TW = 256, BLEND_TH = 16;   // k_blend8_t tile (8 x 2 px per thread, 32 x 8 threads)
+
+}  // namespace ms
