@@ -371,20 +371,39 @@ __device__ __forceinline__ void unpack8(const uint2 b, int v[8])
     v[0] = b.x & 0xff; v[1] = (b.x >> 8) & 0xff; v[2] = (b.x >> 16) & 0xff; v[3] = b.x >> 24;
     v[4] = b.y & 0xff; v[5] = (b.y >> 8) & 0xff; v[6] = (b.y >> 16) & 0xff; v[7] = b.y >> 24;
 }
-// pyrUp of the 2x8 fine block whose top-left is (2i, 2*j0) (j0 % 4 == 0, cw % 4 == 0) from one coarse plane
+// 16 bytes from a 4-byte aligned address as one global_load_dwordx4
+__device__ __forceinline__ uint4 load16_a4(const void *p)
+{
+    uint4 r;
+    __builtin_memcpy(&r, __builtin_assume_aligned(p, 4), 16);
+    return r;
+}
+__device__ __forceinline__ uint2 load8_a1(const void *p)
+{
+    uint2 r;
+    __builtin_memcpy(&r, p, 8);
+    return r;
+}
+// pyrUp of the 2x8 fine block whose top-left is (2i, 2*j0) (j0 % 4 == 0, cw % 4 == 0) from one coarse plane.
+// One 16-byte load per coarse row: columns j0-2 .. j0+5 cover the 6 taps j0-1 .. j0+4 (at j0 == 0 the window
+// starts at 0 and column -1 mirrors to 1; past the right edge column cw clamps to cw-1).  The load may run two
+// int16 past the end of a row: rows are contiguous inside buffers that carry 64 bytes of slack.
 __device__ __forceinline__ void up_2x8(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
                                        int ue[8], int uo[8])
 {
     const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
+    const int jb = max(j0 - 2, 0);
+    uint4 raw[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
     int he[3][4], ho[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const int16_t *row = cs + (size_t)rr[r] * cpitch;
-        const uint2 b = *reinterpret_cast<const uint2 *>(row + j0);
-        int a[6];
-        a[1] = (int16_t)(b.x & 0xffff); a[2] = (int)b.x >> 16; a[3] = (int16_t)(b.y & 0xffff); a[4] = (int)b.y >> 16;
-        a[0] = (j0 == 0) ? a[2] : (int)row[j0 - 1];             // |-1| = 1
-        a[5] = (j0 + 4 >= cw) ? a[4] : (int)row[j0 + 4];        // min(cw-1, .)
+        int v[8], a[6];
+        unpack8(raw[r], v);
+        if (j0 == 0) { a[0] = v[1]; a[1] = v[0]; a[2] = v[1]; a[3] = v[2]; a[4] = v[3]; a[5] = v[4]; }
+        else { a[0] = v[1]; a[1] = v[2]; a[2] = v[3]; a[3] = v[4]; a[4] = v[5]; a[5] = v[6]; }
+        if (j0 + 4 >= cw) a[5] = a[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { he[r][q] = a[q] + 6 * a[q + 1] + a[q + 2]; ho[r][q] = 4 * (a[q + 1] + a[q + 2]); }
     }
@@ -418,10 +437,24 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
-        const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
-        const float4 wa = *reinterpret_cast<const float4 *>(wp), wb = *reinterpret_cast<const float4 *>(wp + 4);
-        const float4 wc = *reinterpret_cast<const float4 *>(wp + L.wpitch), wd = *reinterpret_cast<const float4 *>(wp + L.wpitch + 4);
-        const float w[2][8] = {{wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w}, {wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z, wd.w}};
+        float w[2][8];
+        if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
+            const uint8_t *mp = views[v].wm0 + (size_t)ly * views[v].wm0_pitch + lx;
+            int m0[8], m1[8];
+            unpack8(*reinterpret_cast<const uint2 *>(mp), m0);
+            unpack8(*reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch), m1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                w[0][k] = __builtin_fmaf(P.alpha, (float)m0[k], 0.f);
+                w[1][k] = __builtin_fmaf(P.alpha, (float)m1[k], 0.f);
+            }
+        } else {
+            const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
+            const float4 wa = *reinterpret_cast<const float4 *>(wp), wb = *reinterpret_cast<const float4 *>(wp + 4);
+            const float4 wc = *reinterpret_cast<const float4 *>(wp + L.wpitch), wd = *reinterpret_cast<const float4 *>(wp + L.wpitch + 4);
+            w[0][0] = wa.x; w[0][1] = wa.y; w[0][2] = wa.z; w[0][3] = wa.w; w[0][4] = wb.x; w[0][5] = wb.y; w[0][6] = wb.z; w[0][7] = wb.w;
+            w[1][0] = wc.x; w[1][1] = wc.y; w[1][2] = wc.z; w[1][3] = wc.w; w[1][4] = wd.x; w[1][5] = wd.y; w[1][6] = wd.z; w[1][7] = wd.w;
+        }
         float wsum = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) wsum += w[0][k] + w[1][k];      // weights are >= 0
@@ -491,9 +524,15 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
             const uint8_t *mrow = P.mask + (size_t)y * P.mask_pitch;
             int px[8][3];
             const int nvalid = min(8, P.fw - x0);
+            int mk[8];
+            if (nvalid == 8) unpack8(load8_a1(mrow + x0), mk);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mk[k] = (k < nvalid) ? (int)mrow[x0 + k] : 0;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const bool m = (k < nvalid) && mrow[x0 + k] != 0;
+                const bool m = mk[k] != 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[k][c] = m ? res[c][r][k] : 0;
             }
@@ -630,6 +669,8 @@ struct ms_ctx {
     DevBuf masks;                      // per view 8UC1 (aw x ah, pitch = aw)
     size_t mask_off[MAX_VIEWS] = {};
     DevBuf weights;                    // per view per level fp32
+    DevBuf wm0;                        // per view padded 8-bit mask (level-0 weights in 1 byte/px)
+    size_t wm0_off[MAX_VIEWS] = {};
     size_t w_off[MAX_VIEWS][MAX_LEVELS] = {};
     DevBuf den;                        // per level fp32 over the padded pano
     size_t den_off[MAX_LEVELS] = {};
@@ -854,7 +895,7 @@ void ms_destroy(ms_ctx *c)
 {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    c->maps.release(); c->masks.release(); c->weights.release(); c->den.release(); c->result_mask.release();
+    c->maps.release(); c->masks.release(); c->weights.release(); c->wm0.release(); c->den.release(); c->result_mask.release();
     c->view_tab.release(); c->g0.release(); c->gl.release(); c->cl.release(); c->stage.release();
     c->mesh[0].release(); c->mesh[1].release(); c->mesh_tmp.release();
     c->warp_tiles.release();
@@ -1033,6 +1074,23 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     }
     if (int e = c->weights.alloc(w_total * sizeof(float))) return e;
     MS_HIP(hipMemsetAsync(c->weights.p, 0, w_total * sizeof(float), st));
+    {
+        size_t m_total = 0;
+        for (int v = 0; v < N; ++v) {
+            ViewDesc &V = c->h_views[v];
+            V.wm0_pitch = round_up(V.pw, 16);
+            c->wm0_off[v] = m_total;
+            m_total += (size_t)V.wm0_pitch * V.ph;
+        }
+        if (int e = c->wm0.alloc(m_total + 64)) return e;
+        MS_HIP(hipMemsetAsync(c->wm0.p, 0, m_total + 64, st));
+        for (int v = 0; v < N; ++v) {
+            ViewDesc &V = c->h_views[v];
+            V.wm0 = (const uint8_t *)c->wm0.p + c->wm0_off[v];
+            MS_HIP(hipMemcpy2DAsync((uint8_t *)c->wm0.p + c->wm0_off[v] + (size_t)V.top * V.wm0_pitch + V.left, V.wm0_pitch,
+                                    (const uint8_t *)c->masks.p + c->mask_off[v], V.aw, V.aw, V.ah, hipMemcpyDeviceToDevice, st));
+        }
+    }
     for (int v = 0; v < N; ++v)
         for (int l = 0; l <= nb; ++l) c->h_views[v].lv[l].wgt = (const float *)c->weights.p + c->w_off[v][l];
 
@@ -1054,6 +1112,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     }
     P.fw = c->bg.dst_roi_final.width; P.fh = c->bg.dst_roi_final.height;
     P.mask_pitch = P.fw;
+    P.alpha = (float)(1. / 255.);
     P.canvas_x = c->canvas_x; P.canvas_y = c->canvas_y; P.out_w = c->cfg.out_width; P.out_h = c->cfg.out_height;
     if (int e = c->den.alloc(den_total * sizeof(float))) return e;
     if (int e = c->result_mask.alloc((size_t)P.fw * P.fh)) return e;

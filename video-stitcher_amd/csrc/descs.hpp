@@ -23,6 +23,8 @@ struct ViewDesc {
     float gain;
     const float *xmap, *ymap;     // projection maps (static), pitch in elements
     int map_pitch;
+    const uint8_t *wm0;           // padded 8-bit mask = level-0 weight before the 1/255 scale (static)
+    int wm0_pitch;
     long long s1_off;             // byte offset of the CPW stage-1 image inside the per-frame stage buffer
     int s1_pitch;                 // its row pitch in bytes (multiple of 4)
     LevelDesc lv[MAX_LEVELS];
@@ -33,6 +35,7 @@ struct PanoDesc {
     long long coff[MAX_LEVELS];   // element offset of collapsed level l (l >= 1) in the per-frame buffer
     const float *den[MAX_LEVELS]; // sum_v w_v + 1e-5f (static)
     int dpitch[MAX_LEVELS];
+    float alpha;                  // (float)(1./255.): level-0 weight = fmaf(alpha, mask, 0)
     const uint8_t *mask;          // gpu_dst_mask_ over dst_roi_final
     int mask_pitch;
     int fw, fh;                   // dst_roi_final size
