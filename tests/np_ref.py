@@ -1,0 +1,88 @@
+"""Independent numpy restatements of the reference kernels, used ONLY to cross-check the C oracle
+(tests/test_oracle_crosscheck.py).  Deliberately written differently from oracle/*.c: vectorised, integer
+arithmetic for the 16S pyramids (the CUDA fp32 sums are exact dyadics), float64 emulation of fmaf for the taps."""
+import numpy as np
+
+
+def r101(i, n):
+    i = np.abs(i)
+    return np.abs((n - 1) - np.abs((n - 1) - i)) % n
+
+
+def reflect(i, n):
+    last = n - 1
+    hi = last - np.abs(last - i) + (i > last)
+    return (np.abs(hi) - (hi < 0)) % n
+
+
+def rne_shift(s, k):
+    s = s.astype(np.int64)
+    return (s + ((1 << (k - 1)) - 1) + ((s >> k) & 1)) >> k
+
+
+def pyr_down_16s(src):
+    """pyr_down.cu:55-174 as an integer 5x5 binomial with BORDER_REFLECT_101 and round-half-even."""
+    h, w = src.shape[:2]
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    oy = np.arange((h + 1) // 2) * 2
+    ox = np.arange((w + 1) // 2) * 2
+    acc = 0
+    s = src.astype(np.int64)
+    for a in range(5):
+        rows = s[r101(oy + a - 2, h)]
+        for b in range(5):
+            acc = acc + k[a] * k[b] * rows[:, r101(ox + b - 2, w)]
+    return np.clip(rne_shift(acc, 8), -32768, 32767).astype(np.int16)
+
+
+def pyr_up_16s(src):
+    """pyr_up.cu:55-145: zero-insert, 5x5 binomial x4, source index min(n-1, |i|)."""
+    h, w = src.shape[:2]
+    s = src.astype(np.int64)
+    z = np.zeros((2 * h + 4, 2 * w + 4) + src.shape[2:], np.int64)    # dst grid with 2-px apron, index = dst + 2
+    ys = np.arange(-2, 2 * h + 2)
+    xs = np.arange(-2, 2 * w + 2)
+    ry = np.minimum(np.abs(ys >> 1), h - 1)
+    rx = np.minimum(np.abs(xs >> 1), w - 1)
+    full = s[ry][:, rx]
+    ev_y = (ys % 2 == 0)
+    ev_x = (xs % 2 == 0)
+    m = ev_y[:, None] & ev_x[None, :]
+    z = full * (m[..., None] if src.ndim == 3 else m)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    acc = 0
+    H, W = 2 * h, 2 * w
+    for a in range(5):
+        for b in range(5):
+            acc = acc + k[a] * k[b] * z[a:a + H, b:b + W]
+    return np.clip(rne_shift(acc, 6), -32768, 32767).astype(np.int16)
+
+
+def remap_linear(src, mx, my):
+    """filters.hpp:90-114 + border_interpolate.hpp:698-717; fmaf emulated in float64 (products of two fp32 are exact
+    in fp64; the final rounding to fp32 can double-round in rare cases -> compare with tolerance 1)."""
+    h, w = src.shape[:2]
+    x1 = np.floor(mx).astype(np.int64); y1 = np.floor(my).astype(np.int64)
+    x2, y2 = x1 + 1, y1 + 1
+    f = np.float32
+    wts = [((x2.astype(f) - mx) * (y2.astype(f) - my)), ((mx - x1.astype(f)) * (y2.astype(f) - my)),
+           ((x2.astype(f) - mx) * (my - y1.astype(f))), ((mx - x1.astype(f)) * (my - y1.astype(f)))]
+    taps = [(y1, x1), (y1, x2), (y2, x1), (y2, x2)]
+    out = np.zeros(mx.shape + (3,), np.float32)
+    for (yy, xx), wt in zip(taps, wts):
+        inb = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        v = np.where(inb[..., None], src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)], 0).astype(np.float64)
+        out = (v * wt[..., None].astype(np.float64) + out.astype(np.float64)).astype(np.float32)
+    r = np.rint(out)
+    return np.clip(np.nan_to_num(r, nan=0.0), 0, 255).astype(np.uint8)
+
+
+def add_src_weight(src, w, dst, dst_w):
+    t = np.trunc(src.astype(np.float32) * w[..., None].astype(np.float32)).astype(np.int64)
+    dst[...] = ((dst.astype(np.int64) + t + 32768) % 65536 - 32768).astype(np.int16)
+    dst_w += w
+
+
+def normalize(w, src):
+    den = (w + np.float32(1e-5)).astype(np.float32)
+    src[...] = np.trunc(src.astype(np.float32) / den[..., None]).astype(np.int16)

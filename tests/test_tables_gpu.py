@@ -1,0 +1,149 @@
+"""Calibration-time tables built on the device (ms_build_maps / ms_build_masks / ms_init_blender / ms_set_mesh)
+against the oracle: geometry exact (SURVEY App. C known answers), maps within the reference's own 1e-4-class
+tolerance (device sinf/cosf), masks/seams and weight pyramids exact GIVEN the same masks, CPW mesh -> map exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import host, make_rig, to_dev
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = {c["name"]: c for c in json.load(open(os.path.join(HERE, "golden", "geometry_kats.json")))["cases"]}
+
+
+def test_config2_geometry_known_answers(ms, cuda):
+    comp, cfg, _ = make_rig(ms, "cfg2", mask_mode=0)
+    case = KATS["config2_spherical"]
+    pg = comp.pano_geom()
+    assert list(pg.dst_roi_final.tuple()) == case["result_roi"] and list(pg.dst_roi.tuple()) == case["dst_roi"]
+    assert (pg.canvas_x, pg.canvas_y) == (1, 646)
+    for i, v in enumerate(case["views"]):
+        g = comp.view_geom(i)
+        assert list(g.roi.tuple()) == v["tl"] + v["size"]
+        assert [g.top, g.left, g.bottom, g.right] == v["tlbr"]
+        assert [g.x_tl, g.y_tl] == v["xy_tl"]
+        assert [g.x_br - g.x_tl, g.y_br - g.y_tl] == v["padded"]
+    comp.close()
+
+
+@pytest.mark.parametrize("proj", ["spherical", "cylindrical"])
+def test_maps_and_masks_vs_oracle(ms, cuda, oracle, proj):
+    pid = {"spherical": ms.PROJ_SPHERICAL, "cylindrical": ms.PROJ_CYLINDRICAL}[proj]
+    comp, cfg, _ = make_rig(ms, "mini6", mask_mode=1, projection=pid)
+    sc = synth.warp_scale(cfg["out_w"])
+    rois, masks_ref = [], []
+    for i in range(cfg["n"]):
+        K, R = synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i)
+        r = comp.view_geom(i).roi.tuple()
+        assert r == oracle.warp_roi(pid, K, R, sc, cfg["w"], cfg["h"])
+        rois.append(r)
+        rx, ry = oracle.build_warp_maps(pid, r[0], r[1], r[3], r[2], oracle.k_rinv_gpu(K, R), sc)
+        gx, gy = [host(t) for t in comp.maps(i)]
+        # reference bound: 1e-4 at scale 2 (ocl/test_warpers.cpp:100).  Here: 1e-3 px for coordinates that can touch the
+        # source image, relative 1e-4 for the far-out ones (x/z with z -> 0 amplifies the sinf/cosf ulp differences)
+        for g, r_, lim in ((gx, rx, cfg["w"]), (gy, ry, cfg["h"])):
+            near = np.abs(r_) < 4 * lim
+            assert np.abs(g - r_)[near].max() < 1e-3, float(np.abs(g - r_)[near].max())
+            assert np.allclose(g[~near], r_[~near], rtol=1e-4, atol=0), "far coordinates"
+        # valid mask = warp(255, NEAREST, CONSTANT) evaluated on the DEVICE maps -> exact
+        masks_ref.append(oracle.remap_nearest_8uc1(np.full((cfg["h"], cfg["w"]), 255, np.uint8), gx, gy))
+    oracle.voronoi_seams([r[:2] for r in rois], masks_ref)
+    for i in range(cfg["n"]):
+        assert np.array_equal(host(comp.mask(i)), masks_ref[i]), "seam mask of view %d" % i
+    # masks partition the covered area: no pixel belongs to two views after the seams
+    pg = comp.pano_geom()
+    cover = np.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width), np.int32)
+    for i, r in enumerate(rois):
+        y0, x0 = r[1] - pg.dst_roi_final.y, r[0] - pg.dst_roi_final.x
+        cover[y0:y0 + r[3], x0:x0 + r[2]] += masks_ref[i] != 0
+    assert cover.max() == 1
+    comp.close()
+
+
+def test_weight_pyramids_and_result_mask_vs_oracle(ms, cuda, oracle):
+    comp, cfg, _ = make_rig(ms, "mini4")
+    rois = [comp.view_geom(i).roi.tuple() for i in range(cfg["n"])]
+    b = oracle.Blender([r[:2] for r in rois], [r[2:] for r in rois], cfg["num_bands"])
+    assert b.num_bands == comp.pano_geom().num_bands
+    for i in range(cfg["n"]):
+        b.init_view(i, host(comp.mask(i)))
+        g, og = comp.view_geom(i), b.view_geom(i)
+        assert (g.top, g.left, g.bottom, g.right, g.x_tl, g.y_tl, g.x_br, g.y_br) == \
+               (og.top, og.left, og.bottom, og.right, og.x_tl, og.y_tl, og.x_br, og.y_br)
+        for l in range(b.num_bands + 1):
+            assert np.array_equal(host(comp.weight_level(i, l)), b.weight_level(i, l)), "weights view %d level %d" % (i, l)
+    b.close()
+    comp.close()
+
+
+def test_user_masks_override(ms, cuda, oracle):
+    """init_gpu receives the mask from the caller (blenders.cpp:344): arbitrary 8-bit masks, incl. grey values."""
+    comp, cfg, gains = make_rig(ms, "mini4", mask_mode=0)
+    rng = np.random.default_rng(5)
+    rois = [comp.view_geom(i).roi.tuple() for i in range(cfg["n"])]
+    masks = []
+    for i, r in enumerate(rois):
+        m = (rng.random((r[3], r[2])) < 0.7).astype(np.uint8) * 255
+        m[::5, ::3] = 128                                   # non-binary weights
+        masks.append(m)
+        comp.set_mask(i, m)
+    comp.init_blender()
+    frames = [synth.frame(cfg["w"], cfg["h"], i, 2) for i in range(cfg["n"])]
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    b = oracle.Blender([r[:2] for r in rois], [r[2:] for r in rois], cfg["num_bands"])
+    for i in range(cfg["n"]):
+        b.init_view(i, masks[i])
+    for i in range(cfg["n"]):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames[i], xm, ym, gains[i])
+    ref, refmask = b.blend()
+    assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    b.close(); comp.close()
+
+
+@pytest.mark.parametrize("nm", [(10, 10), (40, 40), (7, 13)])
+def test_mesh_to_map_vs_oracle(ms, cuda, oracle, nm):
+    """convertMeshesToMap (APP/meshwarper.cpp:823-886): custom_resize up, scatter-average at half resolution
+    (holes -> NaN), custom_resize up again.  Device atomics vs the reference's sequential loop: the partial
+    sums are integers < 2^24, so the result is order-independent and must match bit for bit."""
+    comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)
+    for i in (0, 3):
+        r = comp.view_geom(i).roi
+        mx, my = synth.mesh(r.width, r.height, nm[0], nm[1], phase=0.5 + i, amp=6.0)
+        comp.set_mesh(i, mx, my)
+        gx, gy = [host(t) for t in comp.mesh_maps(i)]
+        rx, ry = oracle.convert_mesh_to_map(mx, my, r.width, r.height)
+        for g, ref in ((gx, rx), (gy, ry)):
+            assert np.array_equal(np.isnan(g), np.isnan(ref))
+            assert np.array_equal(g[~np.isnan(g)], ref[~np.isnan(ref)])
+    comp.close()
+
+
+def test_mesh_double_buffering(ms, cuda):
+    """ms_set_mesh from the recalibration side takes effect at the next ms_stitch and never tears a frame."""
+    comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 0)) for i in range(cfg["n"])]]
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+
+    def stitch_with(phase):
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 10, 10, phase=phase, amp=5.0))
+        o = torch.zeros(shape, dtype=torch.int16, device=cuda)
+        comp.stitch(frames, out16s=[o])
+        return o
+    a = stitch_with(0.0)
+    b = stitch_with(1.0)
+    a2 = stitch_with(0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    comp.close()
