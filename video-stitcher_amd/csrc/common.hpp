@@ -74,6 +74,38 @@ __device__ __forceinline__ int rne_shift(int s, int k)
     return (s + ((1 << (k - 1)) - 1) + ((s >> k) & 1)) >> k;
 }
 
+
+// ---- backward warp maps (build_warp_maps.cu:67-134), split into a column term, a row term and a combine -----
+// so that the dense-map kernel (ms_build_warp_maps / ms_build_maps) and the fused per-frame kernel (which keeps
+// only the 1-D tables and never reads dense maps) execute the SAME fp32 operations and agree bit for bit.
+struct WarpParams { float k[9]; float t[3]; float scale; };
+
+__device__ __forceinline__ float2 warp_col_term(int proj, float u, const WarpParams &P)
+{
+    if (proj == MS_PROJ_PLANE) return make_float2(u / P.scale - P.t[0], 0.f);
+    u /= P.scale;
+    return make_float2(sinf(u), cosf(u));
+}
+__device__ __forceinline__ float2 warp_row_term(int proj, float v, const WarpParams &P)
+{
+    if (proj == MS_PROJ_PLANE) return make_float2(v / P.scale - P.t[1], 0.f);
+    if (proj == MS_PROJ_CYLINDRICAL) return make_float2(v / P.scale, 0.f);
+    v /= P.scale;
+    return make_float2(sinf(v), cosf(v));
+}
+__device__ __forceinline__ void warp_combine(int proj, const float2 c, const float2 r, const WarpParams &P, float &ox, float &oy)
+{
+    float x_, y_, z_;
+    if (proj == MS_PROJ_PLANE) { x_ = c.x; y_ = r.x; z_ = 1.f - P.t[2]; }
+    else if (proj == MS_PROJ_CYLINDRICAL) { x_ = c.x; y_ = r.x; z_ = c.y; }
+    else { x_ = r.x * c.x; y_ = -r.y; z_ = r.x * c.y; }          // sinv*sinu, -cosv, sinv*cosu
+    ox = __builtin_fmaf(P.k[2], z_, __builtin_fmaf(P.k[1], y_, P.k[0] * x_));
+    oy = __builtin_fmaf(P.k[5], z_, __builtin_fmaf(P.k[4], y_, P.k[3] * x_));
+    const float oz = __builtin_fmaf(P.k[8], z_, __builtin_fmaf(P.k[7], y_, P.k[6] * x_));
+    if (proj == MS_PROJ_PLANE || oz > 0) { ox /= oz; oy /= oz; }
+    else ox = oy = -1.f;
+}
+
 template <typename T>
 __device__ __forceinline__ T *row_ptr(void *base, size_t step, int y) { return (T *)((char *)base + (size_t)y * step); }
 template <typename T>

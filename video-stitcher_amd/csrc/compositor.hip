@@ -128,41 +128,59 @@ __global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views
 // One input row contributes columns [8t-2, 8t+8]: a 16-byte (int16) / 8-byte (u8) aligned body plus a
 // 2-pixel left and 1-pixel right halo; BORDER_REFLECT_101 only touches the first/last thread of a row,
 // where the mirrored columns are already inside the body (col -2 -> 2, -1 -> 1, w -> w-2).
-// Raw row fetch: body + halos, all issued unconditionally (clamped addresses) so that the 7 rows' loads are
-// in flight together; the reflect selection happens after, in registers.
-struct Row11u8 { uint2 b; unsigned l; unsigned r; };
-struct Row11s16 { uint4 b; unsigned l; int r; };
+// Raw row fetch for columns [8t-2, 8t+8] of one input row, issued unconditionally (clamped addresses) so that the
+// 7 rows' loads are in flight together; the reflect selection happens after, in registers.
+//   u8:    ONE 16-byte load at byte 8t-4 (dword aligned) covers bytes 8t-4 .. 8t+11
+//   int16: a 16-byte load at element 8t-2 (dword aligned) covers 8t-2 .. 8t+5, an 8-byte load covers 8t+6 .. 8t+9
+// (wave-wide gathers cost per instruction, so fewer, wider loads win).  Reads may run a few bytes past the end of
+// the last row of a plane: planes are contiguous and the buffers carry 64 bytes of slack.
+struct Row11u8 { uint4 b; };
+struct Row11s16 { uint4 b; uint2 c; };
 __device__ __forceinline__ Row11u8 fetch_row11(const uint8_t *__restrict__ row, int t, int w)
 {
     Row11u8 o;
-    o.b = *reinterpret_cast<const uint2 *>(row + 8 * t);
-    o.l = *reinterpret_cast<const uint16_t *>(row + max(8 * t - 2, 0));
-    o.r = row[min(8 * t + 8, w - 1)];
+    __builtin_memcpy(&o.b, __builtin_assume_aligned(row + max(8 * t - 4, 0), 4), 16);
     return o;
 }
 __device__ __forceinline__ Row11s16 fetch_row11(const int16_t *__restrict__ row, int t, int w)
 {
     Row11s16 o;
-    o.b = *reinterpret_cast<const uint4 *>(row + 8 * t);
-    o.l = *reinterpret_cast<const unsigned *>(row + max(8 * t - 2, 0));
-    o.r = row[min(8 * t + 8, w - 1)];
+    const int16_t *p = row + max(8 * t - 2, 0);
+    __builtin_memcpy(&o.b, __builtin_assume_aligned(p, 4), 16);
+    __builtin_memcpy(&o.c, __builtin_assume_aligned(p + 8, 4), 8);
     return o;
 }
 __device__ __forceinline__ void unpack_row11(const Row11u8 &o, int t, int w, int v[11])
 {
-    v[2] = o.b.x & 0xff; v[3] = (o.b.x >> 8) & 0xff; v[4] = (o.b.x >> 16) & 0xff; v[5] = o.b.x >> 24;
-    v[6] = o.b.y & 0xff; v[7] = (o.b.y >> 8) & 0xff; v[8] = (o.b.y >> 16) & 0xff; v[9] = o.b.y >> 24;
-    v[0] = (t == 0) ? v[4] : (int)(o.l & 0xff);            // col -2 -> 2
-    v[1] = (t == 0) ? v[3] : (int)((o.l >> 8) & 0xff);     // col -1 -> 1
-    v[10] = (8 * t + 8 >= w) ? v[8] : (int)o.r;            // col w -> w-2
+    const unsigned d[4] = {o.b.x, o.b.y, o.b.z, o.b.w};
+    int e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = (d[i >> 2] >> (8 * (i & 3))) & 0xff;
+    if (t == 0) {            // window starts at column 0: columns -2, -1 mirror to 2, 1
+        v[0] = e[2]; v[1] = e[1];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[2 + k] = e[k];
+    } else {                 // window starts at column 8t-4
+#pragma unroll
+        for (int k = 0; k < 11; ++k) v[k] = e[2 + k];
+    }
+    if (8 * t + 8 >= w) v[10] = v[8];                                   // col w -> w-2
 }
 __device__ __forceinline__ void unpack_row11(const Row11s16 &o, int t, int w, int v[11])
 {
-    v[2] = (int16_t)(o.b.x & 0xffff); v[3] = (int)o.b.x >> 16; v[4] = (int16_t)(o.b.y & 0xffff); v[5] = (int)o.b.y >> 16;
-    v[6] = (int16_t)(o.b.z & 0xffff); v[7] = (int)o.b.z >> 16; v[8] = (int16_t)(o.b.w & 0xffff); v[9] = (int)o.b.w >> 16;
-    v[0] = (t == 0) ? v[4] : (int)(int16_t)(o.l & 0xffff);
-    v[1] = (t == 0) ? v[3] : ((int)o.l >> 16);
-    v[10] = (8 * t + 8 >= w) ? v[8] : o.r;
+    const unsigned d[6] = {o.b.x, o.b.y, o.b.z, o.b.w, o.c.x, o.c.y};
+    int e[12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { e[2 * i] = (int16_t)(d[i] & 0xffff); e[2 * i + 1] = (int)d[i] >> 16; }
+    if (t == 0) {            // window starts at column 0
+        v[0] = e[2]; v[1] = e[1];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[2 + k] = e[k];
+    } else {                 // window starts at column 8t-2
+#pragma unroll
+        for (int k = 0; k < 11; ++k) v[k] = e[k];
+    }
+    if (8 * t + 8 >= w) v[10] = v[8];
 }
 template <typename T> struct Row11 { using type = Row11u8; };
 template <> struct Row11<int16_t> { using type = Row11s16; };
@@ -582,6 +600,13 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
 }
 
 // ---- static-table kernels ---------------------------------------------------------------------
+// 1-D terms of the backward map: coltab[x] = f(tl_u + x), rowtab[y] = g(tl_v + y)
+__global__ void __launch_bounds__(256) k_warp_tabs(int proj, int tl_u, int tl_v, int cols, int rows, float2 *coltab, float2 *rowtab, WarpParams P)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cols) coltab[i] = warp_col_term(proj, (float)(tl_u + i), P);
+    if (i < rows) rowtab[i] = warp_row_term(proj, (float)(tl_v + i), P);
+}
 // warp(255-mask, INTER_NEAREST, BORDER_CONSTANT) == "does the truncated map coordinate hit the source"
 __global__ void __launch_bounds__(256) k_valid_mask(const float *__restrict__ mx, const float *__restrict__ my, int pitch, int rows, int cols,
                                                     int src_rows, int src_cols, uint8_t *__restrict__ mask, int mpitch)
@@ -664,6 +689,9 @@ struct ms_ctx {
     ViewPad pad[MAX_VIEWS];
     // static device tables
     DevBuf maps;                       // per view xmap | ymap
+    DevBuf tabs;                       // per view column table | row table (float2)
+    size_t tab_off[MAX_VIEWS] = {};
+    WarpParams wparams[MAX_VIEWS];
     size_t map_off[MAX_VIEWS] = {};    // float offset of xmap; ymap follows at + ah*pitch
     int map_pitch[MAX_VIEWS] = {};
     DevBuf masks;                      // per view 8UC1 (aw x ah, pitch = aw)
@@ -688,6 +716,8 @@ struct ms_ctx {
     bool warp_tiled = false;
     DevBuf warp_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
+    size_t warp_lds_bytes = 0;         // dynamic LDS of k_warp_t: largest staged source tile
+    int warp_lds_tiles = 0;
     double plan_fraction = 1.0;        // needed level-0 pixels / padded pixels
     // CPW mesh maps, double buffered
     DevBuf mesh[2];
@@ -828,7 +858,17 @@ static int build_plan(ms_ctx *c)
         }
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
-        if (!tiles.empty()) MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
+        c->warp_lds_bytes = 0; c->warp_lds_tiles = 0;
+        if (!tiles.empty()) {
+            MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
+            if (c->warp_tiled) {   // source bounding box of every tile (static: the projection maps do not change per frame)
+                k_tile_bbox<<<c->n_warp_tiles, dim3(16, 16)>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width);
+                MS_LAUNCH_CHECK();
+                MS_HIP(hipMemcpy(tiles.data(), c->warp_tiles.p, tiles.size() * sizeof(WarpTile), hipMemcpyDeviceToHost));
+                for (const WarpTile &t : tiles)
+                    if (t.flags & 1) { c->warp_lds_bytes = std::max(c->warp_lds_bytes, (size_t)warp_lds_pitch(t.sw) * t.sh * 4); ++c->warp_lds_tiles; }
+            }
+        }
     }
     c->plan_fraction = tot0 > 0 ? need0 / tot0 : 1.0;
     // pyrDown tiles: output tiles of level l+1
@@ -895,7 +935,7 @@ void ms_destroy(ms_ctx *c)
 {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    c->maps.release(); c->masks.release(); c->weights.release(); c->wm0.release(); c->den.release(); c->result_mask.release();
+    c->maps.release(); c->tabs.release(); c->masks.release(); c->weights.release(); c->wm0.release(); c->den.release(); c->result_mask.release();
     c->view_tab.release(); c->g0.release(); c->gl.release(); c->cl.release(); c->stage.release();
     c->mesh[0].release(); c->mesh[1].release(); c->mesh_tmp.release();
     c->warp_tiles.release();
@@ -944,11 +984,20 @@ int ms_build_maps(ms_ctx *c, ms_stream stream)
         total += (size_t)2 * c->roi[i].height * c->map_pitch[i];
     }
     if (int e = c->maps.alloc(total * sizeof(float))) return e;
+    size_t tab_total = 0;
+    for (int i = 0; i < c->N; ++i) { c->tab_off[i] = tab_total; tab_total += (size_t)round_up(c->roi[i].width, 4) + round_up(c->roi[i].height, 4); }
+    if (int e = c->tabs.alloc((tab_total + 8) * sizeof(float2))) return e;
     for (int i = 0; i < c->N; ++i) {
         float k_rinv[9];
         k_rinv_gemm(c->K[i], c->R[i], k_rinv);   // warpers_cuda.cpp:108
         ms_image mx = view_map_image(c, i, 0), my = view_map_image(c, i, 1);
         if (int e = launch_build_warp_maps(c->cfg.projection, c->roi[i].x, c->roi[i].y, mx, my, k_rinv, nullptr, c->cfg.warp_scale, st)) return e;
+        WarpParams &W = c->wparams[i];
+        memcpy(W.k, k_rinv, sizeof(W.k)); W.t[0] = W.t[1] = W.t[2] = 0.f; W.scale = c->cfg.warp_scale;
+        float2 *ct = (float2 *)c->tabs.p + c->tab_off[i], *rt = ct + round_up(c->roi[i].width, 4);
+        const int n = std::max(c->roi[i].width, c->roi[i].height);
+        k_warp_tabs<<<div_up(n, 256), 256, 0, st>>>(c->cfg.projection, c->roi[i].x, c->roi[i].y, c->roi[i].width, c->roi[i].height, ct, rt, W);
+        MS_LAUNCH_CHECK();
     }
     // blender->prepare(corners, sizes)
     c->bg = blender_prepare(result_roi(c->N, c->roi), c->cfg.num_bands);
@@ -1037,6 +1086,10 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         V.xmap = (const float *)c->maps.p + c->map_off[v];
         V.ymap = V.xmap + (size_t)V.ah * c->map_pitch[v];
         V.map_pitch = c->map_pitch[v];
+        V.coltab = (const float2 *)c->tabs.p + c->tab_off[v];
+        V.rowtab = V.coltab + round_up(V.aw, 4);
+        V.wp = c->wparams[v];
+        V.proj = c->cfg.projection;
         V.s1_off = stage_total;
         V.s1_pitch = round_up(V.aw * 3, 4);
         stage_total += (long long)round_up(V.s1_pitch * V.ah + 8, 16);
@@ -1160,7 +1213,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     c->gl_stride = (gl_total + 127) / 128 * 128;
     c->cl_stride = (cl_total + 127) / 128 * 128;
     c->stage_stride = (stage_total + 255) / 256 * 256;
-    if (int e = c->g0.alloc((size_t)c->g0_stride * F)) return e;
+    if (int e = c->g0.alloc((size_t)c->g0_stride * F + 64)) return e;
     if (int e = c->gl.alloc((size_t)c->gl_stride * F * sizeof(int16_t) + 64)) return e;
     if (int e = c->cl.alloc((size_t)c->cl_stride * F * sizeof(int16_t) + 64)) return e;
     if (c->cfg.enable_cpw) {
@@ -1317,13 +1370,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
             k_warp_t<true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), 0, st>>>(
-                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
+                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
     } else if (c->warp_tiled && c->cfg.reserved[0] == 0) {
-        k_warp_t<false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), 0, st>>>(
-            (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
+        int lds_ok = c->cfg.reserved[1] != 0;   // experimental LDS staging of the source tile (slower at 2x minification); needs dword-aligned rows
+        for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && (((uintptr_t)src.p[i] | src.step[i]) & 3) == 0;
+        k_warp_t<false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), lds_ok ? c->warp_lds_bytes : 0, st>>>(
+            (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, lds_ok);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

@@ -23,6 +23,9 @@ struct ViewDesc {
     float gain;
     const float *xmap, *ymap;     // projection maps (static), pitch in elements
     int map_pitch;
+    const float2 *coltab, *rowtab; // 1-D terms of the backward map (per ROI column / row); the fused path rebuilds
+    WarpParams wp;                 // the coordinates from these (bit-identical to xmap/ymap) instead of reading 8 B/px
+    int proj;
     const uint8_t *wm0;           // padded 8-bit mask = level-0 weight before the 1/255 scale (static)
     int wm0_pitch;
     long long s1_off;             // byte offset of the CPW stage-1 image inside the per-frame stage buffer

@@ -451,37 +451,13 @@ int launch_dilate3(const ms_image &src, ms_image &dst, hipStream_t st)
 
 // ------------------------------------------------------------------------------------------------
 // buildWarpMapsKernel<Mapper>  [build_warp_maps.cu:67-152]; k_rinv/t/scale by value (no __constant__ upload)
-struct WarpParams { float k[9]; float t[3]; float scale; };
-
 template <int PROJ>
 __global__ void __launch_bounds__(256) k_build_warp_maps(int tl_u, int tl_v, int cols, int rows, float *__restrict__ mapx, size_t mxstep,
                                                          float *__restrict__ mapy, size_t mystep, WarpParams P)
 {
     XY_GUARD(cols, rows)
-    float u = (float)(tl_u + x), v = (float)(tl_v + y);
-    float x_, y_, z_;
-    if (PROJ == MS_PROJ_PLANE) {
-        x_ = u / P.scale - P.t[0];
-        y_ = v / P.scale - P.t[1];
-        z_ = 1.f - P.t[2];
-    } else if (PROJ == MS_PROJ_CYLINDRICAL) {
-        u /= P.scale;
-        x_ = sinf(u);
-        y_ = v / P.scale;
-        z_ = cosf(u);
-    } else {
-        v /= P.scale;
-        u /= P.scale;
-        const float sinv = sinf(v);
-        x_ = sinv * sinf(u);
-        y_ = -cosf(v);
-        z_ = sinv * cosf(u);
-    }
-    float ox = __builtin_fmaf(P.k[2], z_, __builtin_fmaf(P.k[1], y_, P.k[0] * x_));
-    float oy = __builtin_fmaf(P.k[5], z_, __builtin_fmaf(P.k[4], y_, P.k[3] * x_));
-    const float oz = __builtin_fmaf(P.k[8], z_, __builtin_fmaf(P.k[7], y_, P.k[6] * x_));
-    if (PROJ == MS_PROJ_PLANE || oz > 0) { ox /= oz; oy /= oz; }
-    else ox = oy = -1.f;
+    float ox, oy;
+    warp_combine(PROJ, warp_col_term(PROJ, (float)(tl_u + x), P), warp_row_term(PROJ, (float)(tl_v + y), P), P, ox, oy);
     row_ptr<float>(mapx, mxstep, y)[x] = ox;
     row_ptr<float>(mapy, mystep, y)[x] = oy;
 }

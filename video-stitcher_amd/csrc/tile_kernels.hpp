@@ -30,19 +30,18 @@ __device__ __forceinline__ Taps make_taps(float xc, float yc, int srows, int sco
     const float wx2 = (float)x2 - xc, wx1 = xc - (float)t.x1;
     const float wy2 = (float)y2 - yc, wy1 = yc - (float)t.y1;
     t.w11 = wx2 * wy2; t.w12 = wx1 * wy2; t.w21 = wx2 * wy1; t.w22 = wx1 * wy1;
-    t.fast = t.x1 >= 0 && t.x1 < scols - 1 && t.y1 >= 0 && t.y1 < srows - 1;
+    t.fast = t.x1 >= 0 && t.x1 < scols - 2 && t.y1 >= 0 && t.y1 < srows - 1;   // all 4 taps inside, 8-byte row reads inside
     return t;
 }
-// 6 source bytes (two BGR pixels) of one row as a dword + a halfword, from a possibly unaligned address
+// The two BGR pixels of a tap row (6 bytes) fetched as ONE unaligned 8-byte load: the TA/L1 cost of a wave-wide
+// gather is per instruction, not per byte.  The 2 extra bytes stay inside the image row because the caller only
+// uses this for taps with x1 <= cols-3 (the last column pair goes through the bounds-checked path).
 struct Px2 { unsigned lo; unsigned hi; };
 __device__ __forceinline__ Px2 load_px2(const uint8_t *p)
 {
-    Px2 r;
-    unsigned a; uint16_t b;
-    __builtin_memcpy(&a, p, 4);
-    __builtin_memcpy(&b, p + 4, 2);
-    r.lo = a; r.hi = b;
-    return r;
+    uint2 v;
+    __builtin_memcpy(&v, p, 8);
+    return Px2{v.x, v.y};
 }
 __device__ __forceinline__ void blend_taps(const Taps &t, const Px2 &r1, const Px2 &r2, float out[3])
 {
@@ -62,66 +61,188 @@ __device__ __forceinline__ void blend_taps(const Taps &t, const Px2 &r1, const P
 }
 
 // ---- Gaussian level 0 (remap + gain [or CPW stage 2] + reflect pad), 4 px per lane ---------------------
+// Source coordinates of the 4 pixels of a lane.  Non-CPW: rebuilt from the 1-D tables (same fp32 ops as the dense
+// x_map/y_map, which are therefore never read per frame); CPW stage 2: read from the dense mesh maps.
+template <bool CPW>
+__device__ __forceinline__ void warp_coords4(const ViewDesc &V, const MeshTable &mesh, int v, int x, int y, float xc[4], float yc[4])
+{
+    const int ay = reflect_fast(y - V.top, V.ah);
+    const int i0 = x - V.left;
+    const bool interior = i0 >= 0 && i0 + 3 < V.aw;
+    if (!CPW) {
+        const float2 rt = V.rowtab[ay];
+        float2 ct[4];
+        if (interior) {
+            float4 a, b;
+            __builtin_memcpy(&a, __builtin_assume_aligned(V.coltab + i0, 8), 16);
+            __builtin_memcpy(&b, __builtin_assume_aligned(V.coltab + i0 + 2, 8), 16);
+            ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ct[k] = V.coltab[reflect_fast(i0 + k, V.aw)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) warp_combine(V.proj, ct[k], rt, V.wp, xc[k], yc[k]);
+    } else {
+        const float *mxp = mesh.x[v], *myp = mesh.y[v];
+        const int mpitch = mesh.pitch[v];
+        if (interior) {
+            float4 a, b;
+            __builtin_memcpy(&a, __builtin_assume_aligned(mxp + (size_t)ay * mpitch + i0, 4), 16);
+            __builtin_memcpy(&b, __builtin_assume_aligned(myp + (size_t)ay * mpitch + i0, 4), 16);
+            xc[0] = a.x; xc[1] = a.y; xc[2] = a.z; xc[3] = a.w;
+            yc[0] = b.x; yc[1] = b.y; yc[2] = b.z; yc[3] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ax = reflect_fast(i0 + k, V.aw);
+                xc[k] = mxp[(size_t)ay * mpitch + ax];
+                yc[k] = myp[(size_t)ay * mpitch + ax];
+            }
+        }
+    }
+}
+
+// LDS row pitch (pixels) of a staged source tile of width sw (multiple of 4): a multiple of 4 (16-byte rows for
+// ds_write_b128) with an odd number of 16-byte slots so consecutive rows start on different banks.
+__host__ __device__ __forceinline__ int warp_lds_pitch(int sw) { return ((sw >> 2) & 1) ? sw : sw + 4; }
+constexpr int WARP_LDS_CAP_PX = 8192;      // 32 KiB of 4-byte pixels per workgroup (4 workgroups per CU)
+
+// Bounding box (in source pixels) of every in-image bilinear tap of a tile: run once when the tables are built.
+__global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int src_rows, int src_cols)
+{
+    __shared__ int s_box[4];
+    WarpTile T = tiles[blockIdx.x];
+    const ViewDesc &V = views[T.view];
+    if (threadIdx.x == 0 && threadIdx.y == 0) { s_box[0] = s_box[2] = 0x7fffffff; s_box[1] = s_box[3] = -1; }
+    __syncthreads();
+    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
+    if (x < V.pw && y < V.ph) {
+        float xc[4], yc[4];
+        MeshTable none{};
+        warp_coords4<false>(V, none, T.view, x, y, xc, yc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Taps t = make_taps(xc[k], yc[k], src_rows, src_cols);
+            if (t.fast) {
+                atomicMin(&s_box[0], t.x1); atomicMax(&s_box[1], t.x1 + 1);
+                atomicMin(&s_box[2], t.y1); atomicMax(&s_box[3], t.y1 + 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        if (s_box[1] < 0) { T.sx0 = T.sy0 = T.sw = T.sh = 0; T.flags = 0; }
+        else {
+            const int sx0 = s_box[0] & ~3;
+            const int sw = ((s_box[1] - sx0 + 1) + 3) & ~3, sh = s_box[3] - s_box[2] + 1;
+            T.sx0 = (short)sx0; T.sy0 = (short)s_box[2]; T.sw = (short)sw; T.sh = (short)sh;
+            T.flags = (short)((warp_lds_pitch(sw) * sh <= WARP_LDS_CAP_PX) ? 1 : 0);
+        }
+        tiles[blockIdx.x] = T;
+    }
+}
+
 template <bool CPW>
 __global__ void __launch_bounds__(256) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                 SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                 const uint8_t *__restrict__ stage, long long stage_stride,
-                                                uint8_t *__restrict__ g0, long long g0_stride)
+                                                uint8_t *__restrict__ g0, long long g0_stride, int lds_ok)
 {
+    extern __shared__ uint4 s_tile4[];                       // staged source tile, one dword per BGR pixel
     const WarpTile T = tiles[blockIdx.x];
     const int f = blockIdx.z, v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
-    if (x >= V.pw || y >= V.ph) return;
-    const int ay = reflect_fast(y - V.top, V.ah);
-    const int i0 = x - V.left;
-    const float *mxp, *myp;
-    int mpitch;
+    const bool active = x < V.pw && y < V.ph;
     const uint8_t *sp;
     unsigned sstep;
     int srows, scols;
-    if (CPW) {
-        mxp = mesh.x[v]; myp = mesh.y[v]; mpitch = mesh.pitch[v];
-        sp = stage + (size_t)f * stage_stride + V.s1_off; sstep = (unsigned)V.s1_pitch; srows = V.ah; scols = V.aw;
-    } else {
-        mxp = V.xmap; myp = V.ymap; mpitch = V.map_pitch;
-        sp = src.p[f * n_views + v]; sstep = src.step[f * n_views + v]; srows = src_rows; scols = src_cols;
-    }
+    if (CPW) { sp = stage + (size_t)f * stage_stride + V.s1_off; sstep = (unsigned)V.s1_pitch; srows = V.ah; scols = V.aw; }
+    else { sp = src.p[f * n_views + v]; sstep = src.step[f * n_views + v]; srows = src_rows; scols = src_cols; }
+    const bool use_lds = !CPW && lds_ok && (T.flags & 1);
+
     float xc[4], yc[4];
-    if (i0 >= 0 && i0 + 3 < V.aw) {                 // interior: 4 consecutive map entries (dword-aligned 16-byte loads)
-        float4 a, b;
-        __builtin_memcpy(&a, mxp + (size_t)ay * mpitch + i0, 16);
-        __builtin_memcpy(&b, myp + (size_t)ay * mpitch + i0, 16);
-        xc[0] = a.x; xc[1] = a.y; xc[2] = a.z; xc[3] = a.w;
-        yc[0] = b.x; yc[1] = b.y; yc[2] = b.z; yc[3] = b.w;
-    } else {
+    if (active) warp_coords4<CPW>(V, mesh, v, x, y, xc, yc);
+
+    const int lp = warp_lds_pitch(T.sw);
+    if (use_lds) {
+        // cooperative, coalesced fetch of the tile's source bounding box: 12 bytes (4 BGR pixels) per lane and step,
+        // unpacked to 4 dwords so that a bilinear tap pair later is one aligned 8-byte LDS read
+        const int gpr = T.sw >> 2, tasks = gpr * T.sh;
+        unsigned *lds = reinterpret_cast<unsigned *>(s_tile4);
+        for (int i = (int)threadIdx.y * 16 + (int)threadIdx.x; i < tasks; i += 256) {
+            const int row = i / gpr, g = i - row * gpr;
+            const int sx = T.sx0 + 4 * g;
+            const uint8_t *p = sp + (size_t)(T.sy0 + row) * sstep + (size_t)sx * 3;
+            uint4 px;
+            if (sx + 4 <= scols) {
+                struct U3 { unsigned a, b, c; } d;
+                __builtin_memcpy(&d, __builtin_assume_aligned(p, 4), 12);
+                px.x = d.a & 0xffffffu; px.y = (d.a >> 24) | ((d.b & 0xffffu) << 8);
+                px.z = (d.b >> 16) | ((d.c & 0xffu) << 16); px.w = d.c >> 8;
+            } else {                                             // group sticks out of the image row
+                unsigned q[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 4; ++k)
+                    if (sx + k < scols) q[k] = (unsigned)p[3 * k] | ((unsigned)p[3 * k + 1] << 8) | ((unsigned)p[3 * k + 2] << 16);
+                px = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+            *reinterpret_cast<uint4 *>(lds + (size_t)row * lp + 4 * g) = px;
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+
+    Taps t[4];
+    unsigned packed[3] = {0, 0, 0};
+    if (use_lds) {
+        const unsigned *lds = reinterpret_cast<const unsigned *>(s_tile4);
+        uint2 a[4], b[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ax = reflect_fast(i0 + k, V.aw);
-            xc[k] = mxp[(size_t)ay * mpitch + ax];
-            yc[k] = myp[(size_t)ay * mpitch + ax];
+            t[k] = make_taps(xc[k], yc[k], srows, scols);
+            const int lx = min(max(t[k].x1 - T.sx0, 0), T.sw - 2), ly = min(max(t[k].y1 - T.sy0, 0), T.sh - 2);
+            const unsigned *q = lds + (size_t)ly * lp + lx;
+            __builtin_memcpy(&a[k], __builtin_assume_aligned(q, 4), 8);
+            __builtin_memcpy(&b[k], __builtin_assume_aligned(q + lp, 4), 8);
         }
-    }
-    Taps t[4];
-    Px2 r1[4], r2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        t[k] = make_taps(xc[k], yc[k], srows, scols);
-        const int xs = min(max(t[k].x1, 0), scols - 2), ys = min(max(t[k].y1, 0), srows - 2);
-        const uint8_t *p = sp + (size_t)ys * sstep + (size_t)xs * 3;
-        r1[k] = load_px2(p);
-        r2[k] = load_px2(p + sstep);
-    }
-    unsigned packed[3] = {0, 0, 0};
+        for (int k = 0; k < 4; ++k) {
+            float o[3];
+            if (t[k].fast) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float o[3];
-        if (t[k].fast) blend_taps(t[k], r1[k], r2[k], o);
-        else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);      // image-edge / invalid coordinates: per-tap bounds
+                for (int c = 0; c < 3; ++c) {
+                    float acc = __builtin_fmaf((float)((a[k].x >> (8 * c)) & 0xff), t[k].w11, 0.f);
+                    acc = __builtin_fmaf((float)((a[k].y >> (8 * c)) & 0xff), t[k].w12, acc);
+                    acc = __builtin_fmaf((float)((b[k].x >> (8 * c)) & 0xff), t[k].w21, acc);
+                    acc = __builtin_fmaf((float)((b[k].y >> (8 * c)) & 0xff), t[k].w22, acc);
+                    o[c] = acc;
+                }
+            } else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);    // image-edge / invalid coordinates: per-tap bounds
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const unsigned val = CPW ? (unsigned)sat_u8(o[c]) : (unsigned)sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
-            packed[c] |= val << (8 * k);
+            for (int c = 0; c < 3; ++c)
+                packed[c] |= (unsigned)sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f)) << (8 * k);
+        }
+    } else {
+        Px2 r1[4], r2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t[k] = make_taps(xc[k], yc[k], srows, scols);
+            const int xs = min(max(t[k].x1, 0), scols - 3), ys = min(max(t[k].y1, 0), srows - 2);
+            const uint8_t *p = sp + (size_t)ys * sstep + (size_t)xs * 3;
+            r1[k] = load_px2(p);
+            r2[k] = load_px2(p + sstep);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[3];
+            if (t[k].fast) blend_taps(t[k], r1[k], r2[k], o);
+            else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned val = CPW ? (unsigned)sat_u8(o[c]) : (unsigned)sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+                packed[c] |= val << (8 * k);
+            }
         }
     }
     const LevelDesc &L = V.lv[0];
