@@ -240,6 +240,12 @@ MS_API int ms_get_mesh_maps(const ms_ctx *ctx, int view, ms_image *xmesh, ms_ima
 MS_API int ms_stitch_timed(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
                            ms_stream stream, int cap, const char **names, float *ms);
 
+/* Self-test of the shared-reciprocal division used by the band kernels (normalizeUsingWeightKernel32F,
+ * multiband_blend.cu:85-100 divides three channels by the same w + 1e-5): for each of the n HOST denominators,
+ * all 65536 int16 numerators are divided both ways on the device; returns the number of results whose bits differ
+ * from the compiler's correctly rounded a / d (expected 0), or a negative ms_status. */
+MS_API int ms_selftest_divide(const float *denominators_host, int n, ms_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,3 +215,15 @@ def test_argument_errors(ms, cuda):
         ms.copy_make_border(f, 1, 1, 1, 1, ms.BORDER_REFLECT)
     with pytest.raises(ms.MsError, match="at least 2x2"):
         ms.custom_resize(f[:1], 8, 8)
+
+
+def test_shared_reciprocal_division_is_ieee(ms, cuda):
+    """The band kernels divide the 3 channels of a pixel by the same w + 1e-5 with one refined reciprocal (DivBy).
+    Exhaustive over all int16 numerators x denominators spanning the weight-sum range (incl. 1e-5 itself, sums of
+    1..12 unit weights, random values): every quotient must equal the compiler's correctly rounded a / d bit for bit."""
+    rng = np.random.default_rng(99)
+    eps = np.float32(1e-5)
+    dens = [eps, np.float32(1.0) + eps, np.float32(2.0) + eps, np.float32(3.0) + eps, np.float32(12.0) + eps, np.float32(0.5) + eps]
+    dens += list((rng.random(1500, dtype=np.float32) * np.float32(4.0) + eps).astype(np.float32))
+    dens += list((np.float32(10.0) ** rng.uniform(-5, 1.5, 500)).astype(np.float32) + eps)
+    assert ms.selftest_divide(np.array(dens, np.float32)) == 0

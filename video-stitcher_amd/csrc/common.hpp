@@ -106,6 +106,30 @@ __device__ __forceinline__ void warp_combine(int proj, const float2 c, const flo
     else ox = oy = -1.f;
 }
 
+// ---- IEEE fp32 division with the reciprocal shared between numerators -----------------------------------
+// normalizeUsingWeightKernel32F divides the three colour channels of a pixel by the same (w + 1e-5).  The
+// compiler's correctly-rounded division is  rcp -> 2 Newton steps on the reciprocal -> quotient -> 2 residual
+// corrections (plus div_scale/div_fixup for extreme exponents, which cannot occur here: |a| <= 32768,
+// 1e-5 <= d < 64).  DivBy keeps the refined reciprocal and repeats only the quotient part per channel: the same
+// fp32 operations, hence the same bits (checked exhaustively over all int16 numerators by ms_selftest_divide).
+struct DivBy {
+    float d, r;
+    __device__ __forceinline__ explicit DivBy(float den) : d(den)
+    {
+        const float r0 = __builtin_amdgcn_rcpf(den);
+        const float e0 = __builtin_fmaf(-den, r0, 1.f);
+        r = __builtin_fmaf(e0, r0, r0);
+    }
+    __device__ __forceinline__ float operator()(float a) const
+    {
+        const float q0 = a * r;
+        const float e1 = __builtin_fmaf(-d, q0, a);
+        const float q1 = __builtin_fmaf(e1, r, q0);
+        const float e2 = __builtin_fmaf(-d, q1, a);
+        return __builtin_fmaf(e2, r, q1);
+    }
+};
+
 template <typename T>
 __device__ __forceinline__ T *row_ptr(void *base, size_t step, int y) { return (T *)((char *)base + (size_t)y * step); }
 template <typename T>

@@ -108,10 +108,21 @@ __global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views
     if (x >= Lo.w || y >= Lo.h) return;
     const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
     const int sy = 2 * y, sx = 2 * x;
-    const int ry[5] = {r101_low(sy - 2, Li.h), r101_low(sy - 1, Li.h), sy, r101_high(sy + 1, Li.h), r101_high(sy + 2, Li.h)};
-    int cx[5];
+    int ry[5], cx[5];
+    if (Li.h >= 3 && Li.w >= 3) {     // |overshoot| <= 2 < len: BORDER_REFLECT_101 without the integer modulo
+        const int lr = Li.h - 1, lc = Li.w - 1;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) cx[k] = r101(sx - 2 + k, Li.w);
+        for (int k = 0; k < 5; ++k) {
+            const int r = abs(sy - 2 + k), q = abs(sx - 2 + k);
+            ry[k] = r > lr ? 2 * lr - r : r;
+            cx[k] = q > lc ? 2 * lc - q : q;
+        }
+    } else {
+        ry[0] = r101_low(sy - 2, Li.h); ry[1] = r101_low(sy - 1, Li.h); ry[2] = sy;
+        ry[3] = r101_high(sy + 1, Li.h); ry[4] = r101_high(sy + 2, Li.h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cx[k] = r101(sx - 2 + k, Li.w);
+    }
     const int wv[5] = {1, 4, 6, 4, 1};
     int acc = 0;
 #pragma unroll
@@ -280,8 +291,9 @@ __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ 
     const float den = P.den[l][(size_t)y * P.dpitch[l] + x];
     const size_t plane = (size_t)P.qh[l] * P.qpitch[l];
     int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)y * P.qpitch[l] + x;
+    const DivBy div(den);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) d[c * plane] = trunc_s16((float)acc[c] / den);
+    for (int c = 0; c < 3; ++c) d[c * plane] = trunc_s16(div((float)acc[c]));
 }
 
 // band l < nb, one 2x2 quad per thread:
@@ -336,13 +348,14 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
     const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
     const int16_t *cc = cl + (size_t)f * cl_stride + P.coff[l + 1];
     int res[3][4];
+    const DivBy div[4] = {DivBy(den[0]), DivBy(den[1]), DivBy(den[2]), DivBy(den[3])};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         int up[4];
         up_quad(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], qy, qx, up);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            res[c][k] = sat_s16((int)sat_s16(up[k]) + (int)trunc_s16((float)acc[c][k] / den[k]));
+            res[c][k] = sat_s16((int)sat_s16(up[k]) + (int)trunc_s16(div[k]((float)acc[c][k])));
     }
 
     if (!L0) {
@@ -509,6 +522,11 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
     const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
     const int16_t *cc = cl + (size_t)f * cl_stride + P.coff[l + 1];
     int res[3][2][8];
+    float rcp[2][8];                      // refined reciprocals, shared by the three colour planes (DivBy)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rcp[r][k] = DivBy(den[r][k]).r;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         int up[2][8];
@@ -516,8 +534,10 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int k = 0; k < 8; ++k)   // int16 accumulation wraps: (short)(sum) == successive `short +=`
-                res[c][r][k] = sat_s16(up[r][k] + (int)trunc_s16((float)(int)(int16_t)acc[c][r][k] / den[r][k]));
+            for (int k = 0; k < 8; ++k) {   // int16 accumulation wraps: (short)(sum) == successive `short +=`
+                DivBy dv(1.f); dv.d = den[r][k]; dv.r = rcp[r][k];
+                res[c][r][k] = sat_s16(up[r][k] + (int)trunc_s16(dv((float)(int)(int16_t)acc[c][r][k])));
+            }
     }
 
     if (!L0) {
@@ -597,6 +617,18 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
             }
         }
     }
+}
+
+// exhaustive check of DivBy against the compiler's IEEE division: all int16 numerators for each denominator
+__global__ void __launch_bounds__(256) k_selftest_divide(const float *__restrict__ dens, int n_dens, unsigned *mismatches)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;      // numerator index 0..65535
+    const int j = blockIdx.y;
+    if (i >= 65536 || j >= n_dens) return;
+    const float a = (float)(i - 32768), d = dens[j];
+    const float ref = a / d;
+    const float got = DivBy(d)(a);
+    if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
 }
 
 // ---- static-table kernels ---------------------------------------------------------------------
@@ -1518,6 +1550,25 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_result_mask: call ms_init_blender first");
     *m = ms_image{c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fh, c->pano.fw, MS_8UC1};
     return MS_OK;
+}
+
+int ms_selftest_divide(const float *dens_host, int n, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(dens_host && n > 0 && n <= 65535, "ms_selftest_divide: bad arguments");
+    hipStream_t st = as_stream(stream);
+    DevBuf d, cnt;
+    if (int e = d.alloc((size_t)n * sizeof(float))) return e;
+    if (int e = cnt.alloc(sizeof(unsigned))) return e;
+    MS_HIP(hipMemcpyAsync(d.p, dens_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned), st));
+    k_selftest_divide<<<dim3(256, n), 256, 0, st>>>((const float *)d.p, n, (unsigned *)cnt.p);
+    MS_LAUNCH_CHECK();
+    unsigned h = 0;
+    MS_HIP(hipMemcpyAsync(&h, cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
+    d.release(); cnt.release();
+    return (int)h;
 }
 
 }  // extern "C"

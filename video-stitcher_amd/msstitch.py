@@ -56,6 +56,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
+    "ms_selftest_divide",
 ]
 
 _lib = None
@@ -136,6 +137,12 @@ def _stream():
 
 def device_count():
     return load().ms_device_count()
+
+
+def selftest_divide(dens):
+    import numpy as np
+    d = np.ascontiguousarray(dens, np.float32)
+    return _chk(load().ms_selftest_divide(d.ctypes.data_as(C.POINTER(C.c_float)), d.size, _stream()))
 
 
 # ------------------------------------------------------------------ image ops (allocate dst like the cv::cuda API)
