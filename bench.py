@@ -108,10 +108,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=8, help="frames per ms_stitch call (1 = live mode)")
+    ap.add_argument("--frames", type=int, default=16, help="frames per ms_stitch call (1 = live mode)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--calib", action="store_true", help="also run 3 known-size streaming copies (PMC calibration, tools/profile_traffic.sh)")
+    ap.add_argument("--streams", type=int, default=1, help="split the F frames of a step over this many contexts/HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,18 +138,26 @@ def main():
     cpw = args.config == "cfg3"
     cfg = synth.CONFIGS["cfg5" if args.config == "cfg5" else "cfg2"]
     F = args.frames
-    comp = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]),
-                         num_bands=cfg["num_bands"], enable_cpw=cpw, out_size=(cfg["out_w"], cfg["out_h"]), max_frames=F)
     gains = synth.gains(cfg["n"])
-    for i in range(cfg["n"]):
-        K, R = synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i)
-        comp.set_camera(i, K, R)
-        comp.set_gain(i, gains[i])
-    comp.build_maps(); comp.build_masks(1); comp.init_blender()
-    if cpw:
+    S = max(1, args.streams)
+    assert F % S == 0, "--frames must be a multiple of --streams"
+
+    def make_comp(max_frames):
+        c = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]),
+                          num_bands=cfg["num_bands"], enable_cpw=cpw, out_size=(cfg["out_w"], cfg["out_h"]), max_frames=max_frames)
         for i in range(cfg["n"]):
-            r = comp.view_geom(i).roi
-            comp.set_mesh(i, *synth.mesh(r.width, r.height, 40, 40, phase=0.1 * i))
+            K, R = synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i)
+            c.set_camera(i, K, R)
+            c.set_gain(i, gains[i])
+        c.build_maps(); c.build_masks(1); c.init_blender()
+        if cpw:
+            for i in range(cfg["n"]):
+                r = c.view_geom(i).roi
+                c.set_mesh(i, *synth.mesh(r.width, r.height, 40, 40, phase=0.1 * i))
+        return c
+    comps = [make_comp(F // S) for _ in range(S)]     # one context (own per-frame buffers) per HIP stream
+    comp = comps[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
 
     # synthetic input: 8 distinct frames per view, cycled; frame t of the global sequence -> rank t mod G
     n_distinct = 8
@@ -157,7 +167,24 @@ def main():
     fh = pg.dst_roi_final.height
     outs = [[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(F)] for _ in range(2)]
     slabs = [torch.zeros((F, fh, cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    runs = [comp.prepared(frames, out8u=outs[b]) for b in range(2)]
+    import ctypes
+    Fs = F // S
+    subruns = [[comps[k].prepared(frames[k * Fs:(k + 1) * Fs], out8u=outs[b][k * Fs:(k + 1) * Fs]) for k in range(S)] for b in range(2)]
+    handles = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+
+    def make_run(b):
+        def run():
+            if S > 1:
+                cur = torch.cuda.current_stream()
+                for k in range(S):
+                    streams[k].wait_stream(cur)
+                    subruns[b][k](handles[k])
+                for k in range(S):
+                    cur.wait_stream(streams[k])
+            else:
+                subruns[b][0](handles[0])
+        return run
+    runs = [make_run(b) for b in range(2)]
     gather = world > 1 and not args.no_gather
     gl = [[torch.empty_like(slabs[0]) for _ in range(world)] for _ in range(2)] if (gather and rank == 0) else [None, None]
     pending = [None, None]
@@ -199,14 +226,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.calib:
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255); b = torch.empty_like(a)
+        for _ in range(3):
+            ms.calib_copy(a, b)
+        torch.cuda.synchronize()
+        del a, b
+
     # ---- instrumented pass: per-kernel hipEvent durations on the launch stream ------------------
     acc = {}
     reps = max(5, min(50, args.steps))
     for _ in range(reps):
-        for name, ms_t in comp.stitch_timed(frames, out8u=outs[0]):
+        for name, ms_t in comp.stitch_timed(frames[:Fs], out8u=outs[0][:Fs]):
             acc.setdefault(name, []).append(ms_t)
     kmean = {k: float(np.mean(v)) for k, v in acc.items()}
-    kb, sumP, Q, A = kernel_bytes(comp, cfg, F, cpw)
+    kb, sumP, Q, A = kernel_bytes(comp, cfg, Fs, cpw)
     dom = max(kmean, key=kmean.get)
     achieved = kb[dom] / (kmean[dom] * 1e-3) / 1e9          # GB/s
     b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), [0], 0, (cfg["out_w"], cfg["out_h"]))  # placeholder, replaced below
@@ -217,6 +251,12 @@ def main():
     b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), P_list, Q, (cfg["out_w"], cfg["out_h"]), warped_px=A, cpw=cpw)
     gpu_ms_step = float(sum(kmean.values()))
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):       # PMC-measured HBM bytes per launch of the dominant kernel (tools/profile_traffic.sh), same workload only
+        tj = json.load(open(tpath))
+        if tj.get("config") == args.config and tj.get("frames_per_launch") == Fs and dom in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
     if rank == 0:
         total_frames = world * F * args.steps
         res = {
@@ -228,16 +268,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in / int16+fp32 pyramid arithmetic", "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, spherical, %d bands, CPW %s; "
-                                   "%d frames per step per GPU, inputs resident in HBM"
+                                   "%d frames per step per GPU on %d HIP stream(s), inputs resident in HBM"
                                    % (args.config, cfg["n"], cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"],
-                                      pg.num_bands, "on (40x40 mesh)" if cpw else "off", F),
-                       "frames_per_step": F, "parallelism": "frame-parallel x%d%s" % (world, ", RCCL gather of pano slabs on rank 0" if gather else "")},
+                                      pg.num_bands, "on (40x40 mesh)" if cpw else "off", F, S),
+                       "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s" % (world, ", RCCL gather of pano slabs on rank 0" if gather else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "alg_bytes_per_launch": int(kb[dom]), "mean_launch_ms": round(kmean[dom], 5)},
-            "frame_roofline": {"alg_bytes_per_frame": int(b_alg_frame), "gpu_ms_per_frame": round(gpu_ms_step / F, 5),
-                               "achieved_GBps": round(b_alg_frame * F / (gpu_ms_step * 1e-3) / 1e9, 1),
-                               "frac": round(b_alg_frame * F / (gpu_ms_step * 1e-3) / 8e12, 4)},
+            "frame_roofline": {"alg_bytes_per_frame": int(b_alg_frame), "gpu_ms_per_frame": round(gpu_ms_step / Fs, 5),
+                               "achieved_GBps": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 1e9, 1),
+                               "frac": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),
+                               "wall_frac": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4)},
             "kernels_ms_per_step": {k: round(v, 5) for k, v in kmean.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

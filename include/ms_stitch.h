@@ -240,6 +240,10 @@ MS_API int ms_get_mesh_maps(const ms_ctx *ctx, int view, ms_image *xmesh, ms_ima
 MS_API int ms_stitch_timed(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
                            ms_stream stream, int cap, const char **names, float *ms);
 
+/* Profiling aid: streaming device-to-device copy (16 B per lane) of a known byte count, used to calibrate the rocprofv3
+ * FETCH_SIZE / WRITE_SIZE counters (tools/profile_traffic.sh). */
+MS_API int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream stream);
+
 /* Self-test of the shared-reciprocal division used by the band kernels (normalizeUsingWeightKernel32F,
  * multiband_blend.cu:85-100 divides three channels by the same w + 1e-5): for each of the n HOST denominators,
  * all 65536 int16 numerators are divided both ways on the device; returns the number of results whose bits differ

@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# Run ON THE GPU BOX (through gpurun): kernel trace + separate PMC passes for FETCH_SIZE and WRITE_SIZE of bench.py,
+# with a known-size streaming copy in the same process for calibration.  Outputs under gpurun_out/prof_$TAG/.
+#   gpurun -- 'bash tools/profile_traffic.sh r01 cfg2 16'
+set -euo pipefail
+TAG=${1:-r01}; CFG=${2:-cfg2}; F=${3:-16}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
+B="python bench.py --steps 12 --warmup 3 --no-cpu-baseline --frames $F --config $CFG --calib"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $B > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $B > $OUT/bench_write.log 2>&1
+python bench.py --frames $F --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err || true
+python tools/summarize_traffic.py $OUT $TAG $CFG $F

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 databases written by tools/profile_traffic.sh into the committed evidence:
+  profiles/<tag>_kernel_trace.txt   per-kernel calls/mean/min/max (kernel trace)
+  profiles/<tag>_traffic.json       per-kernel HBM bytes per launch = (FETCH_SIZE*f_r + WRITE_SIZE*f_w) KB, where f_r/f_w are
+                                    calibrated on k_calib_copy (a 1 GiB streaming copy in the same run), as the MI355X guide prescribes
+  profiles/traffic_latest.json      copy of the above, read by bench.py for roofline.traffic"""
+import json
+import os
+import shutil
+import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import rocpd_stats  # noqa: E402
+
+
+def counters(db, name):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, avg(value), count(*), avg(duration) from counters_collection where counter_name = ? group by kernel_name", (name,)).fetchall()
+    return {r[0]: (r[1], r[2], r[3]) for r in rows}
+
+
+def short(n):
+    n = n.replace("void ", "").replace("ms::", "")
+    return n.split("(")[0]
+
+
+def main(out, tag, cfg, frames):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    rocpd_stats.main(os.path.join(out, "trace", "trace_results.db"), os.path.join(prof, "%s_kernel_trace.txt" % tag))
+    fetch = counters(os.path.join(out, "fetch", "fetch_results.db"), "FETCH_SIZE")
+    write = counters(os.path.join(out, "write", "write_results.db"), "WRITE_SIZE")
+    GiB = float(1 << 30)
+    cal_r = [v for k, v in fetch.items() if "k_calib_copy" in k]
+    cal_w = [v for k, v in write.items() if "k_calib_copy" in k]
+    f_r = GiB / (cal_r[0][0] * 1024.0) if cal_r and cal_r[0][0] > 0 else 2.0     # guide: FETCH_SIZE reads 1/2 on gfx950
+    f_w = GiB / (cal_w[0][0] * 1024.0) if cal_w and cal_w[0][0] > 0 else 1.0
+    res = {"tag": tag, "config": cfg, "frames_per_launch": int(frames), "unit": "bytes per launch",
+           "calibration": {"kernel": "k_calib_copy (1 GiB read + 1 GiB written, 16 B/lane)",
+                           "FETCH_SIZE_KB_reported": cal_r[0][0] if cal_r else None, "WRITE_SIZE_KB_reported": cal_w[0][0] if cal_w else None,
+                           "read_factor": f_r, "write_factor": f_w}, "kernels": {}}
+    names = {"k_warp": "k_warp_t<false>", "k_remap_gain": "k_remap_gain"}
+    order = sorted(set(fetch) | set(write))
+    for k in order:
+        if "ms::" not in k or "calib" in k:
+            continue
+        fr = fetch.get(k, (0, 0, 0)); wr = write.get(k, (0, 0, 0))
+        res["kernels"][short(k)] = {"fetch_KB_raw": fr[0], "write_KB_raw": wr[0], "launches": fr[1], "mean_ns": fr[2],
+                                    "hbm_bytes_per_launch": int(fr[0] * 1024 * f_r + wr[0] * 1024 * f_w)}
+    # bench.py names its per-level launches k_down_l<l> / k_blend_l<l>; map the dominant ones by kernel template
+    alias = {}
+    for k, v in res["kernels"].items():
+        if k.startswith("k_warp_t<false>") or k.startswith("k_warp<false>"):
+            alias["k_warp"] = v
+        if k.startswith("k_blend8<true>"):
+            alias["k_blend_l0"] = v
+        if k.startswith("k_down_t<unsigned char>"):
+            alias["k_down_l0"] = v
+    res["kernels"].update(alias)
+    path = os.path.join(prof, "%s_traffic.json" % tag)
+    json.dump(res, open(path, "w"), indent=1, sort_keys=True)
+    shutil.copyfile(path, os.path.join(prof, "traffic_latest.json"))
+    bp = os.path.join(out, "bench_plain.json")
+    if os.path.exists(bp) and os.path.getsize(bp) > 10:
+        shutil.copyfile(bp, os.path.join(prof, "%s_bench.json" % tag))
+    print(json.dumps(res["calibration"]))
+    for k in ("k_warp", "k_down_l0", "k_blend_l0"):
+        if k in res["kernels"]:
+            print(k, res["kernels"][k])
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])

@@ -631,6 +631,13 @@ __global__ void __launch_bounds__(256) k_selftest_divide(const float *__restrict
     if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
 }
 
+// PMC calibration: a plain 16-byte-per-lane streaming copy of a known size, so that FETCH_SIZE / WRITE_SIZE of the
+// real kernels can be scaled by what the counters report for a known byte count (MI355X guide, HBM section)
+__global__ void __launch_bounds__(256) k_calib_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---- static-table kernels ---------------------------------------------------------------------
 // 1-D terms of the backward map: coltab[x] = f(tl_u + x), rowtab[y] = g(tl_v + y)
 __global__ void __launch_bounds__(256) k_warp_tabs(int proj, int tl_u, int tl_v, int cols, int rows, float2 *coltab, float2 *rowtab, WarpParams P)
@@ -1549,6 +1556,15 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
     if (!c || !m) return fail(MS_ERR_INVALID, "null argument");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_result_mask: call ms_init_blender first");
     *m = ms_image{c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fh, c->pano.fw, MS_8UC1};
+    return MS_OK;
+}
+
+int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(src && dst && bytes >= 16 && bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "ms_calib_copy: 16-byte aligned buffers and size required");
+    k_calib_copy<<<2048, 256, 0, as_stream(stream)>>>((const uint4 *)src, (uint4 *)dst, bytes / 16);
+    MS_LAUNCH_CHECK();
     return MS_OK;
 }
 

@@ -56,7 +56,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide",
+    "ms_selftest_divide", "ms_calib_copy",
 ]
 
 _lib = None
@@ -137,6 +137,11 @@ def _stream():
 
 def device_count():
     return load().ms_device_count()
+
+
+def calib_copy(src, dst):
+    n = src.numel() * src.element_size()
+    _chk(load().ms_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), _stream()))
 
 
 def selftest_divide(dens):
