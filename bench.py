@@ -124,12 +124,20 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: libmsstitch has no CPU fallback"
+    # MS_BENCH_SHARE_GPU=1 is a DEBUG mode for 1-GPU boxes: every rank uses cuda:0 and the process group is gloo (pano slabs
+    # staged through host memory) -- it exercises the multi-rank control flow, it is not a scaling measurement.
+    share = os.environ.get("MS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import msstitch as ms
     import synth
@@ -198,7 +206,10 @@ def main():
         if gather:
             for j in range(F):   # the pano ROI rows of each canvas are one contiguous slab
                 slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
-            pending[b], _ = df.gather_slabs(slabs[b], rank, world, dst=0, async_op=True, out=gl[b])
+            if share:
+                df.gather_slabs(slabs[b].cpu(), rank, world, dst=0, async_op=False)
+            else:
+                pending[b], _ = df.gather_slabs(slabs[b], rank, world, dst=0, async_op=True, out=gl[b])
 
     def drain():
         for b in range(2):
@@ -222,7 +233,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -271,7 +282,8 @@ def main():
                                    "%d frames per step per GPU on %d HIP stream(s), inputs resident in HBM"
                                    % (args.config, cfg["n"], cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"],
                                       pg.num_bands, "on (40x40 mesh)" if cpw else "off", F, S),
-                       "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s" % (world, ", RCCL gather of pano slabs on rank 0" if gather else "")},
+                       "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s%s" % (world, ", RCCL gather of pano slabs on rank 0" if gather else "",
+                                                                  " [DEBUG: ranks share one GPU, gloo]" if share else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "alg_bytes_per_launch": int(kb[dom]), "mean_launch_ms": round(kmean[dom], 5)},

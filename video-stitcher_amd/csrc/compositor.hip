@@ -753,7 +753,8 @@ struct ms_ctx {
     bool blend_vec[MAX_LEVELS] = {};   // band l may use the 2x8 kernel
     // work lists (tiles that are actually needed)
     bool warp_tiled = false;
-    DevBuf warp_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
+    DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
+    int n_stage1_tiles = 0;
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
     size_t warp_lds_bytes = 0;         // dynamic LDS of k_warp_t: largest staged source tile
     int warp_lds_tiles = 0;
@@ -910,6 +911,15 @@ static int build_plan(ms_ctx *c)
         }
     }
     c->plan_fraction = tot0 > 0 ? need0 / tot0 : 1.0;
+    if (c->cfg.enable_cpw) {   // CPW stage 1 covers the whole warped view: the mesh (hence what stage 2 samples) changes at recalibration
+        std::vector<WarpTile> tiles;
+        for (int v = 0; v < N; ++v)
+            for (int y0 = 0; y0 < c->h_views[v].ah; y0 += WARP_TH)
+                for (int x0 = 0; x0 < c->h_views[v].aw; x0 += WARP_TW) { WarpTile t{}; t.view = (short)v; t.x0 = (short)x0; t.y0 = (short)y0; tiles.push_back(t); }
+        c->n_stage1_tiles = (int)tiles.size();
+        if (int e = c->stage1_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
+        MS_HIP(hipMemcpy(c->stage1_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
+    }
     // pyrDown tiles: output tiles of level l+1
     for (int l = 0; l < nb; ++l) {
         std::vector<DownTile> tiles;
@@ -977,7 +987,7 @@ void ms_destroy(ms_ctx *c)
     c->maps.release(); c->tabs.release(); c->masks.release(); c->weights.release(); c->wm0.release(); c->den.release(); c->result_mask.release();
     c->view_tab.release(); c->g0.release(); c->gl.release(); c->cl.release(); c->stage.release();
     c->mesh[0].release(); c->mesh[1].release(); c->mesh_tmp.release();
-    c->warp_tiles.release();
+    c->warp_tiles.release(); c->stage1_tiles.release();
     for (int l = 0; l < MAX_LEVELS; ++l) { c->down_tiles[l].release(); c->blend_tiles[l].release(); }
     if (c->last_stitch) (void)hipEventDestroy(c->last_stitch);
     delete c;
@@ -1403,8 +1413,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (int e = mark(nullptr)) return e;
 
     if (cpw) {
-        k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
-            vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
+        if (c->cfg.reserved[0] == 0)
+            k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(16, 16), 0, st>>>(
+                (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
+        else
+            k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
+                vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)

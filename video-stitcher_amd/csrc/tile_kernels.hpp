@@ -253,6 +253,52 @@ __global__ void __launch_bounds__(256) k_warp_t(const WarpTile *__restrict__ til
     *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
 }
 
+// ---- CPW stage 1: images[i] = gain(remap(full_img, x_map, y_map)) (timed.cpp:90-94), 4 px per lane --------------
+// Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).
+__global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                  SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    const int f = blockIdx.z, v = T.view;
+    const ViewDesc &V = views[v];
+    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
+    if (x >= V.aw || y >= V.ah) return;
+    const uint8_t *sp = src.p[f * n_views + v];
+    const unsigned sstep = src.step[f * n_views + v];
+    const float2 rt = V.rowtab[y];
+    float xc[4], yc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) warp_combine(V.proj, V.coltab[min(x + k, V.aw - 1)], rt, V.wp, xc[k], yc[k]);
+    Taps t[4];
+    Px2 r1[4], r2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t[k] = make_taps(xc[k], yc[k], srows, scols);
+        const int xs = min(max(t[k].x1, 0), scols - 3), ys = min(max(t[k].y1, 0), srows - 2);
+        const uint8_t *p = sp + (size_t)ys * sstep + (size_t)xs * 3;
+        r1[k] = load_px2(p);
+        r2[k] = load_px2(p + sstep);
+    }
+    uint8_t o8[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o[3];
+        if (t[k].fast) blend_taps(t[k], r1[k], r2[k], o);
+        else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o8[3 * k + c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+    }
+    uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
+    if (x + 3 < V.aw) {
+        unsigned w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = (unsigned)o8[4 * i] | ((unsigned)o8[4 * i + 1] << 8) | ((unsigned)o8[4 * i + 2] << 16) | ((unsigned)o8[4 * i + 3] << 24);
+        __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
+    } else {
+        for (int k = 0; k < 4 && x + k < V.aw; ++k) { d[3 * k] = o8[3 * k]; d[3 * k + 1] = o8[3 * k + 1]; d[3 * k + 2] = o8[3 * k + 2]; }
+    }
+}
+
 // ---- pyrDown, tile list, 2 rows x 4 cols per lane (block 32 x 8) -------------------------------------
 template <typename TIN>
 __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int l,
