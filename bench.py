@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-format", default="i420", choices=["i420", "bgr"],
+                    help="what the sink rank receives: planar I420 of the pano rows (the encoder input of consume(), timed.cpp:308-316; "
+                         "half the bytes) or the 8UC3 rows themselves")
     ap.add_argument("--calib", action="store_true", help="also run 3 known-size streaming copies (PMC calibration, tools/profile_traffic.sh)")
     ap.add_argument("--streams", type=int, default=1, help="split the F frames of a step over this many contexts/HIP streams")
     args = ap.parse_args()
@@ -174,7 +177,12 @@ def main():
     pg = comp.pano_geom()
     fh = pg.dst_roi_final.height
     outs = [[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(F)] for _ in range(2)]
-    slabs = [torch.zeros((F, fh, cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    ya, yb = pg.canvas_y & ~1, min(cfg["out_h"], (pg.canvas_y + fh + 1) & ~1)       # even-aligned pano rows of the canvas
+    i420 = args.gather_format == "i420" and cfg["out_w"] % 2 == 0
+    if i420:
+        slabs = [torch.zeros((F, (yb - ya) * 3 // 2, cfg["out_w"]), dtype=torch.uint8, device=dev) for _ in range(2)]
+    else:
+        slabs = [torch.zeros((F, fh, cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     import ctypes
     Fs = F // S
     subruns = [[comps[k].prepared(frames[k * Fs:(k + 1) * Fs], out8u=outs[b][k * Fs:(k + 1) * Fs]) for k in range(S)] for b in range(2)]
@@ -205,7 +213,10 @@ def main():
         runs[b]()
         if gather:
             for j in range(F):   # the pano ROI rows of each canvas are one contiguous slab
-                slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
+                if i420:
+                    ms.bgr_to_i420(outs[b][j][ya:yb], dst=slabs[b][j])
+                else:
+                    slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
             if share:
                 df.gather_slabs(slabs[b].cpu(), rank, world, dst=0, async_op=False)
             else:
@@ -282,7 +293,7 @@ def main():
                                    "%d frames per step per GPU on %d HIP stream(s), inputs resident in HBM"
                                    % (args.config, cfg["n"], cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"],
                                       pg.num_bands, "on (40x40 mesh)" if cpw else "off", F, S),
-                       "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s%s" % (world, ", RCCL gather of pano slabs on rank 0" if gather else "",
+                       "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s%s" % (world, (", RCCL gather of the %s pano rows on rank 0 (%.1f MB/frame), overlapped" % (args.gather_format.upper(), slabs[0][0].numel() / 1e6)) if gather else "",
                                                                   " [DEBUG: ranks share one GPU, gloo]" if share else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,

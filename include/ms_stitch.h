@@ -141,6 +141,11 @@ MS_API int ms_build_warp_maps(int projection, int tl_u, int tl_v, ms_image *map_
                               const float *k_rinv, const float *r_kinv, const float *t, float scale,
                               ms_stream stream);
 
+/* cvtColor(src, dst, COLOR_BGR2YUV_I420): the encoder input of consume() (APP/timed.cpp:308-316) ->
+ * RGB888toYUV420pInvoker (OCV/imgproc/src/color.cpp:9082-9160).  src 8UC3 with even width/height; dst contiguous
+ * 8UC1 of (rows*3/2) x cols = planar I420.  Also what bench.py gathers across GPUs (half the bytes of BGR). */
+MS_API int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream stream);
+
 /* custom_resize(GpuMat &in, GpuMat &out, Size t_size)  APP/resize.cu:30-45, APP/calibration.h:15.
  * out->rows/cols give t_size.  32FC1. */
 MS_API int ms_custom_resize_32f(const ms_image *in, ms_image *out, ms_stream stream);

@@ -107,6 +107,8 @@ void orc_set_zero_masked_16sc3(int16_t *img, size_t step, const uint8_t *mask, s
 void orc_bitwise_and_8u(const uint8_t *a, size_t astep, const uint8_t *b, size_t bstep,
                         uint8_t *dst, size_t dstep, int rows, int cols);
 void orc_dilate3x3_8u(const uint8_t *src, size_t sstep, uint8_t *dst, size_t dstep, int rows, int cols);
+/* egress: cvtColor(COLOR_BGR2YUV_I420) of consume() (APP/timed.cpp:308-316); w, h even; dst = planar I420, w*h*3/2 bytes */
+void orc_bgr_to_i420(const uint8_t *src, size_t sstep, int w, int h, uint8_t *dst);
 /* K18 buildWarp{Plane,Cylindrical,Spherical}Maps: k_rinv = 9 floats, t = 3 floats (plane only). */
 void orc_build_warp_maps(int proj, int tl_u, int tl_v, int rows, int cols,
                          const float *k_rinv, const float *t, float scale,

@@ -612,3 +612,27 @@ void orc_custom_resize_32f(const float *in, size_t istep, int rows, int cols,
         }
     }
 }
+
+/* cvtColor(COLOR_BGR2YUV_I420) = RGB888toYUV420pInvoker (bIdx 0, uIdx 1, planar)  OCV/imgproc/src/color.cpp:8745-8756,9082-9160
+ * (the encoder input of consume(), APP/timed.cpp:308-316).  dst is the contiguous planar I420 image:
+ * Y[h][w], then U[h/2][w/2], then V[h/2][w/2]; chroma is taken from the top-left pixel of each 2x2 block. */
+void orc_bgr_to_i420(const uint8_t *src, size_t sstep, int w, int h, uint8_t *dst)
+{
+    const int SH = 20, half = 1 << (SH - 1);
+    const int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+    uint8_t *Y = dst, *U = dst + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t *p = CROWP(uint8_t, src, sstep, y);
+        for (int x = 0; x < w; ++x) {
+            const int b = p[3 * x], g = p[3 * x + 1], r = p[3 * x + 2];
+            int yy = (CRY * r + CGY * g + CBY * b + half + (16 << SH)) >> SH;
+            Y[(size_t)y * w + x] = (uint8_t)(yy < 0 ? 0 : (yy > 255 ? 255 : yy));
+            if (((x | y) & 1) == 0) {
+                int u = (CRU * r + CGU * g + CBU * b + half + (128 << SH)) >> SH;
+                int v = (CBU * r + CGV * g + CBV * b + half + (128 << SH)) >> SH;
+                U[(size_t)(y / 2) * (w / 2) + x / 2] = (uint8_t)(u < 0 ? 0 : (u > 255 ? 255 : u));
+                V[(size_t)(y / 2) * (w / 2) + x / 2] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+}

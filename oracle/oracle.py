@@ -212,6 +212,13 @@ def dilate3x3_8u(src):
     return dst
 
 
+def bgr_to_i420(src):
+    h, w = src.shape[:2]
+    dst = np.empty((h * 3 // 2, w), np.uint8)
+    lib().orc_bgr_to_i420(_p(src), _st(src), w, h, _p(dst))
+    return dst
+
+
 def build_warp_maps(proj, tl_u, tl_v, rows, cols, k_rinv, scale, t=(0, 0, 0)):
     k = np.ascontiguousarray(k_rinv, np.float32).reshape(9)
     tt = np.ascontiguousarray(t, np.float32).reshape(3)

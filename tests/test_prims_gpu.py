@@ -227,3 +227,15 @@ def test_shared_reciprocal_division_is_ieee(ms, cuda):
     dens += list((rng.random(1500, dtype=np.float32) * np.float32(4.0) + eps).astype(np.float32))
     dens += list((np.float32(10.0) ** rng.uniform(-5, 1.5, 500)).astype(np.float32) + eps)
     assert ms.selftest_divide(np.array(dens, np.float32)) == 0
+
+
+@pytest.mark.parametrize("size", [(628, 3840), (36, 50), (2, 2), (10, 6)])
+def test_bgr_to_i420(ms, cuda, oracle, size):
+    """consume()'s cvtColor(COLOR_BGR2YUV_I420) (timed.cpp:308-316): BT.601 fixed point, chroma from the top-left pixel."""
+    rng = rng_for("i420", size)
+    src = rng.integers(0, 256, size=size + (3,), dtype=np.uint8)
+    src[0, 0] = (255, 255, 255); src[-1, -1] = (0, 0, 0)
+    ref = oracle.bgr_to_i420(src)
+    assert np.array_equal(host(ms.bgr_to_i420(to_dev(src))), ref)
+    assert np.array_equal(host(ms.bgr_to_i420(to_dev_roi(src, rng))), ref)       # padded source step
+    assert ref[0, 0] == 235 and ref[size[0] - 1, size[1] - 1] == 16              # studio-swing luma of white / black

@@ -204,6 +204,16 @@ int ms_build_warp_maps(int projection, int tl_u, int tl_v, ms_image *mx, ms_imag
     return launch_build_warp_maps(projection, tl_u, tl_v, *mx, *my, k_rinv, t, scale, as_stream(s));
 }
 
+int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream s)
+{
+    PRE() IMG(src, "ms_bgr_to_i420 src") IMG(dst, "ms_bgr_to_i420 dst")
+    MS_CHECK(src->type == MS_8UC3 && dst->type == MS_8UC1, "ms_bgr_to_i420: 8UC3 -> 8UC1 planes");
+    MS_CHECK(src->cols % 2 == 0 && src->rows % 2 == 0, "ms_bgr_to_i420: width and height must be even (color.cpp: CV_Assert)");
+    MS_CHECK(dst->cols == src->cols && dst->rows == src->rows * 3 / 2 && dst->step == (size_t)dst->cols,
+             "ms_bgr_to_i420: dst must be a contiguous 8UC1 image of %d x %d", src->cols, src->rows * 3 / 2);
+    return launch_bgr_to_i420(*src, *dst, as_stream(s));
+}
+
 int ms_custom_resize_32f(const ms_image *in, ms_image *out, ms_stream s)
 {
     PRE() IMG(in, "ms_custom_resize_32f in") IMG(out, "ms_custom_resize_32f out")

@@ -482,6 +482,48 @@ int launch_build_warp_maps(int proj, int tl_u, int tl_v, ms_image &mx, ms_image 
 }
 
 // ------------------------------------------------------------------------------------------------
+// cvtColor(COLOR_BGR2YUV_I420)  [imgproc/src/color.cpp:8745-8756, 9082-9160]: BT.601 fixed point (shift 20), chroma from
+// the top-left pixel of each 2x2 block, planar I420 output.  One lane = 2 rows x 4 pixels (12-byte row loads).
+__device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
+__global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= w || y >= h) return;
+    constexpr int SH = 20, HALF = 1 << (SH - 1);
+    constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+    uint8_t *Y = dst, *U = dst + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
+    const int n = min(4, w - x);
+    unsigned yq[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint8_t *p = row_ptr<uint8_t>(src, sstep, y + r) + (size_t)x * 3;
+        uint8_t px[12];
+        if (n == 4 && ((sstep | (size_t)src) & 3) == 0) __builtin_memcpy(px, __builtin_assume_aligned(p, 4), 12);
+        else for (int i = 0; i < 3 * n; ++i) px[i] = p[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n) break;
+            const int b = px[3 * k], g = px[3 * k + 1], rr = px[3 * k + 2];
+            yq[r] |= (unsigned)clamp_u8((CRY * rr + CGY * g + CBY * b + HALF + (16 << SH)) >> SH) << (8 * k);
+            if (r == 0 && (k & 1) == 0) {
+                U[(size_t)(y / 2) * (w / 2) + (x + k) / 2] = clamp_u8((CRU * rr + CGU * g + CBU * b + HALF + (128 << SH)) >> SH);
+                V[(size_t)(y / 2) * (w / 2) + (x + k) / 2] = clamp_u8((CBU * rr + CGV * g + CBV * b + HALF + (128 << SH)) >> SH);
+            }
+        }
+        uint8_t *yd = Y + (size_t)(y + r) * w + x;
+        if (n == 4 && (w & 3) == 0) *reinterpret_cast<unsigned *>(yd) = yq[r];
+        else for (int k = 0; k < n; ++k) yd[k] = (uint8_t)(yq[r] >> (8 * k));
+    }
+}
+int launch_bgr_to_i420(const ms_image &src, ms_image &dst, hipStream_t st)
+{
+    k_bgr_to_i420<<<dim3(div_up(div_up(src.cols, 4), BX), div_up(src.rows / 2, BY)), dim3(BX, BY), 0, st>>>(
+        (const uint8_t *)src.data, src.step, src.cols, src.rows, (uint8_t *)dst.data);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // custom_resize  [APP/resize.cu:9-27]
 __global__ void __launch_bounds__(256) k_custom_resize(int tx, int ty, int cols, int rows, const float *__restrict__ in, size_t istep,
                                                        float *__restrict__ out, size_t ostep)
