@@ -176,7 +176,9 @@ typedef struct ms_config {
     int enable_cpw;         /* enable_local (APP/defs.h:27): second remap through the mesh maps       */
     int out_width, out_height;   /* equirect canvas (0,0 = emit the pano ROI only)                     */
     int max_frames;         /* frames batched per ms_stitch call (1 = live; >1 amortises launches)    */
-    int reserved[8];        /* [0] != 0: debug, run the simple one-pixel-per-lane kernels instead of the tiled ones */
+    int reserved[8];        /* [0] != 0: debug, run the simple one-pixel-per-lane kernels instead of the tiled ones;
+                             * [1] != 0: stage the warp kernel's source tiles through LDS (measured slower);
+                             * [2] != 0: keep the work lists in raster order instead of the XCD-aware order */
 } ms_config;
 
 MS_API int ms_create(const ms_config *cfg, ms_ctx **out);

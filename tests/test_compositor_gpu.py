@@ -133,6 +133,45 @@ def test_tiled_kernels_equal_simple_kernels(ms, cuda, rig, cpw):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("rig", ["cfg2", "mini4"])
+def test_lds_staged_warp_equals_direct(ms, cuda, rig):
+    """Opt-in variant of the warp kernel that stages each tile's source bounding box through LDS (16-byte chunk copy,
+    v_alignbyte extraction): same pixels as the default direct-gather path."""
+    outs = []
+    for lds in (False, True):
+        comp, cfg, gains = make_rig(ms, rig, lds_stage=lds)
+        pg = comp.pano_geom()
+        out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+        comp.stitch([[to_dev(synth.frame(cfg["w"], cfg["h"], i, 4)) for i in range(cfg["n"])]], out16s=[out16])
+        torch.cuda.synchronize()
+        outs.append(out16)
+        comp.close()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_config1_two_views(ms, cuda, oracle):
+    """BASELINE configs[0] geometry (2 views 640x480, yaw -/+25 deg, hfov 90, scale 2000/2pi; SURVEY App. C known ROIs),
+    composited with the multiband path on the GPU and compared with the oracle."""
+    import math
+    sc = float(np.float32(2000.0 / (2 * math.pi)))
+    comp = ms.Compositor(2, (640, 480), ms.PROJ_SPHERICAL, sc, num_bands=5, out_size=(2000, 1000))
+    cams = [synth.camera(1, 640, 480, 90.0, 0, yaw=math.radians(a)) for a in (-25.0, 25.0)]
+    gains = [0.97, 1.04]
+    for i, (K, R) in enumerate(cams):
+        comp.set_camera(i, K, R); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    assert comp.view_geom(0).roi.tuple() == (-388, 295, 499, 410) and comp.view_geom(1).roi.tuple() == (-111, 295, 500, 410)
+    frames = [synth.frame(640, 480, i, 0) for i in range(2)]
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    cfg = dict(n=2, num_bands=5)
+    ref16, refmask = run_oracle(oracle, comp, cfg, gains, frames)
+    assert np.array_equal(host(out16), ref16) and np.array_equal(host(comp.result_mask()), refmask)
+    comp.close()
+
+
 def test_state_errors(ms, cuda):
     comp = ms.Compositor(2, (64, 48), ms.PROJ_SPHERICAL, 50.0, num_bands=2, out_size=(0, 0))
     with pytest.raises(ms.MsError, match="camera 0 not set"):

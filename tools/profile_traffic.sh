@@ -12,3 +12,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B > $OUT/be
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $B > $OUT/bench_write.log 2>&1
 python bench.py --frames $F --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err || true
 python tools/summarize_traffic.py $OUT $TAG $CFG $F
+# gpurun only merges gpurun_out/ back: park the summaries there (copy them into profiles/ and commit)
+mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/traffic_latest.json gpurun_out/profiles_out/

@@ -845,6 +845,26 @@ bool any_in(const Bits &s, int w, int h, int x0, int y0, int tw, int th)
 
 }  // namespace
 
+// Workgroup b runs on XCD b % 8 (observed dispatch order; performance only).  Reorder a tile list so that each
+// XCD receives a CONTIGUOUS run of spatially adjacent tiles: neighbouring tiles share source rows / halo rows, and
+// only then do those re-reads hit in that XCD's private 4 MiB L2 instead of going back to HBM.
+template <typename T>
+static void xcd_order(std::vector<T> &tiles)
+{
+    const size_t n = tiles.size(), per = (n + 7) / 8;
+    if (n < 16) return;
+    std::vector<T> out;
+    out.reserve(n);
+    std::vector<char> used(n, 0);
+    for (size_t b = 0; out.size() < n; ++b) {
+        const size_t src = (b % 8) * per + b / 8;
+        if (src < n && !used[src]) { used[src] = 1; out.push_back(tiles[src]); }
+        if (b > 16 * n) break;
+    }
+    for (size_t i = 0; i < n; ++i) if (!used[i]) out.push_back(tiles[i]);
+    tiles.swap(out);
+}
+
 static int build_plan(ms_ctx *c)
 {
     const int N = c->N, nb = c->pano.nb;
@@ -896,6 +916,7 @@ static int build_plan(ms_ctx *c)
                         need0 += (double)std::min(WARP_TW, V.pw - x0) * std::min(WARP_TH, V.ph - y0);
                     }
         }
+        if (c->cfg.reserved[2] == 0) xcd_order(tiles);
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
         c->warp_lds_bytes = 0; c->warp_lds_tiles = 0;
@@ -906,7 +927,7 @@ static int build_plan(ms_ctx *c)
                 MS_LAUNCH_CHECK();
                 MS_HIP(hipMemcpy(tiles.data(), c->warp_tiles.p, tiles.size() * sizeof(WarpTile), hipMemcpyDeviceToHost));
                 for (const WarpTile &t : tiles)
-                    if (t.flags & 1) { c->warp_lds_bytes = std::max(c->warp_lds_bytes, (size_t)warp_lds_pitch(t.sw) * t.sh * 4); ++c->warp_lds_tiles; }
+                    if (t.flags & 1) { c->warp_lds_bytes = std::max(c->warp_lds_bytes, (size_t)warp_lds_pitch(t.sw) * t.sh + 16); ++c->warp_lds_tiles; }
             }
         }
     }
@@ -930,6 +951,7 @@ static int build_plan(ms_ctx *c)
                     for (int x0 = 0; x0 < Lo.w; x0 += DOWN_TW)
                         if (any_in(Nd[v][l + 1], Lo.w, Lo.h, x0, y0, DOWN_TW, DOWN_TH)) tiles.push_back(DownTile{(short)v, 0, (short)x0, (short)y0});
             }
+        if (c->cfg.reserved[2] == 0) xcd_order(tiles);
         c->n_down_tiles[l] = (int)tiles.size();
         if (int e = c->down_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(DownTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->down_tiles[l].p, tiles.data(), tiles.size() * sizeof(DownTile), hipMemcpyHostToDevice));
@@ -947,6 +969,7 @@ static int build_plan(ms_ctx *c)
                     }
                     tiles.push_back(BlendTile{(short)x0, (short)y0, m});
                 }
+        if (c->cfg.reserved[2] == 0) xcd_order(tiles);
         c->n_blend_tiles[l] = (int)tiles.size();
         if (int e = c->blend_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(BlendTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->blend_tiles[l].p, tiles.data(), tiles.size() * sizeof(BlendTile), hipMemcpyHostToDevice));
@@ -1422,15 +1445,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
-            k_warp_t<true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), 0, st>>>(
+            k_warp_t<true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), 0, st>>>(
                 (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
     } else if (c->warp_tiled && c->cfg.reserved[0] == 0) {
-        int lds_ok = c->cfg.reserved[1] != 0;   // experimental LDS staging of the source tile (slower at 2x minification); needs dword-aligned rows
-        for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && (((uintptr_t)src.p[i] | src.step[i]) & 3) == 0;
-        k_warp_t<false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, 16), lds_ok ? c->warp_lds_bytes : 0, st>>>(
+        int lds_ok = c->cfg.reserved[1] != 0 && c->warp_lds_bytes > 0;   // opt-in: LDS staging of the source tiles (measured slower than direct gathers)
+        for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
+        k_warp_t<false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), lds_ok ? c->warp_lds_bytes : 0, st>>>(
             (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, lds_ok);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(

@@ -103,10 +103,14 @@ __device__ __forceinline__ void warp_coords4(const ViewDesc &V, const MeshTable 
     }
 }
 
-// LDS row pitch (pixels) of a staged source tile of width sw (multiple of 4): a multiple of 4 (16-byte rows for
-// ds_write_b128) with an odd number of 16-byte slots so consecutive rows start on different banks.
-__host__ __device__ __forceinline__ int warp_lds_pitch(int sw) { return ((sw >> 2) & 1) ? sw : sw + 4; }
-constexpr int WARP_LDS_CAP_PX = 8192;      // 32 KiB of 4-byte pixels per workgroup (4 workgroups per CU)
+// Staged source tile: the tile's source bounding box is copied row by row, PACKED (3 B/px), in 16-byte chunks that are
+// 16-byte aligned in global memory; LDS row pitch in bytes = chunks * 16 with an odd chunk count (bank spread).
+__host__ __device__ __forceinline__ int warp_lds_pitch(int sw)
+{
+    const int chunks = (3 * sw + 15 + 15) / 16 + 1;       // worst-case leading misalignment of 15 bytes, +1 chunk of slack
+    return 16 * (chunks | 1);
+}
+constexpr int WARP_LDS_CAP_BYTES = 36 * 1024;             // 4 workgroups per CU
 
 // Bounding box (in source pixels) of every in-image bilinear tap of a tile: run once when the tables are built.
 __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int src_rows, int src_cols)
@@ -137,24 +141,33 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
             const int sx0 = s_box[0] & ~3;
             const int sw = ((s_box[1] - sx0 + 1) + 3) & ~3, sh = s_box[3] - s_box[2] + 1;
             T.sx0 = (short)sx0; T.sy0 = (short)s_box[2]; T.sw = (short)sw; T.sh = (short)sh;
-            T.flags = (short)((warp_lds_pitch(sw) * sh <= WARP_LDS_CAP_PX) ? 1 : 0);
+            T.flags = (short)((warp_lds_pitch(sw) * sh <= WARP_LDS_CAP_BYTES) ? 1 : 0);
         }
         tiles[blockIdx.x] = T;
     }
 }
 
+// One lane owns WARP_NG groups of 4 consecutive pixels (rows y and y + 16/WARP_NG of the tile): all WARP_NG*8 tap-row
+// loads are in flight together, so a wave pays the memory round trip once for 2x the pixels (the kernel is bound by
+// dependent-load latency x waves in flight, not by bytes).
+constexpr int WARP_NG = 2;
+constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = 16 x WARP_BY lanes
+
 template <bool CPW>
-__global__ void __launch_bounds__(256) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
-                                                SrcTable src, int src_rows, int src_cols, MeshTable mesh,
-                                                const uint8_t *__restrict__ stage, long long stage_stride,
-                                                uint8_t *__restrict__ g0, long long g0_stride, int lds_ok)
+__global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                         SrcTable src, int src_rows, int src_cols, MeshTable mesh,
+                                                         const uint8_t *__restrict__ stage, long long stage_stride,
+                                                         uint8_t *__restrict__ g0, long long g0_stride, int lds_ok)
 {
-    extern __shared__ uint4 s_tile4[];                       // staged source tile, one dword per BGR pixel
+    extern __shared__ uint4 s_tile4[];                       // optional staged source tile (packed BGR rows)
     const WarpTile T = tiles[blockIdx.x];
     const int f = blockIdx.z, v = T.view;
     const ViewDesc &V = views[v];
-    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
-    const bool active = x < V.pw && y < V.ph;
+    const int x = T.x0 + 4 * (int)threadIdx.x;
+    int ys[WARP_NG];
+    bool active[WARP_NG];
+#pragma unroll
+    for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + (int)threadIdx.y + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
     const uint8_t *sp;
     unsigned sstep;
     int srows, scols;
@@ -162,95 +175,100 @@ __global__ void __launch_bounds__(256) k_warp_t(const WarpTile *__restrict__ til
     else { sp = src.p[f * n_views + v]; sstep = src.step[f * n_views + v]; srows = src_rows; scols = src_cols; }
     const bool use_lds = !CPW && lds_ok && (T.flags & 1);
 
-    float xc[4], yc[4];
-    if (active) warp_coords4<CPW>(V, mesh, v, x, y, xc, yc);
+    float xc[WARP_NG][4], yc[WARP_NG][4];
+#pragma unroll
+    for (int g = 0; g < WARP_NG; ++g) {
+        if (active[g]) warp_coords4<CPW>(V, mesh, v, x, ys[g], xc[g], yc[g]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xc[g][k] = yc[g][k] = -1.f;
+        }
+    }
 
-    const int lp = warp_lds_pitch(T.sw);
+    const int lp = warp_lds_pitch(T.sw);                     // bytes
+    const uint8_t *tile0 = sp + (size_t)T.sy0 * sstep + (size_t)T.sx0 * 3;   // first byte of the bounding box
     if (use_lds) {
-        // cooperative, coalesced fetch of the tile's source bounding box: 12 bytes (4 BGR pixels) per lane and step,
-        // unpacked to 4 dwords so that a bilinear tap pair later is one aligned 8-byte LDS read
-        const int gpr = T.sw >> 2, tasks = gpr * T.sh;
-        unsigned *lds = reinterpret_cast<unsigned *>(s_tile4);
-        for (int i = (int)threadIdx.y * 16 + (int)threadIdx.x; i < tasks; i += 256) {
-            const int row = i / gpr, g = i - row * gpr;
-            const int sx = T.sx0 + 4 * g;
-            const uint8_t *p = sp + (size_t)(T.sy0 + row) * sstep + (size_t)sx * 3;
-            uint4 px;
-            if (sx + 4 <= scols) {
-                struct U3 { unsigned a, b, c; } d;
-                __builtin_memcpy(&d, __builtin_assume_aligned(p, 4), 12);
-                px.x = d.a & 0xffffffu; px.y = (d.a >> 24) | ((d.b & 0xffffu) << 8);
-                px.z = (d.b >> 16) | ((d.c & 0xffu) << 16); px.w = d.c >> 8;
-            } else {                                             // group sticks out of the image row
-                unsigned q[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 4; ++k)
-                    if (sx + k < scols) q[k] = (unsigned)p[3 * k] | ((unsigned)p[3 * k + 1] << 8) | ((unsigned)p[3 * k + 2] << 16);
-                px = make_uint4(q[0], q[1], q[2], q[3]);
+        // cooperative copy global -> LDS: lane (tx, ty) moves 16-byte chunks tx, tx+16, .. of rows ty, ty+BY, ..
+        // (every chunk is 16-byte aligned in global memory and in LDS: one dwordx4 load + one ds_write_b128)
+        uint8_t *lds = reinterpret_cast<uint8_t *>(s_tile4);
+        const int nch = lp >> 4;
+        const uint8_t *img_end = sp + (size_t)(srows - 1) * sstep + (size_t)scols * 3;
+        for (int r = (int)threadIdx.y; r < T.sh; r += WARP_BY) {
+            const uint8_t *row = tile0 + (size_t)r * sstep;
+            const uint8_t *arow = row - ((size_t)row & 15);
+            for (int ch = (int)threadIdx.x; ch < nch; ch += 16) {
+                const uint8_t *p = arow + 16 * ch;
+                uint4 q;
+                if (p + 16 <= img_end) q = *reinterpret_cast<const uint4 *>(p);
+                else {                                            // last bytes of the last image row: stay inside the buffer
+                    uint8_t tmp[16];
+                    for (int i = 0; i < 16; ++i) tmp[i] = (p + i < img_end) ? p[i] : (uint8_t)0;
+                    __builtin_memcpy(&q, tmp, 16);
+                }
+                *reinterpret_cast<uint4 *>(lds + (size_t)r * lp + 16 * ch) = q;
             }
-            *reinterpret_cast<uint4 *>(lds + (size_t)row * lp + 4 * g) = px;
         }
         __syncthreads();
     }
-    if (!active) return;
 
-    Taps t[4];
-    unsigned packed[3] = {0, 0, 0};
+    Taps t[WARP_NG][4];
+    Px2 r1[WARP_NG][4], r2[WARP_NG][4];
     if (use_lds) {
-        const unsigned *lds = reinterpret_cast<const unsigned *>(s_tile4);
-        uint2 a[4], b[4];
+        const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_tile4);
+        const unsigned a0 = (unsigned)((size_t)tile0 & 15), astep = sstep & 15;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            t[k] = make_taps(xc[k], yc[k], srows, scols);
-            const int lx = min(max(t[k].x1 - T.sx0, 0), T.sw - 2), ly = min(max(t[k].y1 - T.sy0, 0), T.sh - 2);
-            const unsigned *q = lds + (size_t)ly * lp + lx;
-            __builtin_memcpy(&a[k], __builtin_assume_aligned(q, 4), 8);
-            __builtin_memcpy(&b[k], __builtin_assume_aligned(q + lp, 4), 8);
-        }
+        for (int g = 0; g < WARP_NG; ++g)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float o[3];
-            if (t[k].fast) {
+            for (int k = 0; k < 4; ++k) {
+                t[g][k] = make_taps(xc[g][k], yc[g][k], srows, scols);
+                const int lx = min(max(t[g][k].x1 - T.sx0, 0), T.sw - 2), ly = min(max(t[g][k].y1 - T.sy0, 0), T.sh - 2);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float acc = __builtin_fmaf((float)((a[k].x >> (8 * c)) & 0xff), t[k].w11, 0.f);
-                    acc = __builtin_fmaf((float)((a[k].y >> (8 * c)) & 0xff), t[k].w12, acc);
-                    acc = __builtin_fmaf((float)((b[k].x >> (8 * c)) & 0xff), t[k].w21, acc);
-                    acc = __builtin_fmaf((float)((b[k].y >> (8 * c)) & 0xff), t[k].w22, acc);
-                    o[c] = acc;
+                for (int rr = 0; rr < 2; ++rr) {
+                    // byte offset of pixel (ly+rr, lx) inside its staged row = leading misalignment of that row + 3*lx
+                    const unsigned off = (unsigned)(ly + rr) * lp + ((a0 + (unsigned)(ly + rr) * astep) & 15) + 3u * lx;
+                    const unsigned *w = reinterpret_cast<const unsigned *>(lds + (off & ~3u));
+                    const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
+                    const unsigned sh = off & 3u;
+                    Px2 px;
+                    px.lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                    px.hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    if (rr == 0) r1[g][k] = px; else r2[g][k] = px;
                 }
-            } else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);    // image-edge / invalid coordinates: per-tap bounds
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                packed[c] |= (unsigned)sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f)) << (8 * k);
-        }
+            }
     } else {
-        Px2 r1[4], r2[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            t[k] = make_taps(xc[k], yc[k], srows, scols);
-            const int xs = min(max(t[k].x1, 0), scols - 3), ys = min(max(t[k].y1, 0), srows - 2);
-            const uint8_t *p = sp + (size_t)ys * sstep + (size_t)xs * 3;
-            r1[k] = load_px2(p);
-            r2[k] = load_px2(p + sstep);
-        }
+        for (int g = 0; g < WARP_NG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[g][k] = make_taps(xc[g][k], yc[g][k], srows, scols);
+                const int xs = min(max(t[g][k].x1, 0), scols - 3), ysrc = min(max(t[g][k].y1, 0), srows - 2);
+                const uint8_t *p = sp + (size_t)ysrc * sstep + (size_t)xs * 3;
+                r1[g][k] = load_px2(p);
+                r2[g][k] = load_px2(p + sstep);
+            }
+    }
+    const LevelDesc &L = V.lv[0];
+    const size_t plane = (size_t)L.h * L.pitch;
+#pragma unroll
+    for (int g = 0; g < WARP_NG; ++g) {
+        if (!active[g]) continue;
+        unsigned packed[3] = {0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float o[3];
-            if (t[k].fast) blend_taps(t[k], r1[k], r2[k], o);
-            else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);
+            if (t[g][k].fast) blend_taps(t[g][k], r1[g][k], r2[g][k], o);
+            else sample3(sp, sstep, srows, scols, xc[g][k], yc[g][k], o);      // image-edge / invalid coordinates: per-tap bounds
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const unsigned val = CPW ? (unsigned)sat_u8(o[c]) : (unsigned)sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
                 packed[c] |= val << (8 * k);
             }
         }
+        uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
+        *reinterpret_cast<unsigned *>(d) = packed[0];
+        *reinterpret_cast<unsigned *>(d + plane) = packed[1];
+        *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
     }
-    const LevelDesc &L = V.lv[0];
-    uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)y * L.pitch + x;
-    const size_t plane = (size_t)L.h * L.pitch;
-    *reinterpret_cast<unsigned *>(d) = packed[0];
-    *reinterpret_cast<unsigned *>(d + plane) = packed[1];
-    *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
 }
 
 // ---- CPW stage 1: images[i] = gain(remap(full_img, x_map, y_map)) (timed.cpp:90-94), 4 px per lane --------------

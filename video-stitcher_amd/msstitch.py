@@ -304,10 +304,11 @@ class Compositor:
     """stitch_calib tables once (build_maps / build_masks / init_blender), then stitch() per frame batch."""
 
     def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
-                 out_size=(0, 0), max_frames=1, simple_kernels=False):
+                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=False):
         cfg = Config(num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
                      out_size[0], out_size[1], max_frames)
         cfg.reserved[0] = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
+        cfg.reserved[1] = 1 if lds_stage else 0        # opt-in: stage the warp kernel's source tiles through LDS
         self._ctx = C.c_void_p()
         _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
         self.cfg = cfg
