@@ -71,11 +71,12 @@ MS_API int ms_device_count(void);       /* cuda::getCudaEnabledDeviceCount (blen
  * 1. Image-op entry points: one per cv::cuda:: call / device launcher on the hot path
  * ============================================================================================= */
 
-/* cuda::remap(src, dst, xmap, ymap, INTER_LINEAR|INTER_NEAREST, BORDER_CONSTANT, Scalar(0), stream)
+/* cuda::remap(src, dst, xmap, ymap, INTER_LINEAR|INTER_NEAREST, borderMode, Scalar(0), stream)
  * OCV/cudawarping/src/remap.cpp:61-102 -> device::imgproc::remap_gpu<uchar3|uchar> (cuda/remap.cu:56-86).
- * 8UC3 (linear) and 8UC1 (linear, nearest); dst.size == xmap.size == ymap.size. */
+ * BORDER_CONSTANT(0): 8UC3 linear, 8UC1 linear/nearest (the per-frame warps, timed.cpp:84-101; mask warps);
+ * BORDER_REFLECT: 8UC3 linear (the seam-scale image warp, calibration.cpp:118).  dst.size == xmap.size == ymap.size. */
 MS_API int ms_remap(const ms_image *src, const ms_image *xmap, const ms_image *ymap, ms_image *dst,
-                    int interpolation, ms_stream stream);
+                    int interpolation, int border_type, ms_stream stream);
 
 /* cuda::resize(src, dst, Size(), fx, fy, INTER_LINEAR, stream)  OCV/cudawarping/src/resize.cpp:57-106
  * -> device::resize<uchar3|uchar> (cuda/resize.cu:71-106).  Two call forms, as resize.cpp:72-81:
@@ -197,6 +198,19 @@ MS_API int ms_build_maps(ms_ctx *ctx, ms_stream stream);
  * mode 1: AND with Voronoi seams (VoronoiSeamFinder, seam_finders.cpp:85-160) computed at compose size
  * (the app computes them at seam scale and resizes up: stated simplification). */
 MS_API int ms_build_masks(ms_ctx *ctx, int mode, ms_stream stream);
+/* The reference's own calibration at seam scale (APP/calibration.cpp:92-135, 224-237): resize the N full frames (DEVICE 8UC3) by
+ * seam_scale, warp image (LINEAR/REFLECT) and a 255-mask (NEAREST/CONSTANT) with the per-view seam intrinsics K_seam (HOST, N x 9,
+ * = K at work scale times seam_work_aspect, calibration.cpp:110-116) and seam_warp_scale, estimate the exposure gains
+ * (GainCompensator::feed, exposure_compensate.cpp:71-145), cut Voronoi seams, optionally dilate, resize the seam masks to the compose
+ * mask size and AND them with warp(255) at compose scale.  Leaves the masks ready for ms_init_blender; gains_out (HOST, N) may be NULL. */
+typedef struct ms_seam_params {
+    double seam_scale;        /* min(1, sqrt(SEAM_MEGAPIX*1e6 / area))  (calibration.cpp:280)            */
+    float seam_warp_scale;    /* warped_image_scale * seam_work_aspect  (calibration.cpp:101)             */
+    int dilate;               /* enable_local: 3x3 dilation of the seam masks (calibration.cpp:209,231)   */
+    int estimate_gains;       /* also ms_set_gain() the estimated gains                                   */
+} ms_seam_params;
+MS_API int ms_calibrate_seam(ms_ctx *ctx, const ms_image *full_imgs, const float *K_seam, const ms_seam_params *params,
+                             double *gains_out, ms_stream stream);
 /* Or hand a mask over, as init_gpu(img, mask, tl) receives it (blenders.cpp:344): HOST 8UC1, view-ROI sized. */
 MS_API int ms_set_mask(ms_ctx *ctx, int view, const uint8_t *mask_host, size_t step);
 /* mb->init_gpu(_, mask, corner) for every view, in view order (calibration.cpp:240 -> blenders.cpp:344-461),

@@ -109,6 +109,10 @@ void orc_bitwise_and_8u(const uint8_t *a, size_t astep, const uint8_t *b, size_t
 void orc_dilate3x3_8u(const uint8_t *src, size_t sstep, uint8_t *dst, size_t dstep, int rows, int cols);
 /* egress: cvtColor(COLOR_BGR2YUV_I420) of consume() (APP/timed.cpp:308-316); w, h even; dst = planar I420, w*h*3/2 bytes */
 void orc_bgr_to_i420(const uint8_t *src, size_t sstep, int w, int h, uint8_t *dst);
+/* K1 with BORDER_REFLECT (seam-scale image warp, calibration.cpp:118) */
+void orc_remap_linear_reflect_8uc3(const uint8_t *src, size_t sstep, int srows, int scols,
+                                   const float *mapx, size_t mxstep, const float *mapy, size_t mystep,
+                                   uint8_t *dst, size_t dstep, int drows, int dcols);
 /* K18 buildWarp{Plane,Cylindrical,Spherical}Maps: k_rinv = 9 floats, t = 3 floats (plane only). */
 void orc_build_warp_maps(int proj, int tl_u, int tl_v, int rows, int cols,
                          const float *k_rinv, const float *t, float scale,
@@ -171,6 +175,10 @@ void orc_voronoi_seams(int n, const int *corner_x, const int *corner_y, const in
  * mesh_x/mesh_y: N rows x M cols (contiguous); out maps: height x width (contiguous). */
 void orc_convert_mesh_to_map(const float *mesh_x, const float *mesh_y, int N, int M,
                              int width, int height, float *map_x, float *map_y);
+
+/* GainCompensator::feed + cv::solve  OCV/stitching/src/exposure_compensate.cpp:71-145; returns 0 if singular */
+int orc_gain_compensator(int n, const int *corner_x, const int *corner_y, const int *w, const int *h,
+                         const uint8_t *const *images, const uint8_t *const *masks, double *gains);
 
 /* ------------------------------------------------------------------ whole blender (a7, a13) */
 

@@ -356,3 +356,99 @@ void orc_stitch_online(orc_blender *b, int v, const uint8_t *src, size_t sstep, 
     orc_blender_feed(b, v, img, step3);
     free(img);
 }
+
+/* cv::solve(A, b, x, DECOMP_LU) for CV_64F: closed forms for n <= 3 (OCV/core/src/lapack.cpp:1107-1237), otherwise
+ * hal::LU64f = LUImpl (OCV/core/src/matrix_decomp.cpp:52-112) with partial pivoting, in the reference's operation order. */
+static int solve_lu64(double *A, double *b, int n)
+{
+    if (n == 1) { if (A[0] == 0.) return 0; b[0] = b[0] / A[0]; return 1; }
+    if (n == 2) {
+        double d = A[0] * A[3] - A[1] * A[2];
+        if (d == 0.) return 0;
+        d = 1. / d;
+        const double t = (b[0] * A[3] - b[1] * A[1]) * d;
+        b[1] = (b[1] * A[0] - b[0] * A[2]) * d;
+        b[0] = t;
+        return 1;
+    }
+    if (n == 3) {
+#define S(i, j) A[(i) * 3 + (j)]
+        double d = S(0, 0) * (S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) - S(0, 1) * (S(1, 0) * S(2, 2) - S(1, 2) * S(2, 0)) +
+                   S(0, 2) * (S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0));
+        if (d == 0.) return 0;
+        d = 1. / d;
+        double t[3];
+        t[0] = ((S(1, 1) * S(2, 2) - S(1, 2) * S(2, 1)) * b[0] + (S(0, 2) * S(2, 1) - S(0, 1) * S(2, 2)) * b[1] + (S(0, 1) * S(1, 2) - S(0, 2) * S(1, 1)) * b[2]) * d;
+        t[1] = ((S(1, 2) * S(2, 0) - S(1, 0) * S(2, 2)) * b[0] + (S(0, 0) * S(2, 2) - S(0, 2) * S(2, 0)) * b[1] + (S(0, 2) * S(1, 0) - S(0, 0) * S(1, 2)) * b[2]) * d;
+        t[2] = ((S(1, 0) * S(2, 1) - S(1, 1) * S(2, 0)) * b[0] + (S(0, 1) * S(2, 0) - S(0, 0) * S(2, 1)) * b[1] + (S(0, 0) * S(1, 1) - S(0, 1) * S(1, 0)) * b[2]) * d;
+#undef S
+        b[0] = t[0]; b[1] = t[1]; b[2] = t[2];
+        return 1;
+    }
+    const double eps = 2.220446049250313e-16 * 100;
+    for (int i = 0; i < n; ++i) {
+        int k = i;
+        for (int j = i + 1; j < n; ++j) if (fabs(A[j * n + i]) > fabs(A[k * n + i])) k = j;
+        if (fabs(A[k * n + i]) < eps) return 0;
+        if (k != i) {
+            for (int j = i; j < n; ++j) { double t = A[i * n + j]; A[i * n + j] = A[k * n + j]; A[k * n + j] = t; }
+            double t = b[i]; b[i] = b[k]; b[k] = t;
+        }
+        const double d = -1 / A[i * n + i];
+        for (int j = i + 1; j < n; ++j) {
+            const double alpha = A[j * n + i] * d;
+            for (int q = i + 1; q < n; ++q) A[j * n + q] += alpha * A[i * n + q];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double sv = b[i];
+        for (int q = i + 1; q < n; ++q) sv -= A[i * n + q] * b[q];
+        b[i] = sv / A[i * n + i];
+    }
+    return 1;
+}
+
+/* GainCompensator::feed  OCV/stitching/src/exposure_compensate.cpp:71-145.  images: 8UC3 contiguous (h x w x 3),
+ * masks: 8UC1 contiguous; overlap pixels are those where both masks equal 255. */
+int orc_gain_compensator(int n, const int *cx, const int *cy, const int *w, const int *h,
+                         const uint8_t *const *images, const uint8_t *const *masks, double *gains)
+{
+    int *N = (int *)calloc((size_t)n * n, sizeof(int));
+    double *I = (double *)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+            orc_rect roi;
+            if (!overlap_roi(cx[i], cy[i], cx[j], cy[j], w[i], h[i], w[j], h[j], &roi)) continue;
+            int cnt = 0;
+            double s1 = 0, s2 = 0;
+            for (int y = 0; y < roi.height; ++y)
+                for (int x = 0; x < roi.width; ++x) {
+                    const size_t p1 = (size_t)(roi.y - cy[i] + y) * w[i] + (roi.x - cx[i] + x);
+                    const size_t p2 = (size_t)(roi.y - cy[j] + y) * w[j] + (roi.x - cx[j] + x);
+                    if (masks[i][p1] == 255 && masks[j][p2] == 255) {
+                        ++cnt;
+                        const uint8_t *a = images[i] + 3 * p1, *b = images[j] + 3 * p2;
+                        s1 += sqrt((double)(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]));
+                        s2 += sqrt((double)(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
+                    }
+                }
+            N[i * n + j] = N[j * n + i] = cnt > 1 ? cnt : 1;
+            I[i * n + j] = s1 / N[i * n + j];
+            I[j * n + i] = s2 / N[i * n + j];
+        }
+    const double alpha = 0.01, beta = 100;
+    double *A = (double *)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i < n; ++i) gains[i] = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            gains[i] += beta * N[i * n + j];
+            A[i * n + i] += beta * N[i * n + j];
+            if (j == i) continue;
+            A[i * n + i] += 2 * alpha * I[i * n + j] * I[i * n + j] * N[i * n + j];
+            A[i * n + j] -= 2 * alpha * I[i * n + j] * I[j * n + i] * N[i * n + j];
+        }
+    const int ok = solve_lu64(A, gains, n);
+    free(N); free(I); free(A);
+    return ok;
+}

@@ -636,3 +636,31 @@ void orc_bgr_to_i420(const uint8_t *src, size_t sstep, int w, int h, uint8_t *ds
         }
     }
 }
+
+/* K1 with BORDER_REFLECT: remap<LinearFilter<BorderReader<PtrStep<uchar3>, BrdReflect<float3>>>> (the seam-scale image warp,
+ * APP/calibration.cpp:118).  Tap indices go through BrdReflect::idx_row/idx_col (border_interpolate.hpp:485-525). */
+void orc_remap_linear_reflect_8uc3(const uint8_t *src, size_t sstep, int srows, int scols,
+                                   const float *mapx, size_t mxstep, const float *mapy, size_t mystep,
+                                   uint8_t *dst, size_t dstep, int drows, int dcols)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y) {
+        const float *mx = CROWP(float, mapx, mxstep, y);
+        const float *my = CROWP(float, mapy, mystep, y);
+        uint8_t *d = ROWP(uint8_t, dst, dstep, y);
+        for (int x = 0; x < dcols; ++x) {
+            const float xc = mx[x], yc = my[x];
+            const int x1 = f2i_rd(xc), y1 = f2i_rd(yc);
+            const int x2 = (int)((unsigned)x1 + 1u), y2 = (int)((unsigned)y1 + 1u);
+            const float ws[4] = {((float)x2 - xc) * ((float)y2 - yc), (xc - (float)x1) * ((float)y2 - yc),
+                                 ((float)x2 - xc) * (yc - (float)y1), (xc - (float)x1) * (yc - (float)y1)};
+            const int xs[4] = {x1, x2, x1, x2}, ys[4] = {y1, y1, y2, y2};
+            float acc[3] = {0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) {
+                const uint8_t *p = CROWP(uint8_t, src, sstep, reflect_idx(ys[t], srows)) + (size_t)reflect_idx(xs[t], scols) * 3;
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf((float)p[c], ws[t], acc[c]);
+            }
+            for (int c = 0; c < 3; ++c) d[(size_t)x * 3 + c] = sat_u8f(acc[c]);
+        }
+    }
+}

@@ -99,6 +99,14 @@ def remap_linear_8uc1(src, mapx, mapy):
     return dst
 
 
+def remap_linear_reflect_8uc3(src, mapx, mapy):
+    mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
+    dst = np.empty(mapx.shape + (3,), np.uint8)
+    lib().orc_remap_linear_reflect_8uc3(_p(src), _st(src), src.shape[0], src.shape[1], _p(mapx), _st(mapx),
+                                        _p(mapy), _st(mapy), _p(dst), _st(dst), dst.shape[0], dst.shape[1])
+    return dst
+
+
 def remap_nearest_8uc1(src, mapx, mapy):
     mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
     dst = np.empty(mapx.shape, np.uint8)
@@ -307,6 +315,17 @@ def voronoi_seams(corners, masks):
     lib().orc_voronoi_seams(n, _ia([c[0] for c in corners]), _ia([c[1] for c in corners]),
                             _ia([m.shape[1] for m in masks]), _ia([m.shape[0] for m in masks]), ptrs)
     return masks
+
+
+def gain_compensator(corners, images, masks):
+    n = len(images)
+    imgs = [np.ascontiguousarray(i, np.uint8) for i in images]; ms_ = [np.ascontiguousarray(m, np.uint8) for m in masks]
+    ip = (C.c_void_p * n)(*[i.ctypes.data for i in imgs]); mp = (C.c_void_p * n)(*[m.ctypes.data for m in ms_])
+    g = (C.c_double * n)()
+    ok = lib().orc_gain_compensator(n, _ia([c[0] for c in corners]), _ia([c[1] for c in corners]),
+                                    _ia([m.shape[1] for m in ms_]), _ia([m.shape[0] for m in ms_]), ip, mp, g)
+    assert ok
+    return list(g)
 
 
 def convert_mesh_to_map(mesh_x, mesh_y, width, height):

@@ -147,3 +147,66 @@ def test_mesh_double_buffering(ms, cuda):
     torch.cuda.synchronize()
     assert torch.equal(a, a2) and not torch.equal(a, b)
     comp.close()
+
+
+@pytest.mark.parametrize("dilate", [False, True])
+def test_seam_scale_calibration_pipeline(ms, cuda, oracle, dilate):
+    """stitch_calib's own mask/gain pipeline (APP/calibration.cpp:92-135, 224-237) through ms_calibrate_seam vs the same sequence
+    composed from oracle primitives: resize -> seam-scale warp (image REFLECT/LINEAR, mask NEAREST) -> GainCompensator::feed ->
+    Voronoi -> [dilate] -> resize up (INTER_LINEAR, grey values!) -> AND with the compose-scale valid mask."""
+    n, w, h = 6, 480, 270
+    rig = synth.reference_rig(n, w, h)                    # WORK 0.6 MP, SEAM 0.01 MP, compose at full size
+    proj = ms.PROJ_CYLINDRICAL                           # what the app ships (calibration.cpp:100)
+    comp = ms.Compositor(n, (w, h), proj, rig["compose_warp_scale"], num_bands=4, out_size=(0, 0))
+    for i in range(n):
+        comp.set_camera(i, rig["K_compose"][i], rig["R"][i])
+    comp.build_maps()
+    frames = [synth.frame(w, h, i, 0, noise=False) for i in range(n)]
+    frames = [np.clip(f.astype(np.float32) * (0.9 + 0.04 * i), 0, 255).astype(np.uint8) for i, f in enumerate(frames)]   # exposure differences
+    gains = comp.calibrate_seam([to_dev(f) for f in frames], rig["K_seam"], rig["seam_scale"], rig["seam_warp_scale"], dilate=dilate)
+
+    # ---- the same pipeline from oracle primitives ----
+    ss = rig["seam_scale"]
+    rois, imgs_w, masks_w = [], [], []
+    for i in range(n):
+        seam = oracle.resize_linear_8u(frames[i], fx=ss, fy=ss)
+        hs, ws = seam.shape[:2]
+        r = oracle.warp_roi(proj, rig["K_seam"][i], rig["R"][i], rig["seam_warp_scale"], ws, hs)
+        mx, my = oracle.build_warp_maps(proj, r[0], r[1], r[3], r[2], oracle.k_rinv_gpu(rig["K_seam"][i], rig["R"][i]), rig["seam_warp_scale"])
+        rois.append(r)
+        imgs_w.append(oracle.remap_linear_reflect_8uc3(seam, mx, my))
+        masks_w.append(oracle.remap_nearest_8uc1(np.full((hs, ws), 255, np.uint8), mx, my))
+    ref_gains = oracle.gain_compensator([r[:2] for r in rois], imgs_w, masks_w)
+    oracle.voronoi_seams([r[:2] for r in rois], masks_w)
+    assert np.allclose(gains, ref_gains, rtol=2e-3), (gains, ref_gains)        # device vs glibc sinf/cosf in the seam maps -> <= 1 LSB image diffs
+    assert 0.7 < min(gains) and max(gains) < 1.3 and max(gains) - min(gains) > 0.02   # it does compensate the injected exposure ramp
+    diff_px = 0
+    for i in range(n):
+        g = comp.view_geom(i).roi
+        m = masks_w[i]
+        if dilate:
+            m = oracle.dilate3x3_8u(m)
+        big = oracle.resize_linear_8u(m, dsize=(g.width, g.height))
+        gx, gy = [host(t) for t in comp.maps(i)]
+        valid = oracle.remap_nearest_8uc1(np.full((h, w), 255, np.uint8), gx, gy)
+        ref = big & valid
+        got = host(comp.mask(i))
+        diff_px += int((got != ref).sum())
+        assert ((got != 0) & (got != 255)).any(), "bilinear upsizing leaves grey seam pixels (non-binary weights)"
+    assert diff_px <= 0.002 * sum(m.size for m in masks_w) * 16, diff_px       # a seam-scale border flip would show as a small block
+    # the blender accepts these grey masks: end-to-end vs the oracle fed with the product's masks and gains
+    comp.init_blender()
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    rois_c = [comp.view_geom(i).roi.tuple() for i in range(n)]
+    b = oracle.Blender([r[:2] for r in rois_c], [r[2:] for r in rois_c], 4)
+    for i in range(n):
+        b.init_view(i, host(comp.mask(i)))
+    for i in range(n):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames[i], xm, ym, gains[i])
+    ref16, refmask = b.blend()
+    assert np.array_equal(host(out16), ref16) and np.array_equal(host(comp.result_mask()), refmask)
+    b.close(); comp.close()

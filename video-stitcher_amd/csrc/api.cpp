@@ -68,14 +68,14 @@ int ms_device_count(void)
     return n;
 }
 
-int ms_remap(const ms_image *src, const ms_image *xmap, const ms_image *ymap, ms_image *dst, int interp, ms_stream s)
+int ms_remap(const ms_image *src, const ms_image *xmap, const ms_image *ymap, ms_image *dst, int interp, int border_type, ms_stream s)
 {
     PRE() IMG(src, "ms_remap src") IMG(xmap, "ms_remap xmap") IMG(ymap, "ms_remap ymap") IMG(dst, "ms_remap dst")
     MS_CHECK(xmap->type == MS_32FC1 && ymap->type == MS_32FC1, "ms_remap: maps must be 32FC1");   // remap.cpp:81
     SAME(xmap, ymap, "ms_remap maps") SAME(xmap, dst, "ms_remap dst")
     MS_CHECK(dst->type == src->type, "ms_remap: dst type must equal src type");
     MS_CHECK(src->data != dst->data, "ms_remap: in-place remap is not supported (the reference allocates a new dst)");
-    return launch_remap(*src, *xmap, *ymap, *dst, interp, as_stream(s));
+    return launch_remap(*src, *xmap, *ymap, *dst, interp, border_type, as_stream(s));
 }
 
 int ms_resize_linear(const ms_image *src, ms_image *dst, double fx, double fy, ms_stream s)

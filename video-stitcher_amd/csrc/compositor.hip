@@ -1123,6 +1123,96 @@ int ms_build_masks(ms_ctx *c, int mode, ms_stream stream)
     return MS_OK;
 }
 
+// Seam-scale calibration, the reference's own pipeline (APP/calibration.cpp:92-135 and 224-237):
+//   resize(full, seam_scale) -> warp(image: LINEAR/REFLECT, mask 255: NEAREST/CONSTANT) at seam scale -> download ->
+//   GainCompensator::feed (host) -> VoronoiSeamFinder (host) -> upload -> [dilate] -> resize to the compose mask size
+//   (INTER_LINEAR) -> bitwise_and with warp(255) at compose scale  => the masks init_gpu receives.
+int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam, const ms_seam_params *prm, double *gains_out, ms_stream stream)
+{
+    if (!c || !full_imgs || !K_seam || !prm) return fail(MS_ERR_INVALID, "ms_calibrate_seam: null argument");
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_calibrate_seam: call ms_build_maps first");
+    MS_CHECK(prm->seam_scale > 0 && prm->seam_scale <= 1.0 && prm->seam_warp_scale > 0, "ms_calibrate_seam: bad scales");
+    hipStream_t st = as_stream(stream);
+    const int N = c->N, W = c->cfg.src_width, H = c->cfg.src_height;
+    const int ws = (int)__builtin_rint(W * prm->seam_scale), hs = (int)__builtin_rint(H * prm->seam_scale);   // resize.cpp:74
+    MS_CHECK(ws >= 2 && hs >= 2, "ms_calibrate_seam: seam image %dx%d too small", ws, hs);
+    if (int e = alloc_masks(c)) return e;
+    std::vector<ms_rect> rs(N);
+    std::vector<std::vector<uint8_t>> himg(N), hmask(N);
+    DevBuf seam, mapx, mapy, wimg, wmask;
+    if (int e = seam.alloc((size_t)ws * hs * 3)) return e;
+    for (int i = 0; i < N; ++i) {
+        MS_CHECK(full_imgs[i].data && full_imgs[i].type == MS_8UC3 && full_imgs[i].rows == H && full_imgs[i].cols == W,
+                 "ms_calibrate_seam: image %d must be 8UC3 %dx%d", i, W, H);
+        ms_image simg{seam.p, (size_t)ws * 3, hs, ws, MS_8UC3};
+        if (int e = launch_resize_linear(full_imgs[i], simg, prm->seam_scale, prm->seam_scale, st)) return e;        // calibration.cpp:95
+        const float *Ks = K_seam + 9 * i;
+        Projector P;
+        set_camera_params(P, Ks, c->R[i], nullptr, prm->seam_warp_scale);
+        rs[i] = warp_roi(c->cfg.projection, P, ws, hs);
+        MS_CHECK(rs[i].width > 0 && rs[i].height > 0 && (size_t)rs[i].width * rs[i].height < (1u << 28), "ms_calibrate_seam: bad seam ROI for view %d", i);
+        const size_t npx = (size_t)rs[i].width * rs[i].height;
+        if (int e = mapx.alloc(npx * 4)) return e;
+        if (int e = mapy.alloc(npx * 4)) return e;
+        if (int e = wimg.alloc(npx * 3)) return e;
+        if (int e = wmask.alloc(npx)) return e;
+        ms_image mx{mapx.p, (size_t)rs[i].width * 4, rs[i].height, rs[i].width, MS_32FC1}, my{mapy.p, (size_t)rs[i].width * 4, rs[i].height, rs[i].width, MS_32FC1};
+        float k_rinv[9];
+        k_rinv_gemm(Ks, c->R[i], k_rinv);
+        if (int e = launch_build_warp_maps(c->cfg.projection, rs[i].x, rs[i].y, mx, my, k_rinv, nullptr, prm->seam_warp_scale, st)) return e;
+        ms_image wi{wimg.p, (size_t)rs[i].width * 3, rs[i].height, rs[i].width, MS_8UC3};
+        if (int e = launch_remap(simg, mx, my, wi, MS_INTER_LINEAR, MS_BORDER_REFLECT, st)) return e;                   // calibration.cpp:118
+        k_valid_mask<<<dim3(div_up(rs[i].width, 64), div_up(rs[i].height, 4)), dim3(64, 4), 0, st>>>(                // calibration.cpp:122
+            (const float *)mapx.p, (const float *)mapy.p, rs[i].width, rs[i].height, rs[i].width, hs, ws, (uint8_t *)wmask.p, rs[i].width);
+        MS_LAUNCH_CHECK();
+        himg[i].resize(npx * 3); hmask[i].resize(npx);
+        MS_HIP(hipMemcpyAsync(himg[i].data(), wimg.p, npx * 3, hipMemcpyDeviceToHost, st));
+        MS_HIP(hipMemcpyAsync(hmask[i].data(), wmask.p, npx, hipMemcpyDeviceToHost, st));
+        MS_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<const uint8_t *> ip(N), mp(N);
+    std::vector<uint8_t *> mpw(N);
+    for (int i = 0; i < N; ++i) { ip[i] = himg[i].data(); mp[i] = hmask[i].data(); mpw[i] = hmask[i].data(); }
+    if (prm->estimate_gains || gains_out) {                                                                          // calibration.cpp:131
+        std::vector<double> g(N, 1.0);
+        if (!estimate_gains(N, rs.data(), ip.data(), mp.data(), g.data())) return fail(MS_ERR_INVALID, "ms_calibrate_seam: singular gain system");
+        for (int i = 0; i < N; ++i) {
+            if (gains_out) gains_out[i] = g[i];
+            if (prm->estimate_gains) if (int e = ms_set_gain(c, i, g[i])) return e;
+        }
+    }
+    voronoi_seams(N, rs.data(), mpw.data());                                                                          // calibration.cpp:134-135
+    DevBuf dil, big;
+    for (int i = 0; i < N; ++i) {
+        const size_t npx = hmask[i].size();
+        const int aw = c->roi[i].width, ah = c->roi[i].height;
+        if (int e = wmask.alloc(npx)) return e;
+        MS_HIP(hipMemcpyAsync(wmask.p, hmask[i].data(), npx, hipMemcpyHostToDevice, st));                            // calibration.cpp:229
+        ms_image sm{wmask.p, (size_t)rs[i].width, rs[i].height, rs[i].width, MS_8UC1};
+        if (prm->dilate) {                                                                                            // calibration.cpp:231-232
+            if (int e = dil.alloc(npx)) return e;
+            ms_image dm{dil.p, (size_t)rs[i].width, rs[i].height, rs[i].width, MS_8UC1};
+            if (int e = launch_dilate3(sm, dm, st)) return e;
+            sm = dm;
+        }
+        if (int e = big.alloc((size_t)aw * ah)) return e;
+        ms_image bm{big.p, (size_t)aw, ah, aw, MS_8UC1};
+        if (int e = launch_resize_linear(sm, bm, 0, 0, st)) return e;                                                // calibration.cpp:236
+        ms_image mx = view_map_image(c, i, 0), my = view_map_image(c, i, 1);
+        uint8_t *dstm = (uint8_t *)c->masks.p + c->mask_off[i];
+        k_valid_mask<<<dim3(div_up(aw, 64), div_up(ah, 4)), dim3(64, 4), 0, st>>>(                                   // calibration.cpp:224-227
+            (const float *)mx.data, (const float *)my.data, c->map_pitch[i], ah, aw, H, W, dstm, aw);
+        MS_LAUNCH_CHECK();
+        ms_image vm{dstm, (size_t)aw, ah, aw, MS_8UC1};
+        if (int e = launch_and_8u(bm, vm, vm, st)) return e;                                                         // calibration.cpp:237
+        MS_HIP(hipStreamSynchronize(st));
+    }
+    seam.release(); mapx.release(); mapy.release(); wimg.release(); wmask.release(); dil.release(); big.release();
+    c->masks_built = true;
+    c->blender_ready = false;
+    return MS_OK;
+}
+
 int ms_set_mask(ms_ctx *c, int view, const uint8_t *mask_host, size_t step)
 {
     if (int e = ctx_check_view(c, view)) return e;

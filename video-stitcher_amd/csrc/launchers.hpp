@@ -6,7 +6,7 @@
 
 namespace ms {
 
-int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms_image &dst, int interp, hipStream_t st);
+int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms_image &dst, int interp, int border, hipStream_t st);
 int launch_resize_linear(const ms_image &src, ms_image &dst, double fx, double fy, hipStream_t st);
 int launch_convert_scale_8u(const ms_image &src, ms_image &dst, double alpha, hipStream_t st);
 int launch_convert(const ms_image &src, ms_image &dst, double alpha, hipStream_t st);
@@ -40,5 +40,7 @@ BlendGeom blender_prepare(ms_rect dst_roi, int actual_num_bands);
 ViewPad blender_view_pad(const BlendGeom &g, int tl_x, int tl_y, int mask_cols, int mask_rows);
 // VoronoiSeamFinder over host masks (contiguous, h x w each), in place
 void voronoi_seams(int n, const ms_rect *rois, uint8_t **masks);
+// GainCompensator::feed over host images (8UC3, contiguous) and masks (8UC1, contiguous); false if the system is singular
+bool estimate_gains(int n, const ms_rect *rois, const uint8_t *const *images, const uint8_t *const *masks, double *gains);
 
 }  // namespace ms

@@ -71,8 +71,41 @@ __global__ void __launch_bounds__(256) k_remap_nearest_c1(const uint8_t *__restr
     row_ptr<uint8_t>(dst, dstep, y)[x] = inb ? row_ptr<uint8_t>(src, sstep, yy)[xx] : (uint8_t)0;
 }
 
-int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms_image &dst, int interp, hipStream_t st)
+// remap, INTER_LINEAR, BORDER_REFLECT, 8UC3: the seam-scale image warp of calibration (APP/calibration.cpp:118);
+// every tap index goes through BrdReflect (border_interpolate.hpp:485-525)
+__global__ void __launch_bounds__(256) k_remap_linear_reflect3(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                               const float *__restrict__ mx, size_t mxstep, const float *__restrict__ my, size_t mystep,
+                                                               uint8_t *__restrict__ dst, size_t dstep, int drows, int dcols)
 {
+    XY_GUARD(dcols, drows)
+    const float xc = row_ptr<float>(mx, mxstep, y)[x], yc = row_ptr<float>(my, mystep, y)[x];
+    const int x1 = f2i_rd(xc), y1 = f2i_rd(yc);
+    const int x2 = (int)((unsigned)x1 + 1u), y2 = (int)((unsigned)y1 + 1u);
+    const float w[4] = {((float)x2 - xc) * ((float)y2 - yc), (xc - (float)x1) * ((float)y2 - yc),
+                        ((float)x2 - xc) * (yc - (float)y1), (xc - (float)x1) * (yc - (float)y1)};
+    const int xs[4] = {x1, x2, x1, x2}, ys[4] = {y1, y1, y2, y2};
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint8_t *p = row_ptr<uint8_t>(src, sstep, reflect_idx(ys[t], srows)) + (size_t)reflect_idx(xs[t], scols) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_fmaf((float)p[c], w[t], acc[c]);
+    }
+    uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + (size_t)x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = sat_u8(acc[c]);
+}
+
+int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms_image &dst, int interp, int border, hipStream_t st)
+{
+    if (border == MS_BORDER_REFLECT) {
+        if (!(src.type == MS_8UC3 && interp == MS_INTER_LINEAR)) return fail(MS_ERR_UNSUPPORTED, "ms_remap: BORDER_REFLECT is only used for 8UC3 / INTER_LINEAR");
+        k_remap_linear_reflect3<<<grid2d(dst.cols, dst.rows), dim3(BX, BY), 0, st>>>((const uint8_t *)src.data, src.step, src.rows, src.cols,
+            (const float *)xm.data, xm.step, (const float *)ym.data, ym.step, (uint8_t *)dst.data, dst.step, dst.rows, dst.cols);
+        MS_LAUNCH_CHECK();
+        return MS_OK;
+    }
+    if (border != MS_BORDER_CONSTANT) return fail(MS_ERR_UNSUPPORTED, "ms_remap: border type %d not on the path", border);
     const dim3 g = grid2d(dst.cols, dst.rows), b(BX, BY);
     auto S = (const uint8_t *)src.data; auto D = (uint8_t *)dst.data;
     auto MX = (const float *)xm.data; auto MY = (const float *)ym.data;

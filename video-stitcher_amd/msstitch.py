@@ -40,6 +40,10 @@ class Config(C.Structure):
                 ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int), ("reserved", C.c_int * 8)]
 
 
+class SeamParams(C.Structure):
+    _fields_ = [("seam_scale", C.c_double), ("seam_warp_scale", C.c_float), ("dilate", C.c_int), ("estimate_gains", C.c_int)]
+
+
 class ViewGeom(C.Structure):
     _fields_ = [("roi", Rect)] + [(n, C.c_int) for n in ("top", "left", "bottom", "right", "x_tl", "y_tl", "x_br", "y_br")]
 
@@ -56,7 +60,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420",
+    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam",
 ]
 
 _lib = None
@@ -156,9 +160,9 @@ def _new(shape, dtype):
     return _torch().empty(shape, dtype=dtype, device="cuda")
 
 
-def remap(src, xmap, ymap, interpolation=INTER_LINEAR):
+def remap(src, xmap, ymap, interpolation=INTER_LINEAR, border_type=BORDER_CONSTANT):
     dst = _new(tuple(xmap.shape) + tuple(src.shape[2:]), src.dtype)
-    _chk(load().ms_remap(C.byref(img(src)), C.byref(img(xmap)), C.byref(img(ymap)), C.byref(img(dst)), interpolation, _stream()))
+    _chk(load().ms_remap(C.byref(img(src)), C.byref(img(xmap)), C.byref(img(ymap)), C.byref(img(dst)), interpolation, border_type, _stream()))
     return dst
 
 
@@ -337,6 +341,16 @@ class Compositor:
 
     def build_masks(self, mode=1):
         _chk(load().ms_build_masks(self._ctx, mode, _stream()))
+
+    def calibrate_seam(self, full_imgs, K_seam, seam_scale, seam_warp_scale, dilate=False, estimate_gains=True):
+        """stitch_calib's seam-scale pipeline; returns the estimated gains."""
+        import numpy as np
+        arr = (Image * self.n)(*[img(t) for t in full_imgs])
+        k = np.ascontiguousarray(K_seam, np.float32).reshape(self.n * 9)
+        prm = SeamParams(seam_scale, seam_warp_scale, int(dilate), int(estimate_gains))
+        g = (C.c_double * self.n)()
+        _chk(load().ms_calibrate_seam(self._ctx, arr, k.ctypes.data_as(C.POINTER(C.c_float)), C.byref(prm), g, _stream()))
+        return list(g)
 
     def set_mask(self, view, mask_np):
         import numpy as np

@@ -23,8 +23,8 @@ template <class Mat> inline ms_image wrap(const Mat &m)
 
 // ---- cv::cuda:: free functions (dst must be pre-created, as GpuMat::create would) ------------------------
 namespace cuda {
-template <class Mat> void remap(const Mat &src, Mat &dst, const Mat &xmap, const Mat &ymap, int interpolation, ms_stream s = nullptr)
-{ ms_image a = wrap(src), x = wrap(xmap), y = wrap(ymap), d = wrap(dst); check(ms_remap(&a, &x, &y, &d, interpolation, s)); }
+template <class Mat> void remap(const Mat &src, Mat &dst, const Mat &xmap, const Mat &ymap, int interpolation, int borderMode = MS_BORDER_CONSTANT, ms_stream s = nullptr)
+{ ms_image a = wrap(src), x = wrap(xmap), y = wrap(ymap), d = wrap(dst); check(ms_remap(&a, &x, &y, &d, interpolation, borderMode, s)); }
 template <class Mat> void resize(const Mat &src, Mat &dst, double fx, double fy, ms_stream s = nullptr)
 { ms_image a = wrap(src), d = wrap(dst); check(ms_resize_linear(&a, &d, fx, fy, s)); }
 template <class Mat> void copyMakeBorder(const Mat &src, Mat &dst, int top, int bottom, int left, int right, int borderType, ms_stream s = nullptr)

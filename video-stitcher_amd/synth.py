@@ -74,3 +74,34 @@ def algorithmic_bytes(view_src_wh, padded_px, pano_padded_px, out_wh, warped_px=
     if cpw:
         b += 6.0 * warped_px
     return b
+
+
+def reference_rig(n, w, h, work_megapix=0.6, seam_megapix=0.01, compose_megapix=-1.0, hfov_deg=90.0):
+    """stitch_calib's scale bookkeeping and rig model (APP/calibration.cpp:28-68, 101-116, 147-181, 269-281, defs.h:51-53).
+    Returns a dict with the scales and, per view, K at compose scale, K at seam scale (fp32) and R."""
+    area = float(w * h)
+    work_scale = 1.0 if work_megapix < 0 else min(1.0, math.sqrt(work_megapix * 1e6 / area))
+    seam_scale = min(1.0, math.sqrt(seam_megapix * 1e6 / area))
+    seam_work_aspect = seam_scale / work_scale
+    compose_scale = min(1.0, math.sqrt(compose_megapix * 1e6 / area)) if compose_megapix > 0 else 1.0
+    compose_work_aspect = compose_scale / work_scale
+    focal_tmp = 1.0 / math.tan(math.radians(hfov_deg) * 0.5)
+    ppx = (w * work_scale) / 2.0
+    ppy = (h * work_scale) / 2.0
+    focal = focal_tmp * ppx
+    warped_image_scale = float(np.float32(focal))                       # static_cast<float>(cameras[0].focal)
+    out = dict(work_scale=work_scale, seam_scale=seam_scale, seam_work_aspect=seam_work_aspect, compose_scale=compose_scale,
+               warped_image_scale=warped_image_scale,
+               seam_warp_scale=float(np.float32(warped_image_scale * seam_work_aspect)),      # static_cast<float>(scale * swa)
+               compose_warp_scale=float(np.float32(np.float32(warped_image_scale) * np.float32(compose_work_aspect))),
+               K_seam=[], K_compose=[], R=[])
+    swa = np.float32(seam_work_aspect)
+    for i in range(n):
+        _, R = camera(n, w, h, hfov_deg, i)
+        Kw = np.array([[focal, 0, ppx], [0, focal, ppy], [0, 0, 1]], np.float64).astype(np.float32)   # K().convertTo(CV_32F)
+        Ks = Kw.copy()
+        Ks[0, 0] *= swa; Ks[0, 2] *= swa; Ks[1, 1] *= swa; Ks[1, 2] *= swa                           # calibration.cpp:112-116
+        Kc = np.array([[focal * compose_work_aspect, 0, ppx * compose_work_aspect],
+                       [0, focal * compose_work_aspect, ppy * compose_work_aspect], [0, 0, 1]], np.float64).astype(np.float32)
+        out["K_seam"].append(Ks); out["K_compose"].append(Kc); out["R"].append(R)
+    return out
