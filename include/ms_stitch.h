@@ -142,6 +142,11 @@ MS_API int ms_build_warp_maps(int projection, int tl_u, int tl_v, ms_image *map_
                               const float *k_rinv, const float *r_kinv, const float *t, float scale,
                               ms_stream stream);
 
+/* cvtColor(src, dst, CV_YUV2BGR_NV12): the capture-side conversion the reference runs on the CPU per camera frame
+ * (APP/networking.cpp:45-47, 1920x1620 NV12 -> 1920x1080 BGR, defs.h:10-17) -> YUV420sp2RGB888Invoker<0,0>
+ * (OCV/imgproc/src/color.cpp).  src 8UC1 of (rows*3/2) x cols (Y plane, then interleaved UV); dst 8UC3, even size. */
+MS_API int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream stream);
+
 /* cvtColor(src, dst, COLOR_BGR2YUV_I420): the encoder input of consume() (APP/timed.cpp:308-316) ->
  * RGB888toYUV420pInvoker (OCV/imgproc/src/color.cpp:9082-9160).  src 8UC3 with even width/height; dst contiguous
  * 8UC1 of (rows*3/2) x cols = planar I420.  Also what bench.py gathers across GPUs (half the bytes of BGR). */

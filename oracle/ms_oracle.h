@@ -109,6 +109,8 @@ void orc_bitwise_and_8u(const uint8_t *a, size_t astep, const uint8_t *b, size_t
 void orc_dilate3x3_8u(const uint8_t *src, size_t sstep, uint8_t *dst, size_t dstep, int rows, int cols);
 /* egress: cvtColor(COLOR_BGR2YUV_I420) of consume() (APP/timed.cpp:308-316); w, h even; dst = planar I420, w*h*3/2 bytes */
 void orc_bgr_to_i420(const uint8_t *src, size_t sstep, int w, int h, uint8_t *dst);
+/* ingest: cvtColor(COLOR_YUV2BGR_NV12) of the capture threads (APP/networking.cpp:45-47); src = (h*3/2) x w 8UC1 */
+void orc_nv12_to_bgr(const uint8_t *src, size_t sstep, int w, int h, uint8_t *dst, size_t dstep);
 /* K1 with BORDER_REFLECT (seam-scale image warp, calibration.cpp:118) */
 void orc_remap_linear_reflect_8uc3(const uint8_t *src, size_t sstep, int srows, int scols,
                                    const float *mapx, size_t mxstep, const float *mapy, size_t mystep,

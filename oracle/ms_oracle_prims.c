@@ -664,3 +664,26 @@ void orc_remap_linear_reflect_8uc3(const uint8_t *src, size_t sstep, int srows, 
         }
     }
 }
+
+/* ingest: cvtColor(COLOR_YUV2BGR_NV12) = YUV420sp2RGB888Invoker<bIdx 0, uIdx 0>  OCV/imgproc/src/color.cpp:8738-8745 and the
+ * invoker above them; called per received camera frame in APP/networking.cpp:45-47.  src: h rows of Y then h/2 rows of
+ * interleaved UV (same stride); w, h even. */
+void orc_nv12_to_bgr(const uint8_t *src, size_t sstep, int w, int h, uint8_t *dst, size_t dstep)
+{
+    const int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
+    const uint8_t *uvp = src + (size_t)h * sstep;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t *yr = CROWP(uint8_t, src, sstep, y), *uv = CROWP(uint8_t, uvp, sstep, y / 2);
+        uint8_t *d = ROWP(uint8_t, dst, dstep, y);
+        for (int x = 0; x < w; ++x) {
+            const int u = (int)uv[(x & ~1)] - 128, v = (int)uv[(x & ~1) + 1] - 128;
+            const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+            int yy = (int)yr[x] - 16; if (yy < 0) yy = 0;
+            yy *= CY;
+            const int b = (yy + buv) >> SH, g = (yy + guv) >> SH, r = (yy + ruv) >> SH;
+            d[3 * x] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+            d[3 * x + 1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+            d[3 * x + 2] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+}

@@ -220,6 +220,13 @@ def dilate3x3_8u(src):
     return dst
 
 
+def nv12_to_bgr(src):
+    h = src.shape[0] * 2 // 3; w = src.shape[1]
+    dst = np.empty((h, w, 3), np.uint8)
+    lib().orc_nv12_to_bgr(_p(src), _st(src), w, h, _p(dst), _st(dst))
+    return dst
+
+
 def bgr_to_i420(src):
     h, w = src.shape[:2]
     dst = np.empty((h * 3 // 2, w), np.uint8)

@@ -239,3 +239,16 @@ def test_bgr_to_i420(ms, cuda, oracle, size):
     assert np.array_equal(host(ms.bgr_to_i420(to_dev(src))), ref)
     assert np.array_equal(host(ms.bgr_to_i420(to_dev_roi(src, rng))), ref)       # padded source step
     assert ref[0, 0] == 235 and ref[size[0] - 1, size[1] - 1] == 16              # studio-swing luma of white / black
+
+
+@pytest.mark.parametrize("size", [(1080, 1920), (36, 50), (2, 2)])
+def test_nv12_to_bgr(ms, cuda, oracle, size):
+    """The capture threads' cvtColor(CV_YUV2BGR_NV12) (networking.cpp:45-47; 1920x1620 NV12 frames, defs.h:10-17)."""
+    rng = rng_for("nv12", size)
+    h, w = size
+    src = rng.integers(0, 256, size=(h * 3 // 2, w), dtype=np.uint8)
+    src[0, :2] = (16, 235); src[h, :2] = (128, 128)                      # black / white with neutral chroma
+    ref = oracle.nv12_to_bgr(src)
+    assert np.array_equal(host(ms.nv12_to_bgr(to_dev(src))), ref)
+    assert np.array_equal(host(ms.nv12_to_bgr(to_dev_roi(src, rng))), ref)
+    assert tuple(ref[0, 0]) == (0, 0, 0) and tuple(ref[0, 1]) == (255, 255, 255)

@@ -204,6 +204,15 @@ int ms_build_warp_maps(int projection, int tl_u, int tl_v, ms_image *mx, ms_imag
     return launch_build_warp_maps(projection, tl_u, tl_v, *mx, *my, k_rinv, t, scale, as_stream(s));
 }
 
+int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream s)
+{
+    PRE() IMG(src, "ms_nv12_to_bgr src") IMG(dst, "ms_nv12_to_bgr dst")
+    MS_CHECK(src->type == MS_8UC1 && dst->type == MS_8UC3, "ms_nv12_to_bgr: 8UC1 planes -> 8UC3");
+    MS_CHECK(dst->cols % 2 == 0 && dst->rows % 2 == 0 && src->cols == dst->cols && src->rows == dst->rows * 3 / 2,
+             "ms_nv12_to_bgr: src must be (rows*3/2) x cols of an even-sized dst (color.cpp: CV_Assert)");
+    return launch_nv12_to_bgr(*src, *dst, as_stream(s));
+}
+
 int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream s)
 {
     PRE() IMG(src, "ms_bgr_to_i420 src") IMG(dst, "ms_bgr_to_i420 dst")

@@ -515,6 +515,42 @@ int launch_build_warp_maps(int proj, int tl_u, int tl_v, ms_image &mx, ms_image 
 }
 
 // ------------------------------------------------------------------------------------------------
+// cvtColor(COLOR_YUV2BGR_NV12)  [imgproc/src/color.cpp:8738-8745 + YUV420sp2RGB888Invoker<0,0>]: the per-camera ingest the
+// reference does on the CPU (APP/networking.cpp:45-47).  One lane = 2 rows x 4 pixels: two 4-byte Y loads, one 4-byte UV load.
+__global__ void __launch_bounds__(256) k_nv12_to_bgr(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= w || y >= h) return;
+    constexpr int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
+    const int n = min(4, w - x);
+    const uint8_t *uvrow = src + (size_t)(h + y / 2) * sstep + x;
+    uint8_t uv[4] = {128, 128, 128, 128};
+    for (int i = 0; i < n; ++i) uv[i] = uvrow[i];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint8_t *yr = src + (size_t)(y + r) * sstep + x;
+        uint8_t *d = dst + (size_t)(y + r) * dstep + (size_t)x * 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= n) break;
+            const int u = (int)uv[k & ~1] - 128, v = (int)uv[(k & ~1) + 1] - 128;
+            const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+            const int yy = max(0, (int)yr[k] - 16) * CY;
+            d[3 * k] = (uint8_t)min(max((yy + buv) >> SH, 0), 255);
+            d[3 * k + 1] = (uint8_t)min(max((yy + guv) >> SH, 0), 255);
+            d[3 * k + 2] = (uint8_t)min(max((yy + ruv) >> SH, 0), 255);
+        }
+    }
+}
+int launch_nv12_to_bgr(const ms_image &src, ms_image &dst, hipStream_t st)
+{
+    k_nv12_to_bgr<<<dim3(div_up(div_up(dst.cols, 4), BX), div_up(dst.rows / 2, BY)), dim3(BX, BY), 0, st>>>(
+        (const uint8_t *)src.data, src.step, dst.cols, dst.rows, (uint8_t *)dst.data, dst.step);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // cvtColor(COLOR_BGR2YUV_I420)  [imgproc/src/color.cpp:8745-8756, 9082-9160]: BT.601 fixed point (shift 20), chroma from
 // the top-left pixel of each 2x2 block, planar I420 output.  One lane = 2 rows x 4 pixels (12-byte row loads).
 __device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t)min(max(v, 0), 255); }

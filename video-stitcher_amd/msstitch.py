@@ -60,7 +60,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam",
+    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr",
 ]
 
 _lib = None
@@ -273,6 +273,13 @@ def build_warp_maps(projection, tl_u, tl_v, rows, cols, k_rinv, scale, t=None):
         ta, tp = _fa(t, 3)
     _chk(load().ms_build_warp_maps(projection, tl_u, tl_v, C.byref(img(mx)), C.byref(img(my)), kp, kp, tp, C.c_float(scale), _stream()))
     return mx, my
+
+
+def nv12_to_bgr(src, dst=None):
+    if dst is None:
+        dst = _new((src.shape[0] * 2 // 3, src.shape[1], 3), _torch().uint8)
+    _chk(load().ms_nv12_to_bgr(C.byref(img(src)), C.byref(img(dst)), _stream()))
+    return dst
 
 
 def bgr_to_i420(src, dst=None):
