@@ -184,7 +184,8 @@ typedef struct ms_config {
     int max_frames;         /* frames batched per ms_stitch call (1 = live; >1 amortises launches)    */
     int reserved[8];        /* [0] != 0: debug, run the simple one-pixel-per-lane kernels instead of the tiled ones;
                              * [1] != 0: stage the warp kernel's source tiles through LDS (measured slower);
-                             * [2] != 0: keep the work lists in raster order instead of the XCD-aware order */
+                             * [2] != 0: keep the work lists in raster order instead of the XCD-aware order;
+                             * [3], [4]: view sharding (shard count, shard index), see ms_stitch_partial */
 } ms_config;
 
 MS_API int ms_create(const ms_config *cfg, ms_ctx **out);
@@ -238,6 +239,18 @@ MS_API int ms_set_mesh_maps(ms_ctx *ctx, int view, const ms_image *x_mesh, const
  * No allocation, no host sync. */
 MS_API int ms_stitch(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
                      ms_stream stream);
+/* View sharding (BASELINE configs[4]): create every rank's context with the SAME cameras/masks and
+ * ms_config.reserved[3] = number of shards S (<= 4), reserved[4] = this rank's shard index; shard k owns the contiguous block
+ * of views [k*N/S, (k+1)*N/S).  The weighted accumulation into the dst Laplacian pyramid is a sum of int16 terms
+ * (multiband_blend.cu:46-49), so each rank writes the partial sums of its views (ms_stitch_partial; entries of `views` for
+ * views it does not own are ignored), the caller moves the partial buffers to the sink rank (RCCL send/recv: int16 has no
+ * reduce op), and the sink adds them (wrap-around, order independent => bit-identical to one GPU), normalises, collapses and
+ * writes the outputs (ms_stitch_finish).  ms_partial_bytes = size of one frame's partial buffer. */
+MS_API size_t ms_partial_bytes(const ms_ctx *ctx);
+MS_API int ms_stitch_partial(ms_ctx *ctx, int n_frames, const ms_image *views, void *partial_out, ms_stream stream);
+MS_API int ms_stitch_finish(ms_ctx *ctx, int n_frames, const void *const *partials, int n_partials,
+                            ms_image *out8u, ms_image *out16s, ms_stream stream);
+
 /* gpu_dst_mask_ (blenders.cpp:803): frame-invariant; 8UC1 pano-ROI sized DEVICE image owned by ctx. */
 MS_API int ms_get_result_mask(ms_ctx *ctx, ms_image *mask);
 

@@ -149,6 +149,38 @@ def test_lds_staged_warp_equals_direct(ms, cuda, rig):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("rig,shards", [("mini6", 2), ("mini6", 3), ("cfg2", 2)])
+def test_view_sharding_equals_single_context(ms, cuda, rig, shards):
+    """BASELINE configs[4] mechanism on one GPU: S contexts, each owning a block of views, write partial int16 sums;
+    the sink context adds them (wrap-around) and finishes.  Must equal the single-context frame bit for bit."""
+    full, cfg, _ = make_rig(ms, rig, max_frames=2)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(2)]
+    pg = full.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    want16 = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(2)]
+    want8 = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda) for _ in range(2)]
+    full.stitch(frames, out8u=want8, out16s=want16)
+    comps, parts = [], []
+    for k in range(shards):
+        c, _, _ = make_rig(ms, rig, max_frames=2, shards=shards, shard_index=k)
+        lo, hi = k * cfg["n"] // shards, (k + 1) * cfg["n"] // shards
+        mine = [[fr[v] if lo <= v < hi else None for v in range(cfg["n"])] for fr in frames]
+        part = torch.full((2 * c.partial_bytes() // 2,), 12345, dtype=torch.int16, device=cuda)
+        c.stitch_partial(mine, part)
+        comps.append(c); parts.append(part)
+    with pytest.raises(ms.MsError, match="view shard"):
+        comps[0].stitch(frames, out16s=want16)
+    got16 = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(2)]
+    got8 = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda) for _ in range(2)]
+    comps[0].stitch_finish(2, parts[::-1], out8u=got8, out16s=got16)       # order of the partials must not matter
+    torch.cuda.synchronize()
+    for t in range(2):
+        assert torch.equal(got16[t], want16[t]) and torch.equal(got8[t], want8[t])
+    for c in comps:
+        c.close()
+    full.close()
+
+
 def test_config1_two_views(ms, cuda, oracle):
     """BASELINE configs[0] geometry (2 views 640x480, yaw -/+25 deg, hfov 90, scale 2000/2pi; SURVEY App. C known ROIs),
     composited with the multiband path on the GPU and compared with the oracle."""

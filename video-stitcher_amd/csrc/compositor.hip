@@ -269,13 +269,20 @@ __device__ __forceinline__ void up_quad(const int16_t *__restrict__ cs, int cpit
 __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ views, PanoDesc P,
                                                    const uint8_t *__restrict__ g0, long long g0_stride,
                                                    const int16_t *__restrict__ gl, long long gl_stride,
-                                                   int16_t *__restrict__ cl, long long cl_stride)
+                                                   int16_t *__restrict__ cl, long long cl_stride, ShardArgs S)
 {
     const int l = P.nb, f = blockIdx.z;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= P.qw[l] || y >= P.qh[l]) return;
     int16_t acc[3] = {0, 0, 0};
-    for (int v = 0; v < P.n_views; ++v) {
+    const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y * P.qpitch[l] + x;
+    if (S.mode == 2) {
+        for (int s = 0; s < S.n_parts; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = (int16_t)(acc[c] + S.part[s][po + c * pplane]);
+    }
+    for (int v = 0; v < P.n_views && S.mode != 2; ++v) {
+        if (!((S.own_mask >> v) & 1u)) continue;
         const LevelDesc &L = views[v].lv[l];
         const int lx = x - L.x_tl, ly = y - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
@@ -287,6 +294,11 @@ __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ 
                                    : (int)gl[(size_t)f * gl_stride + L.off + c * plane + o];
             acc[c] = (int16_t)(acc[c] + trunc_s16((float)g * w));
         }
+    }
+    if (S.mode == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S.pout[po + c * pplane] = acc[c];
+        return;
     }
     const float den = P.den[l][(size_t)y * P.dpitch[l] + x];
     const size_t plane = (size_t)P.qh[l] * P.qpitch[l];
@@ -304,7 +316,7 @@ template <bool L0>
 __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                const uint8_t *__restrict__ g0, long long g0_stride,
                                                const int16_t *__restrict__ gl, long long gl_stride,
-                                               int16_t *__restrict__ cl, long long cl_stride, OutTable out)
+                                               int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
 {
     const int f = blockIdx.z;
     const int qx = blockIdx.x * 64 + threadIdx.x, qy = blockIdx.y * 4 + threadIdx.y;
@@ -313,8 +325,18 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
     int16_t acc[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
+    const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y0 * P.qpitch[l] + x0;
+    const int pq[4] = {0, 1, P.qpitch[l], P.qpitch[l] + 1};
+    if (S.mode == 2) {
+        for (int s = 0; s < S.n_parts; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[c][k] = (int16_t)(acc[c][k] + S.part[s][po + c * pplane + pq[k]]);
+    }
 
-    for (int v = 0; v < P.n_views; ++v) {
+    for (int v = 0; v < P.n_views && S.mode != 2; ++v) {
+        if (!((S.own_mask >> v) & 1u)) continue;
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;   // rects are even-aligned below level nb
@@ -343,6 +365,13 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
         }
     }
 
+    if (S.mode == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) S.pout[po + c * pplane + pq[k]] = acc[c][k];
+        return;
+    }
     const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
     const float den[4] = {dp[0], dp[1], dp[P.dpitch[l]], dp[P.dpitch[l] + 1]};
     const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
@@ -451,7 +480,7 @@ template <bool L0>
 __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
                                                 const int16_t *__restrict__ gl, long long gl_stride,
-                                                int16_t *__restrict__ cl, long long cl_stride, OutTable out)
+                                                int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
 {
     const BlendTile T = tiles[blockIdx.x];
     const int f = blockIdx.z;
@@ -463,7 +492,20 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[c][0][k] = acc[c][1][k] = 0;
 
-    for (unsigned vm = T.view_mask; vm; vm &= vm - 1) {      // only the views with a non-zero weight in this tile
+    const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y0 * P.qpitch[l] + x0;
+    if (S.mode == 2) {
+        for (int s = 0; s < S.n_parts; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    int pv[8];
+                    unpack8(*reinterpret_cast<const uint4 *>(S.part[s] + po + c * pplane + (size_t)r * P.qpitch[l]), pv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[c][r][k] += pv[k];
+                }
+    }
+    for (unsigned vm = (S.mode == 2) ? 0u : (T.view_mask & S.own_mask); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
         const int v = __builtin_ctz(vm);
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
@@ -515,6 +557,20 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         }
     }
 
+    if (S.mode == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                uint4 o;
+                o.x = (unsigned)(uint16_t)acc[c][r][0] | ((unsigned)(uint16_t)acc[c][r][1] << 16);
+                o.y = (unsigned)(uint16_t)acc[c][r][2] | ((unsigned)(uint16_t)acc[c][r][3] << 16);
+                o.z = (unsigned)(uint16_t)acc[c][r][4] | ((unsigned)(uint16_t)acc[c][r][5] << 16);
+                o.w = (unsigned)(uint16_t)acc[c][r][6] | ((unsigned)(uint16_t)acc[c][r][7] << 16);
+                *reinterpret_cast<uint4 *>(S.pout + po + c * pplane + (size_t)r * P.qpitch[l]) = o;
+            }
+        return;
+    }
     const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
     const float4 da = *reinterpret_cast<const float4 *>(dp), db = *reinterpret_cast<const float4 *>(dp + 4);
     const float4 dc = *reinterpret_cast<const float4 *>(dp + P.dpitch[l]), dd = *reinterpret_cast<const float4 *>(dp + P.dpitch[l] + 4);
@@ -769,6 +825,9 @@ struct ms_ctx {
     hipEvent_t last_stitch = nullptr;
     bool stitch_pending = false;
     int canvas_x = 0, canvas_y = 0;
+    // view sharding (ms_config.reserved[3] = shard count S, [4] = this shard's index): contiguous blocks of views per shard
+    unsigned own_mask = 0xffffffffu;
+    long long pacc_stride = 0;         // elements per frame of a partial-accumulator buffer
 };
 
 namespace ms {
@@ -906,6 +965,7 @@ static int build_plan(ms_ctx *c)
     {
         std::vector<WarpTile> tiles;
         for (int v = 0; v < N; ++v) {
+            if (!((c->own_mask >> v) & 1u)) continue;     // view sharding: another rank warps this view
             const ViewDesc &V = c->h_views[v];
             for (int y0 = 0; y0 < V.ph; y0 += WARP_TH)
                 for (int x0 = 0; x0 < V.pw; x0 += WARP_TW)
@@ -935,6 +995,7 @@ static int build_plan(ms_ctx *c)
     if (c->cfg.enable_cpw) {   // CPW stage 1 covers the whole warped view: the mesh (hence what stage 2 samples) changes at recalibration
         std::vector<WarpTile> tiles;
         for (int v = 0; v < N; ++v)
+            if ((c->own_mask >> v) & 1u)
             for (int y0 = 0; y0 < c->h_views[v].ah; y0 += WARP_TH)
                 for (int x0 = 0; x0 < c->h_views[v].aw; x0 += WARP_TW) { WarpTile t{}; t.view = (short)v; t.x0 = (short)x0; t.y0 = (short)y0; tiles.push_back(t); }
         c->n_stage1_tiles = (int)tiles.size();
@@ -946,6 +1007,7 @@ static int build_plan(ms_ctx *c)
         std::vector<DownTile> tiles;
         if (c->down_vec[l])
             for (int v = 0; v < N; ++v) {
+                if (!((c->own_mask >> v) & 1u)) continue;
                 const LevelDesc &Lo = c->h_views[v].lv[l + 1];
                 for (int y0 = 0; y0 < Lo.h; y0 += DOWN_TH)
                     for (int x0 = 0; x0 < Lo.w; x0 += DOWN_TW)
@@ -998,6 +1060,12 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     c->cfg.max_frames = F;
     c->N = cfg->num_views;
     for (int i = 0; i < MAX_VIEWS; ++i) c->gain[i] = 1.0;
+    {
+        const int S = cfg->reserved[3] > 1 ? cfg->reserved[3] : 1, idx = cfg->reserved[4];
+        if (S > 4 || idx < 0 || idx >= S || S > c->N) { delete c; return fail(MS_ERR_INVALID, "ms_create: bad view-shard setting %d/%d", idx, S); }
+        c->own_mask = 0;
+        for (int v = idx * c->N / S; v < (idx + 1) * c->N / S; ++v) c->own_mask |= 1u << v;
+    }
     if (hipEventCreateWithFlags(&c->last_stitch, hipEventDisableTiming) != hipSuccess) { delete c; return fail(MS_ERR_HIP, "hipEventCreate failed"); }
     *out = c;
     return MS_OK;
@@ -1314,7 +1382,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     P = PanoDesc{};
     P.nb = nb; P.n_views = N;
     size_t den_total = 0;
-    long long cl_total = 0;
+    long long cl_total = 0, pacc_total = 0;
     {
         int w = c->bg.dst_roi.width, h = c->bg.dst_roi.height;
         for (int l = 0; l <= nb; ++l) {
@@ -1322,6 +1390,8 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             c->den_off[l] = den_total; den_total += (size_t)h * P.dpitch[l];
             P.coff[l] = cl_total;
             if (l >= 1) cl_total += 3LL * h * P.qpitch[l];
+            P.poff[l] = pacc_total;
+            pacc_total += 3LL * h * P.qpitch[l];
             w = (w + 1) / 2; h = (h + 1) / 2;
         }
     }
@@ -1374,6 +1444,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     c->g0_stride = (g0_total + 255) / 256 * 256;
     c->gl_stride = (gl_total + 127) / 128 * 128;
     c->cl_stride = (cl_total + 127) / 128 * 128;
+    c->pacc_stride = (pacc_total + 127) / 128 * 128;
     c->stage_stride = (stage_total + 255) / 256 * 256;
     if (int e = c->g0.alloc((size_t)c->g0_stride * F + 64)) return e;
     if (int e = c->gl.alloc((size_t)c->gl_stride * F * sizeof(int16_t) + 64)) return e;
@@ -1468,21 +1539,33 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
 
 // ---- the per-frame path --------------------------------------------------------------------------
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
-                       int cap, const char **names, float *ms_out, int *n_rec)
+                       int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{})
 {
     if (!c) return fail(MS_ERR_INVALID, "null context");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_stitch: call ms_build_maps / masks / ms_init_blender first");
     MS_CHECK(n_frames >= 1 && n_frames <= c->cfg.max_frames, "ms_stitch: n_frames %d not in [1,%d]", n_frames, c->cfg.max_frames);
-    MS_CHECK(views != nullptr, "ms_stitch: null views");
     const int N = c->N, nb = c->pano.nb, F = n_frames;
+    const bool sharded = c->own_mask != ((N >= 32) ? 0xffffffffu : ((1u << N) - 1u));
+    if (S.mode == 0 && sharded) return fail(MS_ERR_STATE, "ms_stitch: this context owns a view shard; use ms_stitch_partial / ms_stitch_finish");
+    S.own_mask = c->own_mask;
+    S.pstride = c->pacc_stride;
+    MS_CHECK(S.mode == 2 || views != nullptr, "ms_stitch: null views");
     const PanoDesc &P = c->pano;
     SrcTable src{};
-    for (int i = 0; i < F * N; ++i) {
+    for (int i = 0; i < F * N && S.mode != 2; ++i) {
+        if (!((c->own_mask >> (i % N)) & 1u)) continue;       // another shard's view: not read
         MS_CHECK(views[i].data && views[i].type == MS_8UC3 && views[i].rows == c->cfg.src_height && views[i].cols == c->cfg.src_width,
                  "ms_stitch: view %d must be 8UC3 %dx%d", i, c->cfg.src_width, c->cfg.src_height);
         src.p[i] = (const uint8_t *)views[i].data;
         src.step[i] = (unsigned)views[i].step;
     }
+    if (sharded && S.mode == 1)      // the full-grid fallback kernels touch every view slot: give the unowned ones a valid (ignored) source
+        for (int f = 0; f < F; ++f) {
+            int owned = 0;
+            while (!((c->own_mask >> owned) & 1u)) ++owned;
+            for (int v = 0; v < N; ++v)
+                if (!((c->own_mask >> v) & 1u)) { src.p[f * N + v] = src.p[f * N + owned]; src.step[f * N + v] = src.step[f * N + owned]; }
+        }
     OutTable out{};
     for (int f = 0; f < F; ++f) {
         if (out8u && out8u[f].data) {
@@ -1525,6 +1608,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     };
     if (int e = mark(nullptr)) return e;
 
+    static const char *down_names[MAX_LEVELS] = {"k_down_l0", "k_down_l1", "k_down_l2", "k_down_l3", "k_down_l4", "k_down_l5", "k_down_l6", "k_down_l7"};
+    static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
+    if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
         if (c->cfg.reserved[0] == 0)
             k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(16, 16), 0, st>>>(
@@ -1552,8 +1638,6 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     MS_LAUNCH_CHECK();
     if (int e = mark("k_warp")) return e;
 
-    static const char *down_names[MAX_LEVELS] = {"k_down_l0", "k_down_l1", "k_down_l2", "k_down_l3", "k_down_l4", "k_down_l5", "k_down_l6", "k_down_l7"};
-    static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
     for (int l = 0; l < nb; ++l) {
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
         if (c->down_vec[l] && c->cfg.reserved[0] == 0) {   // level-l widths are multiples of 8: tile list, 2 rows x 4 cols per lane
@@ -1568,23 +1652,24 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark(down_names[l])) return e;
     }
+    }   // S.mode != 2
     if (nb == 0) {
         // single band: out = mask ? trunc(sum/den) : 0 -- handled by the top kernel writing level 0 is not
         // representable in the collapsed buffer; the path requires num_bands >= 1.
         return fail(MS_ERR_UNSUPPORTED, "ms_stitch: num_bands resolved to 0 (pano smaller than 2 px?)");
     }
-    k_blend_top<<<dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, 0, st>>>(vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride);
+    k_blend_top<<<dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, 0, st>>>(vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, S);
     MS_LAUNCH_CHECK();
     if (int e = mark(blend_names[nb])) return e;
     for (int l = nb - 1; l >= 0; --l) {
         if (c->blend_vec[l] && c->cfg.reserved[0] == 0) {
             const dim3 g(c->n_blend_tiles[l], 1, F), b(32, 8);
-            if (l == 0) k_blend8<true><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
-            else        k_blend8<false><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+            if (l == 0) k_blend8<true><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            else        k_blend8<false><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         } else {
             const dim3 g(div_up(P.qw[l] / 2, 64), div_up(P.qh[l] / 2, 4), F);
-            if (l == 0) k_blend<true><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
-            else        k_blend<false><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out);
+            if (l == 0) k_blend<true><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            else        k_blend<false><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         }
         MS_LAUNCH_CHECK();
         if (int e = mark(blend_names[l])) return e;
@@ -1617,6 +1702,34 @@ int ms_stitch_timed(ms_ctx *c, int n_frames, const ms_image *views, ms_image *ou
     int n = 0;
     const int e = stitch_impl(c, n_frames, views, out8u, out16s, as_stream(stream), cap, names, ms_out, &n);
     return e ? e : n;
+}
+
+// ---- view sharding: partial sums on every rank, finish on the sink (BASELINE configs[4]) -------------
+size_t ms_partial_bytes(const ms_ctx *c)
+{
+    return (c && c->blender_ready) ? (size_t)c->pacc_stride * sizeof(int16_t) : 0;
+}
+
+int ms_stitch_partial(ms_ctx *c, int n_frames, const ms_image *views, void *partial_out, ms_stream stream)
+{
+    MS_CHECK(c && partial_out && ((uintptr_t)partial_out & 15) == 0, "ms_stitch_partial: 16-byte aligned output buffer required");
+    ShardArgs S{};
+    S.mode = 1;
+    S.pout = (int16_t *)partial_out;
+    return stitch_impl(c, n_frames, views, nullptr, nullptr, as_stream(stream), 0, nullptr, nullptr, nullptr, S);
+}
+
+int ms_stitch_finish(ms_ctx *c, int n_frames, const void *const *partials, int n_partials, ms_image *out8u, ms_image *out16s, ms_stream stream)
+{
+    MS_CHECK(c && partials && n_partials >= 1 && n_partials <= 4, "ms_stitch_finish: 1..4 partial buffers required");
+    ShardArgs S{};
+    S.mode = 2;
+    S.n_parts = n_partials;
+    for (int i = 0; i < n_partials; ++i) {
+        MS_CHECK(partials[i] && ((uintptr_t)partials[i] & 15) == 0, "ms_stitch_finish: partial %d must be a 16-byte aligned device buffer", i);
+        S.part[i] = (const int16_t *)partials[i];
+    }
+    return stitch_impl(c, n_frames, nullptr, out8u, out16s, as_stream(stream), 0, nullptr, nullptr, nullptr, S);
 }
 
 // ---- read-back -----------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct PanoDesc {
     int nb, n_views;
     int qw[MAX_LEVELS], qh[MAX_LEVELS], qpitch[MAX_LEVELS];
     long long coff[MAX_LEVELS];   // element offset of collapsed level l (l >= 1) in the per-frame buffer
+    long long poff[MAX_LEVELS];   // element offset of level l (l >= 0) in a per-frame PARTIAL accumulator buffer (view sharding)
     const float *den[MAX_LEVELS]; // sum_v w_v + 1e-5f (static)
     int dpitch[MAX_LEVELS];
     float alpha;                  // (float)(1./255.): level-0 weight = fmaf(alpha, mask, 0)
@@ -43,6 +44,17 @@ struct PanoDesc {
     int mask_pitch;
     int fw, fh;                   // dst_roi_final size
     int canvas_x, canvas_y, out_w, out_h;
+};
+// View sharding (BASELINE configs[4]): the weighted accumulation over views is a sum of int16 terms, so a
+// rank that owns a subset of the views writes its partial sums (mode 1) and the sink adds the partials of all ranks
+// (wrap-around int16, order independent => bit-identical to the single-GPU result), then normalises and collapses (mode 2).
+struct ShardArgs {
+    int mode;                     // 0 = whole frame on this GPU, 1 = write partial sums of the owned views, 2 = finish from partials
+    unsigned own_mask;            // views this rank accumulates (modes 0/1)
+    int n_parts;                  // mode 2: number of partial buffers
+    const int16_t *part[4];
+    int16_t *pout;                // mode 1: where the partial sums go
+    long long pstride;            // elements per frame in a partial buffer
 };
 struct SrcTable { const uint8_t *p[MAX_SRC]; unsigned step[MAX_SRC]; };
 struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pitch[MAX_VIEWS]; };

@@ -60,7 +60,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr",
+    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish",
 ]
 
 _lib = None
@@ -315,11 +315,12 @@ class Compositor:
     """stitch_calib tables once (build_maps / build_masks / init_blender), then stitch() per frame batch."""
 
     def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
-                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=False):
+                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=False, shards=1, shard_index=0):
         cfg = Config(num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
                      out_size[0], out_size[1], max_frames)
         cfg.reserved[0] = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
         cfg.reserved[1] = 1 if lds_stage else 0        # opt-in: stage the warp kernel's source tiles through LDS
+        cfg.reserved[3] = shards; cfg.reserved[4] = shard_index   # view sharding
         self._ctx = C.c_void_p()
         _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
         self.cfg = cfg
@@ -438,6 +439,28 @@ class Compositor:
             _chk(fn(ctx, n, views, o8, o16, stream if stream is not None else _stream()))
         run.keepalive = (frames, out8u, out16s, views, o8, o16)
         return run
+
+    def partial_bytes(self):
+        load().ms_partial_bytes.restype = C.c_size_t
+        return load().ms_partial_bytes(self._ctx)
+
+    def stitch_partial(self, frames, partial):
+        """frames: per frame a list of N tensors (None for views this shard does not own); partial: int16 cuda tensor."""
+        n_frames = len(frames)
+        views = (Image * (n_frames * self.n))()
+        k = 0
+        for fr in frames:
+            for t in fr:
+                if t is not None:
+                    views[k] = img(t)
+                k += 1
+        _chk(load().ms_stitch_partial(self._ctx, n_frames, views, C.c_void_p(partial.data_ptr()), _stream()))
+
+    def stitch_finish(self, n_frames, partials, out8u=None, out16s=None):
+        ptrs = (C.c_void_p * len(partials))(*[p.data_ptr() for p in partials])
+        o8 = (Image * n_frames)(*[img(t) for t in out8u]) if out8u is not None else None
+        o16 = (Image * n_frames)(*[img(t) for t in out16s]) if out16s is not None else None
+        _chk(load().ms_stitch_finish(self._ctx, n_frames, ptrs, len(partials), o8, o16, _stream()))
 
     def stitch_timed(self, frames, out8u=None, out16s=None):
         n, views, o8, o16 = self._tables(frames, out8u, out16s)
