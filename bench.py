@@ -103,6 +103,119 @@ def cpu_baseline(cfg, gains, comp, budget_s=12.0):
                       "(best of 1/8/16/32/64 on a %d-CPU host); 1 thread: %.0f ms/frame" % (n, el, cores, ncpu, one_thread * 1e3)}
 
 
+def run_view_shards(args, cfg, gains, rank, world, dev, share):
+    """SURVEY 8(e) view sharding: ranks form groups of V; rank k of a group owns views [k*N/V, (k+1)*N/V), builds the partial dst
+    Laplacian pyramid of its views for F frames (ms_stitch_partial) and sends it to the group's first rank, which adds the partials,
+    normalises, collapses and writes the canvases (ms_stitch_finish).  Groups are frame-parallel.  int16 has no RCCL reduction:
+    point-to-point send/recv + the add inside the finish kernels."""
+    import torch.distributed as dist
+    import msstitch as ms
+    import synth
+    V, F, N = args.view_shards, args.frames, cfg["n"]
+    assert world == 1 or world % V == 0, "--view-shards must divide the number of ranks"
+    local = world == 1                    # both shards on this GPU, no transfer: measures the compute cost of the split
+    group, k_own = (0, None) if local else (rank // V, rank % V)
+    sink = group * V
+
+    def make(shards, idx):
+        c = ms.Compositor(N, (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), num_bands=cfg["num_bands"],
+                          out_size=(cfg["out_w"], cfg["out_h"]), max_frames=F, shards=shards, shard_index=idx)
+        for i in range(N):
+            K, R = synth.camera(N, cfg["w"], cfg["h"], cfg["hfov_deg"], i)
+            c.set_camera(i, K, R); c.set_gain(i, gains[i])
+        c.build_maps(); c.build_masks(1); c.init_blender()
+        return c
+    mine = list(range(V)) if local else [k_own]
+    comps = {k: make(V, k) for k in mine}
+    pool = [[torch.from_numpy(synth.frame(cfg["w"], cfg["h"], i, t)).to(dev) if any(k * N // V <= i < (k + 1) * N // V for k in mine) else None
+             for i in range(N)] for t in range(4)]
+    frames = [pool[(group + j) % 4] for j in range(F)]
+    c0 = comps[mine[0]]
+    pel = F * c0.partial_bytes() // 2
+    parts = {k: [torch.zeros(pel, dtype=torch.int16, device=dev) for _ in range(2)] for k in mine}
+    is_sink = local or rank == sink
+    if is_sink and not local:
+        for k in range(1, V):
+            parts[k] = [torch.zeros(pel, dtype=torch.int16, device=dev) for _ in range(2)]
+    outs = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(F)] if is_sink else None
+    pending = [[], []]
+
+    def xfer(t, peer, send):
+        if share:      # gloo debug mode: stage through host memory
+            if send:
+                torch.cuda.synchronize(); dist.send(t.cpu(), peer)
+            else:
+                h = torch.empty(t.shape, dtype=t.dtype); dist.recv(h, peer); t.copy_(h)
+            return None
+        return dist.isend(t, peer) if send else dist.irecv(t, peer)
+
+    def step(s):
+        b = s & 1
+        for w in pending[b]:
+            w.wait()
+        pending[b] = []
+        for k in mine:
+            comps[k].stitch_partial(frames, parts[k][b])
+        if not local:
+            if is_sink:
+                ws = [xfer(parts[k][b], sink + k, False) for k in range(1, V)]
+                for w in ws:
+                    if w is not None:
+                        w.wait()
+            else:
+                w = xfer(parts[k_own][b], sink, True)
+                if w is not None:
+                    pending[b].append(w)
+        if is_sink:
+            c0.stitch_finish(F, [parts[k][b] for k in range(V)], out8u=outs)
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(s)
+    for b in range(2):
+        for w in pending[b]:
+            w.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok = None
+    if local:        # same frames through an unsharded context: the split must not change a single byte
+        full = make(1, 0)
+        want = [torch.zeros_like(o) for o in outs]
+        full.stitch(frames, out8u=want)
+        torch.cuda.synchronize()
+        ok = all(torch.equal(a, b) for a, b in zip(outs, want))
+    if rank == 0:
+        groups = 1 if local else world // V
+        total = groups * F * args.steps
+        print(json.dumps({
+            "metric": "stitched frames/sec, view-sharded (%s)" % args.config, "value": round(total / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / int16+fp32 pyramid arithmetic",
+            "data": "synthetic",
+            "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, %d bands; views split over %d shards%s, %d frames per step per group, "
+                                   "%d frame-parallel group(s); partial = %.1f MB/frame/shard"
+                                   % (args.config, N, cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"], cfg["num_bands"], V,
+                                      " on ONE GPU (no transfer)" if local else (" [DEBUG gloo, shared GPU]" if share else " (RCCL send/recv to the sink)"),
+                                      F, groups, c0.partial_bytes() / 1e6)},
+            "equals_unsharded": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +229,9 @@ def main():
                     help="what the sink rank receives: planar I420 of the pano rows (the encoder input of consume(), timed.cpp:308-316; "
                          "half the bytes) or the 8UC3 rows themselves")
     ap.add_argument("--calib", action="store_true", help="also run 3 known-size streaming copies (PMC calibration, tools/profile_traffic.sh)")
+    ap.add_argument("--view-shards", type=int, default=1,
+                    help="BASELINE configs[4]: split the VIEWS of every frame over this many ranks (partial int16 accumulators sent to the "
+                         "group's sink rank, which finishes the frame); world must be a multiple of it (world 1 = both shards on one GPU)")
     ap.add_argument("--streams", type=int, default=1, help="split the F frames of a step over this many contexts/HIP streams")
     args = ap.parse_args()
 
@@ -166,6 +282,8 @@ def main():
                 r = c.view_geom(i).roi
                 c.set_mesh(i, *synth.mesh(r.width, r.height, 40, 40, phase=0.1 * i))
         return c
+    if args.view_shards > 1:
+        return run_view_shards(args, cfg, gains, rank, world, dev, share)
     comps = [make_comp(F // S) for _ in range(S)]     # one context (own per-frame buffers) per HIP stream
     comp = comps[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
