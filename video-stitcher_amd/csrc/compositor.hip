@@ -266,6 +266,7 @@ __device__ __forceinline__ void up_quad(const int16_t *__restrict__ cs, int cpit
 }
 
 // coarsest band: C_nb = trunc( sum_v trunc(G_{v,nb} * w_{v,nb}) / den_nb )   (L_nb = G_nb)
+template <int MODE>      // 0 = whole frame, 1 = partial sums of the owned views, 2 = finish from partial sums (view sharding)
 __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ views, PanoDesc P,
                                                    const uint8_t *__restrict__ g0, long long g0_stride,
                                                    const int16_t *__restrict__ gl, long long gl_stride,
@@ -276,13 +277,13 @@ __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ 
     if (x >= P.qw[l] || y >= P.qh[l]) return;
     int16_t acc[3] = {0, 0, 0};
     const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y * P.qpitch[l] + x;
-    if (S.mode == 2) {
+    if (MODE == 2) {
         for (int s = 0; s < S.n_parts; ++s)
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = (int16_t)(acc[c] + S.part[s][po + c * pplane]);
     }
-    for (int v = 0; v < P.n_views && S.mode != 2; ++v) {
-        if (!((S.own_mask >> v) & 1u)) continue;
+    for (int v = 0; v < P.n_views && MODE != 2; ++v) {
+        if (MODE == 1 && !((S.own_mask >> v) & 1u)) continue;
         const LevelDesc &L = views[v].lv[l];
         const int lx = x - L.x_tl, ly = y - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ 
             acc[c] = (int16_t)(acc[c] + trunc_s16((float)g * w));
         }
     }
-    if (S.mode == 1) {
+    if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) S.pout[po + c * pplane] = acc[c];
         return;
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ 
 //   N_l = trunc( sum_v trunc( sat(G_{v,l} - up(G_{v,l+1})) * w_{v,l} ) / den_l ),  C_l = sat(up(C_{l+1}) + N_l)
 // L0 (l == 0): fine level is the u8 level-0 buffer and the result goes to the outputs
 //   (mask = gpu_dst_mask_, setTo(0, !mask), convertTo 16S out, convertTo 8U canvas).
-template <bool L0>
+template <bool L0, int MODE>
 __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                const uint8_t *__restrict__ g0, long long g0_stride,
                                                const int16_t *__restrict__ gl, long long gl_stride,
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
     for (int c = 0; c < 3; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
     const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y0 * P.qpitch[l] + x0;
     const int pq[4] = {0, 1, P.qpitch[l], P.qpitch[l] + 1};
-    if (S.mode == 2) {
+    if (MODE == 2) {
         for (int s = 0; s < S.n_parts; ++s)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -335,8 +336,8 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
                 for (int k = 0; k < 4; ++k) acc[c][k] = (int16_t)(acc[c][k] + S.part[s][po + c * pplane + pq[k]]);
     }
 
-    for (int v = 0; v < P.n_views && S.mode != 2; ++v) {
-        if (!((S.own_mask >> v) & 1u)) continue;
+    for (int v = 0; v < P.n_views && MODE != 2; ++v) {
+        if (MODE == 1 && !((S.own_mask >> v) & 1u)) continue;
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;   // rects are even-aligned below level nb
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
         }
     }
 
-    if (S.mode == 1) {
+    if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -476,7 +477,7 @@ __device__ __forceinline__ void up_2x8(const int16_t *__restrict__ cs, int cpitc
     }
 }
 
-template <bool L0>
+template <bool L0, int MODE>
 __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
                                                 const int16_t *__restrict__ gl, long long gl_stride,
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         for (int k = 0; k < 8; ++k) acc[c][0][k] = acc[c][1][k] = 0;
 
     const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y0 * P.qpitch[l] + x0;
-    if (S.mode == 2) {
+    if (MODE == 2) {
         for (int s = 0; s < S.n_parts; ++s)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
                     for (int k = 0; k < 8; ++k) acc[c][r][k] += pv[k];
                 }
     }
-    for (unsigned vm = (S.mode == 2) ? 0u : (T.view_mask & S.own_mask); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
+    for (unsigned vm = (MODE == 2) ? 0u : (MODE == 1 ? (T.view_mask & S.own_mask) : T.view_mask); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
         const int v = __builtin_ctz(vm);
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         }
     }
 
-    if (S.mode == 1) {
+    if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1658,18 +1659,30 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         // representable in the collapsed buffer; the path requires num_bands >= 1.
         return fail(MS_ERR_UNSUPPORTED, "ms_stitch: num_bands resolved to 0 (pano smaller than 2 px?)");
     }
-    k_blend_top<<<dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, 0, st>>>(vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, S);
+#define MS_MODE_LAUNCH(K, G, B, ...)                                     \
+    do {                                                                \
+        if (S.mode == 0) K<0><<<G, B, 0, st>>>(__VA_ARGS__);            \
+        else if (S.mode == 1) K<1><<<G, B, 0, st>>>(__VA_ARGS__);       \
+        else K<2><<<G, B, 0, st>>>(__VA_ARGS__);                        \
+    } while (0)
+#define MS_MODE_LAUNCH2(K, L0, G, B, ...)                               \
+    do {                                                                \
+        if (S.mode == 0) K<L0, 0><<<G, B, 0, st>>>(__VA_ARGS__);        \
+        else if (S.mode == 1) K<L0, 1><<<G, B, 0, st>>>(__VA_ARGS__);   \
+        else K<L0, 2><<<G, B, 0, st>>>(__VA_ARGS__);                    \
+    } while (0)
+    MS_MODE_LAUNCH(k_blend_top, dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, S);
     MS_LAUNCH_CHECK();
     if (int e = mark(blend_names[nb])) return e;
     for (int l = nb - 1; l >= 0; --l) {
         if (c->blend_vec[l] && c->cfg.reserved[0] == 0) {
             const dim3 g(c->n_blend_tiles[l], 1, F), b(32, 8);
-            if (l == 0) k_blend8<true><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
-            else        k_blend8<false><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            else        MS_MODE_LAUNCH2(k_blend8, false, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         } else {
             const dim3 g(div_up(P.qw[l] / 2, 64), div_up(P.qh[l] / 2, 4), F);
-            if (l == 0) k_blend<true><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
-            else        k_blend<false><<<g, blk, 0, st>>>(vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            if (l == 0) MS_MODE_LAUNCH2(k_blend, true, g, blk, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            else        MS_MODE_LAUNCH2(k_blend, false, g, blk, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         }
         MS_LAUNCH_CHECK();
         if (int e = mark(blend_names[l])) return e;
