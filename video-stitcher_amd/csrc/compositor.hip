@@ -477,6 +477,48 @@ __device__ __forceinline__ void up_2x8(const int16_t *__restrict__ cs, int cpitc
     }
 }
 
+// ---- packed 16-bit forms for the VIEW side of a band -------------------------------------------------------------
+// Every Gaussian level of a view is a convex combination of 8-bit pixels, rounded: all values are in [0,255] (the
+// per-frame pyramid buffers are zero-filled at creation and only ever hold such values, so stale tiles are in range
+// too).  pyrUp's partial sums are then < 64*255 + 32 < 2^15: two of them live in the 16-bit halves of one register
+// and plain 32-bit adds/shifts never carry from one half into the other.  Results are identical to up_2x8.
+__device__ __forceinline__ unsigned rne6_pk(unsigned s)
+{
+    const unsigned t = (s >> 6) & 0x00010001u;
+    return ((s + t + 0x001f001fu) >> 6) & 0x03ff03ffu;
+}
+// pixel order of the four output registers of a row: (0,2) (1,3) (4,6) (5,7)  [low half, high half]
+__device__ __forceinline__ void up_2x8_pk(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
+                                          unsigned ue[4], unsigned uo[4])
+{
+    const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
+    const int jb = max(j0 - 2, 0);
+    uint4 raw[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
+    unsigned he[3][2], ho[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        unsigned w0 = raw[r].x, w1 = raw[r].y, w2 = raw[r].z, w3 = raw[r].w;
+        if (j0 == 0) { w3 = w2; w2 = w1; w1 = w0; }      // window starts at column 0: tap -1 mirrors to column 1 = hi(w0)
+        if (j0 + 4 >= cw) w3 = w2 >> 16;                 // tap j0+4 clamps to cw-1
+        // taps t0 = hi(w0), (t1,t2) = w1, (t3,t4) = w2, t5 = lo(w3)
+        const unsigned t01 = __builtin_amdgcn_alignbyte(w1, w0, 2), t23 = __builtin_amdgcn_alignbyte(w2, w1, 2),
+                       t45 = __builtin_amdgcn_alignbyte(w3, w2, 2);
+        he[r][0] = t01 + 6u * w1 + t23;                  // (he0, he1), he_q = t_q + 6 t_{q+1} + t_{q+2}
+        he[r][1] = t23 + 6u * w2 + t45;                  // (he2, he3)
+        ho[r][0] = 4u * (w1 + t23);                      // (ho0, ho1), ho_q = 4 (t_{q+1} + t_{q+2})
+        ho[r][1] = 4u * (w2 + t45);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ue[2 * q] = rne6_pk(he[0][q] + 6u * he[1][q] + he[2][q]);
+        ue[2 * q + 1] = rne6_pk(ho[0][q] + 6u * ho[1][q] + ho[2][q]);
+        uo[2 * q] = rne6_pk(4u * (he[1][q] + he[2][q]));
+        uo[2 * q + 1] = rne6_pk(4u * (ho[1][q] + ho[2][q]));
+    }
+}
+
 template <bool L0, int MODE>
 __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
@@ -536,25 +578,44 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         const LevelDesc &C = views[v].lv[l + 1];
         const size_t fplane = (size_t)L.h * L.pitch, cplane = (size_t)C.h * C.pitch;
         const size_t fo = (size_t)ly * L.pitch + lx;
+        float nw[2][8];                       // -256 w (exact): fma(256 + L, w, -256 w) rounds the exact product L*w once
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) nw[r][k] = -256.f * w[r][k];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            int up[2][8];
-            up_2x8(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up[0], up[1]);
-            int g[2][8];
+            unsigned up[2][4];
+            up_2x8_pk(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up[0], up[1]);
+            unsigned g[2][4];                 // same pixel order as up: (0,2) (1,3) (4,6) (5,7)
             if (L0) {
                 const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + c * fplane + fo;
-                unpack8(*reinterpret_cast<const uint2 *>(p), g[0]);
-                unpack8(*reinterpret_cast<const uint2 *>(p + L.pitch), g[1]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint2 b = *reinterpret_cast<const uint2 *>(p + (size_t)r * L.pitch);
+                    g[r][0] = b.x & 0x00ff00ffu; g[r][1] = (b.x >> 8) & 0x00ff00ffu;
+                    g[r][2] = b.y & 0x00ff00ffu; g[r][3] = (b.y >> 8) & 0x00ff00ffu;
+                }
             } else {
                 const int16_t *p = gl + (size_t)f * gl_stride + L.off + c * fplane + fo;
-                unpack8(*reinterpret_cast<const uint4 *>(p), g[0]);
-                unpack8(*reinterpret_cast<const uint4 *>(p + L.pitch), g[1]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint4 b = *reinterpret_cast<const uint4 *>(p + (size_t)r * L.pitch);
+                    g[r][0] = __builtin_amdgcn_perm(b.y, b.x, 0x05040100u); g[r][1] = __builtin_amdgcn_perm(b.y, b.x, 0x07060302u);
+                    g[r][2] = __builtin_amdgcn_perm(b.w, b.z, 0x05040100u); g[r][3] = __builtin_amdgcn_perm(b.w, b.z, 0x07060302u);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    acc[c][r][k] += (int)trunc_s16((float)(int)sat_s16(g[r][k] - up[r][k]) * w[r][k]);
+                for (int q = 0; q < 4; ++q) {
+                    // Laplacian L = g - up in [-255,255], kept as 256 + L per half (no borrow between halves);
+                    // |L*w| <= 255: neither saturate_cast of the reference chain (sub_mat.cu:59-65, multiband_blend.cu:46-49) can trigger
+                    const unsigned d = (g[r][q] | 0x01000100u) - up[r][q];
+                    const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
+                    acc[c][r][k0] += (int)__builtin_fmaf((float)(d & 0xffffu), w[r][k0], nw[r][k0]);
+                    acc[c][r][k1] += (int)__builtin_fmaf((float)(d >> 16), w[r][k1], nw[r][k1]);
+                }
         }
     }
 
@@ -1450,6 +1511,9 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     if (int e = c->g0.alloc((size_t)c->g0_stride * F + 64)) return e;
     if (int e = c->gl.alloc((size_t)c->gl_stride * F * sizeof(int16_t) + 64)) return e;
     if (int e = c->cl.alloc((size_t)c->cl_stride * F * sizeof(int16_t) + 64)) return e;
+    // invariant the packed band arithmetic relies on: every value in the view pyramids is in [0,255], written or not
+    MS_HIP(hipMemsetAsync(c->g0.p, 0, (size_t)c->g0_stride * F + 64, st));
+    MS_HIP(hipMemsetAsync(c->gl.p, 0, (size_t)c->gl_stride * F * sizeof(int16_t) + 64, st));
     if (c->cfg.enable_cpw) {
         if (int e = c->stage.alloc((size_t)c->stage_stride * F)) return e;
         size_t mtotal = 0;
