@@ -289,6 +289,10 @@ MS_API int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream str
  * from the compiler's correctly rounded a / d (expected 0), or a negative ms_status. */
 MS_API int ms_selftest_divide(const float *denominators_host, int n, ms_stream stream);
 
+/* Self-test of the single-instruction saturate_cast<uchar>(float) (v_cvt_pk_u8_f32) used by the warp kernels: compares it with
+ * the rint / clamp / NaN->0 definition over ALL 2^32 float bit patterns on the device; *mismatches_out must come back 0. */
+MS_API int ms_selftest_cvt_u8(unsigned long long *mismatches_out, ms_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,12 @@ def test_argument_errors(ms, cuda):
         ms.custom_resize(f[:1], 8, 8)
 
 
+def test_one_instruction_saturate_cast_u8_is_exact(ms, cuda):
+    """sat_u8 is v_cvt_pk_u8_f32; its definition is rint (half-even) -> clamp [0,255] -> NaN to 0 (saturate_cast<uchar>(float),
+    saturate_cast.hpp:96-101).  Exhaustive over all 2^32 float bit patterns, plain and insert-into-byte forms."""
+    assert ms.selftest_cvt_u8() == 0
+
+
 def test_shared_reciprocal_division_is_ieee(ms, cuda):
     """The band kernels divide the 3 channels of a pixel by the same w + 1e-5 with one refined reciprocal (DivBy).
     Exhaustive over all int16 numerators x denominators spanning the weight-sum range (incl. 1e-5 itself, sums of

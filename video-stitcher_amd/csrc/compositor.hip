@@ -749,6 +749,19 @@ __global__ void __launch_bounds__(256) k_selftest_divide(const float *__restrict
     if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
 }
 
+// exhaustive check of the one-instruction saturate_cast<uchar>(float) against its definition: all 2^32 bit patterns
+__global__ void __launch_bounds__(256) k_selftest_cvt_u8(unsigned long long *mismatches)
+{
+    unsigned bad = 0;
+    const unsigned base = (blockIdx.x * 256u + threadIdx.x) << 8;        // 2^24 lanes x 256 patterns
+    for (unsigned i = 0; i < 256u; ++i) {
+        const float v = __uint_as_float(base | i);
+        bad += (unsigned)sat_u8(v) != (unsigned)sat_u8_ref(v);
+        bad += (sat_u8_into(v, 2u, 0x11223344u) != ((0x11003344u) | ((unsigned)sat_u8_ref(v) << 16)));
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // PMC calibration: a plain 16-byte-per-lane streaming copy of a known size, so that FETCH_SIZE / WRITE_SIZE of the
 // real kernels can be scaled by what the counters report for a known byte count (MI355X guide, HBM section)
 __global__ void __launch_bounds__(256) k_calib_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
@@ -1024,6 +1037,9 @@ static int build_plan(ms_ctx *c)
     // warp tiles (level 0)
     c->warp_tiled = true;
     for (int v = 0; v < N; ++v) c->warp_tiled = c->warp_tiled && (c->h_views[v].pw % 4 == 0);
+    // the tile kernels read tap rows as 8-byte pairs clamped into the image: needs >= 3 columns and >= 2 rows of source
+    c->warp_tiled = c->warp_tiled && c->cfg.src_width >= 3 && c->cfg.src_height >= 2;
+    for (int v = 0; v < N; ++v) c->warp_tiled = c->warp_tiled && c->h_views[v].aw >= 3 && c->h_views[v].ah >= 2;
     {
         std::vector<WarpTile> tiles;
         for (int v = 0; v < N; ++v) {
@@ -1882,6 +1898,22 @@ int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream stream)
     MS_CHECK(src && dst && bytes >= 16 && bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "ms_calib_copy: 16-byte aligned buffers and size required");
     k_calib_copy<<<2048, 256, 0, as_stream(stream)>>>((const uint4 *)src, (uint4 *)dst, bytes / 16);
     MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+int ms_selftest_cvt_u8(unsigned long long *mismatches_out, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(mismatches_out != nullptr, "ms_selftest_cvt_u8: null output");
+    hipStream_t st = as_stream(stream);
+    DevBuf cnt;
+    if (int e = cnt.alloc(sizeof(unsigned long long))) return e;
+    MS_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), st));
+    k_selftest_cvt_u8<<<65536, 256, 0, st>>>((unsigned long long *)cnt.p);
+    MS_LAUNCH_CHECK();
+    MS_HIP(hipMemcpyAsync(mismatches_out, cnt.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
+    cnt.release();
     return MS_OK;
 }
 

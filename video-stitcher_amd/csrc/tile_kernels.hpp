@@ -25,12 +25,15 @@ struct Taps {            // one bilinear sample: clamped tap origin, weights, fa
 __device__ __forceinline__ Taps make_taps(float xc, float yc, int srows, int scols)
 {
     Taps t;
-    t.x1 = f2i_rd(xc); t.y1 = f2i_rd(yc);
-    const int x2 = (int)((unsigned)t.x1 + 1u), y2 = (int)((unsigned)t.y1 + 1u);
-    const float wx2 = (float)x2 - xc, wx1 = xc - (float)t.x1;
-    const float wy2 = (float)y2 - yc, wy1 = yc - (float)t.y1;
+    const float fx1 = __builtin_floorf(xc), fy1 = __builtin_floorf(yc);
+    t.x1 = (int)fx1; t.y1 = (int)fy1;
+    // all 4 taps inside and the 8-byte row reads inside (one unsigned compare per axis)
+    t.fast = (unsigned)t.x1 < (unsigned)(scols - 2) && (unsigned)t.y1 < (unsigned)(srows - 1);
+    // (float)(x1 + 1) == floor(xc) + 1 and (float)x1 == floor(xc) exactly while |xc| < 2^24; beyond that every tap is outside
+    // the image, all four samples are 0 and any finite weight gives 0 (an infinite / NaN one gives NaN -> saturate_cast -> 0)
+    const float wx2 = (fx1 + 1.f) - xc, wx1 = xc - fx1;
+    const float wy2 = (fy1 + 1.f) - yc, wy1 = yc - fy1;
     t.w11 = wx2 * wy2; t.w12 = wx1 * wy2; t.w21 = wx2 * wy1; t.w22 = wx1 * wy1;
-    t.fast = t.x1 >= 0 && t.x1 < scols - 2 && t.y1 >= 0 && t.y1 < srows - 1;   // all 4 taps inside, 8-byte row reads inside
     return t;
 }
 // The two BGR pixels of a tap row (6 bytes) fetched as ONE unaligned 8-byte load: the TA/L1 cost of a wave-wide
@@ -43,20 +46,71 @@ __device__ __forceinline__ Px2 load_px2(const uint8_t *p)
     __builtin_memcpy(&v, p, 8);
     return Px2{v.x, v.y};
 }
+// uniform base + 32-bit lane offset: the address arithmetic stays in one VGPR (global_load ... v_off, s[base])
+__device__ __forceinline__ Px2 load_px2(const uint8_t *base, unsigned off) { return load_px2(base + off); }
+// Byte offset of the two tap rows of a sample, clamped so that both 8-byte reads stay inside the image: rows
+// (ya, ya+1) with ya = clamp(y1, 0, rows-2), bytes [bl, bl+8) with bl = clamp(3*x1, 0, 3*cols-8).  For an interior
+// sample (Taps::fast) this is exactly the tap address.
+__device__ __forceinline__ unsigned tap_offset(int x1, int y1, int srows, int scols, unsigned sstep)
+{
+    const int ya = min(max(y1, 0), srows - 2);
+    const int bl = min(3 * min(max(x1, 0), scols), 3 * scols - 8);
+    return (unsigned)ya * sstep + (unsigned)bl;
+}
+// Samples with a tap outside the image (BORDER_CONSTANT 0, border_interpolate.hpp:698-717) reuse the clamped reads: the wanted
+// 6 bytes are the loaded 8 shifted by the clamp distance, with zeros shifted in for the columns outside, and rows outside
+// are zeroed / swapped.  Pure ALU, run under a wave-level branch only where a wave touches the image border.
+__device__ __forceinline__ void fix_border_taps(Px2 &r1, Px2 &r2, int x1, int y1, int srows, int scols)
+{
+    const int x1c = min(max(x1, -3), scols + 2);                 // anything further out is all zeros anyway
+    const int b = 3 * x1c, bl = min(max(b, 0), 3 * scols - 8), sh = b - bl;
+    unsigned long long v1 = ((unsigned long long)r1.hi << 32) | r1.lo, v2 = ((unsigned long long)r2.hi << 32) | r2.lo;
+    if (sh > 0) { const int n = 8 * min(sh, 7); v1 = sh >= 8 ? 0ull : v1 >> n; v2 = sh >= 8 ? 0ull : v2 >> n; }
+    else if (sh < 0) { const int n = 8 * min(-sh, 7); v1 = sh <= -8 ? 0ull : v1 << n; v2 = sh <= -8 ? 0ull : v2 << n; }
+    // loaded rows are (ya, ya+1), ya = clamp(y1, 0, rows-2)
+    if (y1 == -1) { v2 = v1; v1 = 0ull; }
+    else if (y1 == srows - 1) { v1 = v2; v2 = 0ull; }
+    else if (y1 < -1 || y1 >= srows) { v1 = 0ull; v2 = 0ull; }
+    r1.lo = (unsigned)v1; r1.hi = (unsigned)(v1 >> 32);
+    r2.lo = (unsigned)v2; r2.hi = (unsigned)(v2 >> 32);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// bytes of a tap row: lo = B1 G1 R1 B2, hi = G2 R2 x x
+__device__ __forceinline__ float px_ch(const Px2 &r, int tap, int c)
+{
+    const int b = 3 * tap + c;
+    const unsigned w = b < 4 ? r.lo : r.hi;
+    return (float)((w >> (8 * (b & 3))) & 0xffu);          // v_cvt_f32_ubyteN
+}
 __device__ __forceinline__ void blend_taps(const Taps &t, const Px2 &r1, const Px2 &r2, float out[3])
 {
-    // bytes: lo = B1 G1 R1 B2, hi = G2 R2
-    const float s11[3] = {(float)(r1.lo & 0xff), (float)((r1.lo >> 8) & 0xff), (float)((r1.lo >> 16) & 0xff)};
-    const float s12[3] = {(float)(r1.lo >> 24), (float)(r1.hi & 0xff), (float)((r1.hi >> 8) & 0xff)};
-    const float s21[3] = {(float)(r2.lo & 0xff), (float)((r2.lo >> 8) & 0xff), (float)((r2.lo >> 16) & 0xff)};
-    const float s22[3] = {(float)(r2.lo >> 24), (float)(r2.hi & 0xff), (float)((r2.hi >> 8) & 0xff)};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float o = __builtin_fmaf(s11[c], t.w11, 0.f);
-        o = __builtin_fmaf(s12[c], t.w12, o);
-        o = __builtin_fmaf(s21[c], t.w21, o);
-        o = __builtin_fmaf(s22[c], t.w22, o);
+        float o = __builtin_fmaf(px_ch(r1, 0, c), t.w11, 0.f);
+        o = __builtin_fmaf(px_ch(r1, 1, c), t.w12, o);
+        o = __builtin_fmaf(px_ch(r2, 0, c), t.w21, o);
+        o = __builtin_fmaf(px_ch(r2, 1, c), t.w22, o);
         out[c] = o;
+    }
+}
+// two samples at once: the same four fmas per channel, issued as v_pk_fma_f32 (two fp32 lanes per instruction)
+__device__ __forceinline__ void blend_taps2(const Taps ta, const Taps tb, const Px2 r1a, const Px2 r2a, const Px2 r1b, const Px2 r2b,
+                                            float oa[3], float ob[3])
+{
+    f32x2 w11, w12, w21, w22;
+    w11.x = ta.w11; w11.y = tb.w11; w12.x = ta.w12; w12.y = tb.w12;
+    w21.x = ta.w21; w21.y = tb.w21; w22.x = ta.w22; w22.y = tb.w22;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x2 s11, s12, s21, s22, o = {0.f, 0.f};
+        s11.x = px_ch(r1a, 0, c); s11.y = px_ch(r1b, 0, c); s12.x = px_ch(r1a, 1, c); s12.y = px_ch(r1b, 1, c);
+        s21.x = px_ch(r2a, 0, c); s21.y = px_ch(r2b, 0, c); s22.x = px_ch(r2a, 1, c); s22.y = px_ch(r2b, 1, c);
+        o = __builtin_elementwise_fma(s11, w11, o);
+        o = __builtin_elementwise_fma(s12, w12, o);
+        o = __builtin_elementwise_fma(s21, w21, o);
+        o = __builtin_elementwise_fma(s22, w22, o);
+        oa[c] = o.x; ob[c] = o.y;
     }
 }
 
@@ -211,7 +265,8 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
         __syncthreads();
     }
 
-    Taps t[WARP_NG][4];
+    // phase 1: tap addresses -> all WARP_NG*8 row reads in flight.  Only the coordinates and the loaded bytes stay live across
+    // the wait; weights are rebuilt from the coordinates afterwards (2 v_floor per sample instead of 7 registers each).
     Px2 r1[WARP_NG][4], r2[WARP_NG][4];
     if (use_lds) {
         const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_tile4);
@@ -220,8 +275,8 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
         for (int g = 0; g < WARP_NG; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                t[g][k] = make_taps(xc[g][k], yc[g][k], srows, scols);
-                const int lx = min(max(t[g][k].x1 - T.sx0, 0), T.sw - 2), ly = min(max(t[g][k].y1 - T.sy0, 0), T.sh - 2);
+                const int x1 = f2i_rd(xc[g][k]), y1 = f2i_rd(yc[g][k]);
+                const int lx = min(max(x1 - T.sx0, 0), T.sw - 2), ly = min(max(y1 - T.sy0, 0), T.sh - 2);
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     // byte offset of pixel (ly+rr, lx) inside its staged row = leading misalignment of that row + 3*lx
@@ -240,13 +295,12 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
         for (int g = 0; g < WARP_NG; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                t[g][k] = make_taps(xc[g][k], yc[g][k], srows, scols);
-                const int xs = min(max(t[g][k].x1, 0), scols - 3), ysrc = min(max(t[g][k].y1, 0), srows - 2);
-                const uint8_t *p = sp + (size_t)ysrc * sstep + (size_t)xs * 3;
-                r1[g][k] = load_px2(p);
-                r2[g][k] = load_px2(p + sstep);
+                const unsigned off = tap_offset(f2i_rd(xc[g][k]), f2i_rd(yc[g][k]), srows, scols, sstep);      // images are < 4 GiB
+                r1[g][k] = load_px2(sp, off);
+                r2[g][k] = load_px2(sp + sstep, off);
             }
     }
+    // phase 2: weights, border fix-up, 4 fmas per channel (two samples per v_pk_fma_f32), gain, pack, store
     const LevelDesc &L = V.lv[0];
     const size_t plane = (size_t)L.h * L.pitch;
 #pragma unroll
@@ -254,14 +308,28 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
         if (!active[g]) continue;
         unsigned packed[3] = {0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float o[3];
-            if (t[g][k].fast) blend_taps(t[g][k], r1[g][k], r2[g][k], o);
-            else sample3(sp, sstep, srows, scols, xc[g][k], yc[g][k], o);      // image-edge / invalid coordinates: per-tap bounds
+        for (int k = 0; k < 4; k += 2) {
+            float o[2][3];
+            Taps t[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const unsigned val = CPW ? (unsigned)sat_u8(o[c]) : (unsigned)sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
-                packed[c] |= val << (8 * k);
+            for (int j = 0; j < 2; ++j) {
+                t[j] = make_taps(xc[g][k + j], yc[g][k + j], srows, scols);
+                if (!t[j].fast) {                 // a tap outside the image (or invalid coordinates)
+                    if (use_lds) {                // (the staged box only covers interior samples)
+                        const unsigned off = tap_offset(t[j].x1, t[j].y1, srows, scols, sstep);
+                        r1[g][k + j] = load_px2(sp, off);
+                        r2[g][k + j] = load_px2(sp + sstep, off);
+                    }
+                    fix_border_taps(r1[g][k + j], r2[g][k + j], t[j].x1, t[j].y1, srows, scols);
+                }
+            }
+            blend_taps2(t[0], t[1], r1[g][k], r2[g][k], r1[g][k + 1], r2[g][k + 1], o[0], o[1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    packed[c] = CPW ? sat_u8_into(o[j][c], k + j, packed[c])
+                                    : sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[c]);
             }
         }
         uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
@@ -292,19 +360,22 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         t[k] = make_taps(xc[k], yc[k], srows, scols);
-        const int xs = min(max(t[k].x1, 0), scols - 3), ys = min(max(t[k].y1, 0), srows - 2);
-        const uint8_t *p = sp + (size_t)ys * sstep + (size_t)xs * 3;
-        r1[k] = load_px2(p);
-        r2[k] = load_px2(p + sstep);
+        const unsigned off = tap_offset(t[k].x1, t[k].y1, srows, scols, sstep);
+        r1[k] = load_px2(sp, off);
+        r2[k] = load_px2(sp + sstep, off);
     }
     uint8_t o8[12];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float o[3];
-        if (t[k].fast) blend_taps(t[k], r1[k], r2[k], o);
-        else sample3(sp, sstep, srows, scols, xc[k], yc[k], o);
+    for (int k = 0; k < 4; k += 2) {
+        float o[2][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o8[3 * k + c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+        for (int j = 0; j < 2; ++j)
+            if (!t[k + j].fast) fix_border_taps(r1[k + j], r2[k + j], t[k + j].x1, t[k + j].y1, srows, scols);
+        blend_taps2(t[k], t[k + 1], r1[k], r2[k], r1[k + 1], r2[k + 1], o[0], o[1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o8[3 * (k + j) + c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f));
     }
     uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
     if (x + 3 < V.aw) {

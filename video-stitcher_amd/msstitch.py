@@ -60,7 +60,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish",
+    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8",
 ]
 
 _lib = None
@@ -146,6 +146,12 @@ def device_count():
 def calib_copy(src, dst):
     n = src.numel() * src.element_size()
     _chk(load().ms_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), _stream()))
+
+
+def selftest_cvt_u8():
+    n = C.c_ulonglong(1)
+    _chk(load().ms_selftest_cvt_u8(C.byref(n), _stream()))
+    return n.value
 
 
 def selftest_divide(dens):
