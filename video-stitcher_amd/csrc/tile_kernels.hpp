@@ -389,6 +389,65 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
 }
 
 // ---- pyrDown, tile list, 2 rows x 4 cols per lane (block 32 x 8) -------------------------------------
+// Packed 16-bit arithmetic: every input value is in [0,255] (8-bit pixels, or a Gaussian level of them -- see the invariant at
+// up_2x8_pk), so the vertical sums are <= 16*255 and the full 5x5 sums <= 256*255 = 65280 < 2^16: two columns share one
+// register and plain 32-bit adds never carry between the halves.  Same result as rne_shift(sum, 8) per pixel
+// (pyr_down.cu:55-174: the fp32 sums are exact, saturate_cast<short> rounds half-even).
+// A lane needs input columns 8t-2 .. 8t+8 = taps v0..v10; "even" taps E_i = v_{2i} (i = 0..5), "odd" taps O_i = v_{2i+1} (i = 0..4);
+//   out_i = E_i + 6 E_{i+1} + E_{i+2} + 4 (O_i + O_{i+1}),  i = 0..3.
+struct Down7 { unsigned a[7]; };     // one input row (or a vertical sum of rows): see the two loaders for the layouts
+// u8 row, window bytes 8t-4 .. 8t+11 (d0..d3): a0 = (x,E0) a1 = (E1,E2) a2 = (E3,E4) a3 = (E5,x) a4 = (x,O0) a5 = (O1,O2) a6 = (O3,O4)
+__device__ __forceinline__ Down7 down_row(const Row11u8 &o, int t, int w)
+{
+    unsigned d0 = o.b.x, d1 = o.b.y, d2 = o.b.z, d3 = o.b.w;
+    if (t == 0) {                     // window starts at column 0: taps v0, v1 mirror to columns 2, 1 (BORDER_REFLECT_101)
+        d3 = d2; d2 = d1; d1 = d0;
+        d0 = __builtin_amdgcn_perm(0u, d1, 0x01020c0cu);     // byte2 <- col 2, byte3 <- col 1
+    }
+    Down7 r;
+    r.a[0] = d0 & 0x00ff00ffu; r.a[1] = d1 & 0x00ff00ffu; r.a[2] = d2 & 0x00ff00ffu; r.a[3] = d3 & 0x00ff00ffu;
+    r.a[4] = (d0 >> 8) & 0x00ff00ffu; r.a[5] = (d1 >> 8) & 0x00ff00ffu; r.a[6] = (d2 >> 8) & 0x00ff00ffu;
+    if (8 * t + 8 >= w) r.a[3] = r.a[2] >> 16;              // column w mirrors to w-2: E5 = E4
+    return r;
+}
+// int16 row, window elements 8t-2 .. 8t+9 in natural pairs: a_i = (v_{2i}, v_{2i+1}) = (E_i, O_i), i = 0..5 (a6 unused)
+__device__ __forceinline__ Down7 down_row(const Row11s16 &o, int t, int w)
+{
+    Down7 r;
+    r.a[0] = o.b.x; r.a[1] = o.b.y; r.a[2] = o.b.z; r.a[3] = o.b.w; r.a[4] = o.c.x; r.a[5] = o.c.y; r.a[6] = 0u;
+    if (t == 0) {                     // window starts at column 0
+        r.a[5] = r.a[4]; r.a[4] = r.a[3]; r.a[3] = r.a[2]; r.a[2] = r.a[1]; r.a[1] = r.a[0];
+        r.a[0] = __builtin_amdgcn_perm(r.a[1], r.a[2], 0x07060100u);      // (col 2, col 1)
+    }
+    if (8 * t + 8 >= w) r.a[5] = r.a[4];                    // E5 = E4
+    return r;
+}
+__device__ __forceinline__ unsigned rne8_pk(unsigned s)
+{
+    const unsigned t = (s >> 8) & 0x00010001u;
+    return ((s + t + 0x007f007fu) >> 8) & 0x00ff00ffu;
+}
+// horizontal pass on a vertical sum; returns (out0,out1) and (out2,out3) as int16 pairs
+template <typename TIN>
+__device__ __forceinline__ uint2 down_hpass(const Down7 &v)
+{
+    unsigned e01, e12, e23, e34, e45, o01, o12, o23, o34;
+    if (sizeof(TIN) == 1) {
+        e01 = __builtin_amdgcn_alignbyte(v.a[1], v.a[0], 2); e12 = v.a[1]; e23 = __builtin_amdgcn_alignbyte(v.a[2], v.a[1], 2);
+        e34 = v.a[2]; e45 = __builtin_amdgcn_alignbyte(v.a[3], v.a[2], 2);
+        o01 = __builtin_amdgcn_alignbyte(v.a[5], v.a[4], 2); o12 = v.a[5]; o23 = __builtin_amdgcn_alignbyte(v.a[6], v.a[5], 2); o34 = v.a[6];
+    } else {
+        e01 = __builtin_amdgcn_perm(v.a[1], v.a[0], 0x05040100u); e12 = __builtin_amdgcn_perm(v.a[2], v.a[1], 0x05040100u);
+        e23 = __builtin_amdgcn_perm(v.a[3], v.a[2], 0x05040100u); e34 = __builtin_amdgcn_perm(v.a[4], v.a[3], 0x05040100u);
+        e45 = __builtin_amdgcn_perm(v.a[5], v.a[4], 0x05040100u);
+        o01 = __builtin_amdgcn_perm(v.a[1], v.a[0], 0x07060302u); o12 = __builtin_amdgcn_perm(v.a[2], v.a[1], 0x07060302u);
+        o23 = __builtin_amdgcn_perm(v.a[3], v.a[2], 0x07060302u); o34 = __builtin_amdgcn_perm(v.a[4], v.a[3], 0x07060302u);
+    }
+    const unsigned s01 = e01 + 6u * e12 + e23 + 4u * (o01 + o12);
+    const unsigned s23 = e23 + 6u * e34 + e45 + 4u * (o23 + o34);
+    return make_uint2(rne8_pk(s01), rne8_pk(s23));
+}
+
 template <typename TIN>
 __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int l,
                                                 const TIN *__restrict__ gin, long long in_stride,
@@ -411,27 +470,18 @@ __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ til
     typename Row11<TIN>::type raw[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) raw[j] = fetch_row11(in + (size_t)ridx[j] * Li.pitch, t, Li.w);
-    int V0[11], V1[11];
+    Down7 r[7];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) V0[k] = V1[k] = 0;
-    const int w0[7] = {1, 4, 6, 4, 1, 0, 0}, w1[7] = {0, 0, 1, 4, 6, 4, 1};
+    for (int j = 0; j < 7; ++j) r[j] = down_row(raw[j], t, Li.w);
+    Down7 v0, v1;                     // vertical 1 4 6 4 1 of rows 0..4 (output row y) and rows 2..6 (output row y+1)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        int r[11];
-        unpack_row11(raw[j], t, Li.w, r);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { V0[k] += w0[j] * r[k]; V1[k] += w1[j] * r[k]; }
+    for (int k = 0; k < 7; ++k) {
+        v0.a[k] = (r[0].a[k] + r[4].a[k]) + 4u * (r[1].a[k] + r[3].a[k]) + 6u * r[2].a[k];
+        v1.a[k] = (r[2].a[k] + r[6].a[k]) + 4u * (r[3].a[k] + r[5].a[k]) + 6u * r[4].a[k];
     }
     int16_t *out = gout + (size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + 4 * t;
-    auto emit = [&](const int *V, int16_t *dst) {
-        unsigned o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            o[i] = (unsigned)(uint16_t)sat_s16(rne_shift(V[2 * i] + 4 * V[2 * i + 1] + 6 * V[2 * i + 2] + 4 * V[2 * i + 3] + V[2 * i + 4], 8));
-        *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-    };
-    emit(V0, out);
-    if (two) emit(V1, out + Lo.pitch);
+    *reinterpret_cast<uint2 *>(out) = down_hpass<TIN>(v0);
+    if (two) *reinterpret_cast<uint2 *>(out + Lo.pitch) = down_hpass<TIN>(v1);
 }
 
 }  // namespace ms
