@@ -519,6 +519,54 @@ __device__ __forceinline__ void up_2x8_pk(const int16_t *__restrict__ cs, int cp
     }
 }
 
+// The COLLAPSED coarser level has no such bound (it is a saturate_cast<short> of a sum), but in practice it stays near the 8-bit
+// range: add a bias of 384 and use the same packed arithmetic when all 18 taps of the lane are in [-384, 639]
+// (pyrUp's weights sum to 64 and 384 is even, so rne(S + 64*384, 6) == rne(S, 6) + 384 exactly); lanes with a tap outside
+// that range take the 32-bit up_2x8.  Returns false if the lane must fall back.  Outputs are biased: value + 384.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned add_pk_u16(unsigned a, unsigned b)      // v_pk_add_u16: halves add independently (wrap)
+{
+    u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    x += y;
+    __builtin_memcpy(&a, &x, 4);
+    return a;
+}
+constexpr int UP_BIAS = 384;
+__device__ __forceinline__ bool up_2x8_pkb(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
+                                           unsigned ue[4], unsigned uo[4])
+{
+    const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
+    const int jb = max(j0 - 2, 0);
+    uint4 raw[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
+    unsigned he[3][2], ho[3][2], bad = 0u;
+    const unsigned bias = (unsigned)UP_BIAS * 0x00010001u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        unsigned w0 = add_pk_u16(raw[r].x, bias), w1 = add_pk_u16(raw[r].y, bias), w2 = add_pk_u16(raw[r].z, bias), w3 = add_pk_u16(raw[r].w, bias);
+        if (j0 == 0) { w3 = w2; w2 = w1; w1 = w0; }
+        if (j0 + 4 >= cw) w3 = w2 >> 16;
+        bad |= (w0 & 0xfc000000u) | (w1 & 0xfc00fc00u) | (w2 & 0xfc00fc00u) | (w3 & 0x0000fc00u);   // taps: hi(w0), w1, w2, lo(w3)
+        const unsigned t01 = __builtin_amdgcn_alignbyte(w1, w0, 2), t23 = __builtin_amdgcn_alignbyte(w2, w1, 2),
+                       t45 = __builtin_amdgcn_alignbyte(w3, w2, 2);
+        he[r][0] = t01 + 6u * w1 + t23;
+        he[r][1] = t23 + 6u * w2 + t45;
+        ho[r][0] = 4u * (w1 + t23);
+        ho[r][1] = 4u * (w2 + t45);
+    }
+    if (bad) return false;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ue[2 * q] = rne6_pk(he[0][q] + 6u * he[1][q] + he[2][q]);
+        ue[2 * q + 1] = rne6_pk(ho[0][q] + 6u * ho[1][q] + ho[2][q]);
+        uo[2 * q] = rne6_pk(4u * (he[1][q] + he[2][q]));
+        uo[2 * q + 1] = rne6_pk(4u * (ho[1][q] + ho[2][q]));
+    }
+    return true;
+}
+
 template <bool L0, int MODE>
 __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
@@ -648,7 +696,19 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         int up[2][8];
-        up_2x8(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, up[0], up[1]);
+        unsigned upk[2][4];
+        if (up_2x8_pkb(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, upk[0], upk[1])) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {           // pixel order (0,2) (1,3) (4,6) (5,7)
+                    const int k0 = (q >> 1) * 4 + (q & 1);
+                    up[r][k0] = (int)(upk[r][q] & 0xffffu) - UP_BIAS;
+                    up[r][k0 + 2] = (int)(upk[r][q] >> 16) - UP_BIAS;
+                }
+        } else {
+            up_2x8(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, up[0], up[1]);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1530,6 +1590,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     // invariant the packed band arithmetic relies on: every value in the view pyramids is in [0,255], written or not
     MS_HIP(hipMemsetAsync(c->g0.p, 0, (size_t)c->g0_stride * F + 64, st));
     MS_HIP(hipMemsetAsync(c->gl.p, 0, (size_t)c->gl_stride * F * sizeof(int16_t) + 64, st));
+    MS_HIP(hipMemsetAsync(c->cl.p, 0, (size_t)c->cl_stride * F * sizeof(int16_t) + 64, st));
     if (c->cfg.enable_cpw) {
         if (int e = c->stage.alloc((size_t)c->stage_stride * F)) return e;
         size_t mtotal = 0;
