@@ -1763,7 +1763,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
-            k_warp_t<true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), 0, st>>>(
+            k_warp_t<true, false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), 0, st>>>(
                 (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
@@ -1771,8 +1771,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     } else if (c->warp_tiled && c->cfg.reserved[0] == 0) {
         int lds_ok = c->cfg.reserved[1] != 0 && c->warp_lds_bytes > 0;   // opt-in: LDS staging of the source tiles (measured slower than direct gathers)
         for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
-        k_warp_t<false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), lds_ok ? c->warp_lds_bytes : 0, st>>>(
-            (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, lds_ok);
+        if (lds_ok)
+            k_warp_t<false, true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), c->warp_lds_bytes, st>>>(
+                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1);
+        else
+            k_warp_t<false, false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), 0, st>>>(
+                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

@@ -204,10 +204,13 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
 // One lane owns WARP_NG groups of 4 consecutive pixels (rows y and y + 16/WARP_NG of the tile): all WARP_NG*8 tap-row
 // loads are in flight together, so a wave pays the memory round trip once for 2x the pixels (the kernel is bound by
 // dependent-load latency x waves in flight, not by bytes).
-constexpr int WARP_NG = 2;
+#ifndef MS_WARP_NG
+#define MS_WARP_NG 2
+#endif
+constexpr int WARP_NG = MS_WARP_NG;
 constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = 16 x WARP_BY lanes
 
-template <bool CPW>
+template <bool CPW, bool STAGED>
 __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
@@ -227,8 +230,63 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
     int srows, scols;
     if (CPW) { sp = stage + (size_t)f * stage_stride + V.s1_off; sstep = (unsigned)V.s1_pitch; srows = V.ah; scols = V.aw; }
     else { sp = src.p[f * n_views + v]; sstep = src.step[f * n_views + v]; srows = src_rows; scols = src_cols; }
-    const bool use_lds = !CPW && lds_ok && (T.flags & 1);
+    const bool use_lds = STAGED && !CPW && lds_ok && (T.flags & 1);
 
+    if (!STAGED) {
+    // default form: software pipeline over the WARP_NG row groups of the lane -- the tap reads of group g+1 are in flight while
+    // group g is blended (measured 5 % faster than issuing all groups first; the LDS-staged form below is opt-in and slower)
+    const LevelDesc &L = V.lv[0];
+    const size_t plane = (size_t)L.h * L.pitch;
+    float xc[2][4], yc[2][4];
+    Px2 r1[2][4], r2[2][4];
+    auto issue = [&](int g) {
+        const int b = g & 1;
+        if (active[g]) warp_coords4<CPW>(V, mesh, v, x, ys[g], xc[b], yc[b]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xc[b][k] = yc[b][k] = -1.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
+            r1[b][k] = load_px2(sp, off);
+            r2[b][k] = load_px2(sp + sstep, off);
+        }
+    };
+    issue(0);
+#pragma unroll
+    for (int g = 0; g < WARP_NG; ++g) {
+        const int b = g & 1;
+        if (g + 1 < WARP_NG) issue(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active[g]) {
+            unsigned packed[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                float o[2][3];
+                Taps t[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
+                    if (!t[j].fast) fix_border_taps(r1[b][k + j], r2[b][k + j], t[j].x1, t[j].y1, srows, scols);
+                }
+                blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        packed[c] = CPW ? sat_u8_into(o[j][c], k + j, packed[c])
+                                        : sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[c]);
+            }
+            uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
+            *reinterpret_cast<unsigned *>(d) = packed[0];
+            *reinterpret_cast<unsigned *>(d + plane) = packed[1];
+            *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+    }
     float xc[WARP_NG][4], yc[WARP_NG][4];
 #pragma unroll
     for (int g = 0; g < WARP_NG; ++g) {

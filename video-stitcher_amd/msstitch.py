@@ -73,7 +73,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise MsError("libmsstitch.so not built (run video-stitcher_amd/build.sh or __graft_entry__.build()); "
                           "there is no CPU fallback")
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(os.environ.get("MSSTITCH_LIB", LIB_PATH))       # MSSTITCH_LIB: developer knob for A/B builds of the same ABI
         _lib.ms_last_error.restype = C.c_char_p
         _lib.ms_version.restype = C.c_char_p
     return _lib
