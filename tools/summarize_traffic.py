@@ -52,9 +52,9 @@ def main(out, tag, cfg, frames):
     # bench.py names its per-level launches k_down_l<l> / k_blend_l<l>; map the dominant ones by kernel template
     alias = {}
     for k, v in res["kernels"].items():
-        if k.startswith("k_warp_t<false>") or k.startswith("k_warp<false>"):
+        if k.startswith("k_warp_t<false") or k.startswith("k_warp<false>"):
             alias["k_warp"] = v
-        if k.startswith("k_blend8<true>"):
+        if k.startswith("k_blend8<true, 0>") or k.startswith("k_blend8<true>"):
             alias["k_blend_l0"] = v
         if k.startswith("k_down_t<unsigned char>"):
             alias["k_down_l0"] = v
