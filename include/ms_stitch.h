@@ -222,6 +222,11 @@ MS_API int ms_set_mask(ms_ctx *ctx, int view, const uint8_t *mask_host, size_t s
 /* mb->init_gpu(_, mask, corner) for every view, in view order (calibration.cpp:240 -> blenders.cpp:344-461),
  * plus the frame-invariant weight sums the reference re-accumulates every frame (blenders.cpp:736, :775). */
 MS_API int ms_init_blender(ms_ctx *ctx, ms_stream stream);
+/* FeatherBlender (detail::FeatherBlender, blenders.cpp:139-186; the CPU blender of the reference's 2-view example): same call order as
+ * ms_init_blender on a context created with num_bands = 0.  Weight maps are createWeightMap(mask, sharpness) (blenders.cpp:944-951:
+ * L1 distance transform * sharpness, truncated at 1; OpenCV's default sharpness is 0.02) instead of mask/255; ms_stitch then runs
+ * feed x N + blend as one single-band pass. */
+MS_API int ms_init_feather(ms_ctx *ctx, float sharpness, ms_stream stream);
 
 /* MeshWarper::convertMeshesToMap for one view (APP/meshwarper.cpp:823-886): N x M vertex mesh (HOST fp32,
  * forward positions in view-ROI pixels) -> dense backward maps x_mesh/y_mesh, double-buffered; takes

@@ -209,6 +209,12 @@ void orc_stitch_online(orc_blender *b, int view, const uint8_t *src, size_t sste
                        const float *xmap, const float *ymap, double gain,
                        const float *xmesh, const float *ymesh, uint8_t *warped_out /* optional, w*h*3 */);
 
+/* FeatherBlender (blenders.cpp:139-186, 944-951): BASELINE configs[0]'s CPU blender */
+void orc_feather_weight_map(const uint8_t *mask, size_t mstep, int rows, int cols, float sharpness, float *w, size_t wstep);
+void orc_feather_feed(const int16_t *img, size_t istep, const float *w, size_t wstep, int rows, int cols, int dx, int dy,
+                      int16_t *dst, size_t dstep, float *dst_w, size_t dwstep);
+void orc_feather_blend(int16_t *dst, size_t dstep, const float *dst_w, size_t dwstep, int rows, int cols, uint8_t *mask, size_t mstep);
+
 void orc_set_num_threads(int n);
 
 #ifdef __cplusplus

@@ -452,3 +452,59 @@ int orc_gain_compensator(int n, const int *cx, const int *cy, const int *w, cons
     free(N); free(I); free(A);
     return ok;
 }
+
+
+/* ====================================================================================================================
+ * FeatherBlender -- the CPU blender of BASELINE configs[0].  TEST INFRASTRUCTURE ONLY.
+ * Follows OCV stitching/src/blenders.cpp:
+ *   createWeightMap            :944-951   distanceTransform(mask, DIST_L1, 3) * sharpness, threshold(.., 1, THRESH_TRUNC)
+ *   Blender::prepare(Rect)     :89-95     dst 16SC3 zeros, dst_mask 8U zeros over dst_roi (= resultRoi(corners, sizes), :82-86)
+ *   FeatherBlender::prepare    :139-144   dst_weight_map 32F zeros
+ *   FeatherBlender::feed       :147-178   dst += (short)(src * w) per channel, dst_w += w
+ *   FeatherBlender::blend      :181-186   normalizeUsingWeightMap (:899-912), mask = dst_w > WEIGHT_EPS (1e-5f), Blender::blend:
+ *   Blender::blend             :125-135   dst.setTo(0, dst_mask == 0)
+ * multiply(32F, scalar) works in float (the scalar is converted to the array depth), so weight = min(d * sharpness, 1) in fp32.
+ * static_cast<short>(float) truncates toward zero (values here are far inside the short range).
+ * ==================================================================================================================== */
+void orc_feather_weight_map(const uint8_t *mask, size_t mstep, int rows, int cols, float sharpness, float *w, size_t wstep)
+{
+    orc_distance_transform_l1(mask, mstep, rows, cols, w, wstep);
+    for (int y = 0; y < rows; ++y) {
+        float *r = (float *)((char *)w + (size_t)y * wstep);
+        for (int x = 0; x < cols; ++x) {
+            const float t = r[x] * sharpness;
+            r[x] = t > 1.f ? 1.f : t;                      /* THRESH_TRUNC */
+        }
+    }
+}
+
+/* dst / dst_w cover dst_roi (rows x cols = roi_h x roi_w); img is 16SC3 (the caller's convertTo(CV_16S) of the warped 8U view) */
+void orc_feather_feed(const int16_t *img, size_t istep, const float *w, size_t wstep, int rows, int cols, int dx, int dy,
+                      int16_t *dst, size_t dstep, float *dst_w, size_t dwstep)
+{
+    for (int y = 0; y < rows; ++y) {
+        const int16_t *s = (const int16_t *)((const char *)img + (size_t)y * istep);
+        const float *wr = (const float *)((const char *)w + (size_t)y * wstep);
+        int16_t *d = (int16_t *)((char *)dst + (size_t)(dy + y) * dstep);
+        float *dw = (float *)((char *)dst_w + (size_t)(dy + y) * dwstep);
+        for (int x = 0; x < cols; ++x) {
+            for (int c = 0; c < 3; ++c)
+                d[3 * (dx + x) + c] = (int16_t)(d[3 * (dx + x) + c] + (int16_t)((float)s[3 * x + c] * wr[x]));
+            dw[dx + x] += wr[x];
+        }
+    }
+}
+
+void orc_feather_blend(int16_t *dst, size_t dstep, const float *dst_w, size_t dwstep, int rows, int cols, uint8_t *mask, size_t mstep)
+{
+    for (int y = 0; y < rows; ++y) {
+        int16_t *d = (int16_t *)((char *)dst + (size_t)y * dstep);
+        const float *dw = (const float *)((const char *)dst_w + (size_t)y * dwstep);
+        uint8_t *m = mask + (size_t)y * mstep;
+        for (int x = 0; x < cols; ++x) {
+            for (int c = 0; c < 3; ++c) d[3 * x + c] = (int16_t)((float)d[3 * x + c] / (dw[x] + 1e-5f));
+            m[x] = dw[x] > 1e-5f ? 255 : 0;
+            if (!m[x]) d[3 * x] = d[3 * x + 1] = d[3 * x + 2] = 0;
+        }
+    }
+}

@@ -345,6 +345,29 @@ def convert_mesh_to_map(mesh_x, mesh_y, width, height):
 
 # ------------------------------------------------------------------ blender object
 
+def feather_weight_map(mask, sharpness=0.02):
+    """createWeightMap (blenders.cpp:944-951)."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    w = np.empty(mask.shape, np.float32)
+    lib().orc_feather_weight_map(_p(mask), _st(mask), mask.shape[0], mask.shape[1], C.c_float(sharpness), _p(w), _st(w))
+    return w
+
+
+def feather_blend(corners, imgs8u, masks, sharpness=0.02):
+    """FeatherBlender prepare / feed x N / blend (blenders.cpp:139-186) on 8UC3 views (converted to 16S like the caller does)."""
+    sizes = [(m.shape[1], m.shape[0]) for m in masks]
+    roi = result_roi(corners, sizes)
+    dst = np.zeros((roi[3], roi[2], 3), np.int16); dw = np.zeros((roi[3], roi[2]), np.float32)
+    for (cx, cy), img, m in zip(corners, imgs8u, masks):
+        w = feather_weight_map(m, sharpness)
+        i16 = np.ascontiguousarray(img, np.uint8).astype(np.int16)
+        lib().orc_feather_feed(_p(i16), _st(i16), _p(w), _st(w), m.shape[0], m.shape[1], cx - roi[0], cy - roi[1],
+                               _p(dst), _st(dst), _p(dw), _st(dw))
+    mask = np.empty((roi[3], roi[2]), np.uint8)
+    lib().orc_feather_blend(_p(dst), _st(dst), _p(dw), _st(dw), roi[3], roi[2], _p(mask), _st(mask))
+    return dst, mask, roi
+
+
 class Blender:
     """The fork's GPU MultiBandBlender (prepare / init_gpu / feed_online / blend(gpuOut))."""
 

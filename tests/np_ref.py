@@ -86,3 +86,21 @@ def add_src_weight(src, w, dst, dst_w):
 def normalize(w, src):
     den = (w + np.float32(1e-5)).astype(np.float32)
     src[...] = np.trunc(src.astype(np.float32) / den[..., None]).astype(np.int16)
+
+
+def feather_blend_np(corners, imgs8u, masks, dt_l1, sharpness=0.02):
+    """numpy restatement of FeatherBlender (blenders.cpp:139-186); dt_l1(mask) -> float32 L1 distance transform."""
+    xs = [c[0] for c in corners]; ys = [c[1] for c in corners]
+    x0, y0 = min(xs), min(ys)
+    x1 = max(c[0] + m.shape[1] for c, m in zip(corners, masks)); y1 = max(c[1] + m.shape[0] for c, m in zip(corners, masks))
+    dst = np.zeros((y1 - y0, x1 - x0, 3), np.int16); dw = np.zeros((y1 - y0, x1 - x0), np.float32)
+    for (cx, cy), img, m in zip(corners, imgs8u, masks):
+        w = np.minimum(dt_l1(m).astype(np.float32) * np.float32(sharpness), np.float32(1.0)).astype(np.float32)
+        contrib = np.trunc(img.astype(np.float32) * w[:, :, None]).astype(np.int16)
+        sl = (slice(cy - y0, cy - y0 + m.shape[0]), slice(cx - x0, cx - x0 + m.shape[1]))
+        dst[sl] = (dst[sl].astype(np.int32) + contrib).astype(np.int16)
+        dw[sl] = dw[sl] + w
+    q = np.trunc(dst.astype(np.float32) / (dw + np.float32(1e-5))[:, :, None]).astype(np.int16)
+    mask = np.where(dw > np.float32(1e-5), 255, 0).astype(np.uint8)
+    q[mask == 0] = 0
+    return q, mask

@@ -797,6 +797,43 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
     }
 }
 
+// single band (num_bands == 0): dst = sum_v (short)(img_v * w_v), normalised by the weight sum and masked.  With the weights of
+// ms_init_feather this is FeatherBlender::feed / blend (blenders.cpp:147-186); with mask/255 weights, MultiBandBlender with no bands.
+__global__ void __launch_bounds__(256) k_single_band(const ViewDesc *__restrict__ views, PanoDesc P,
+                                                     const uint8_t *__restrict__ g0, long long g0_stride, OutTable out)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= P.fw || y >= P.fh) return;
+    int16_t acc[3] = {0, 0, 0};
+    for (int v = 0; v < P.n_views; ++v) {
+        const LevelDesc &L = views[v].lv[0];
+        const int lx = x - L.x_tl, ly = y - L.y_tl;
+        if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
+        const float w = L.wgt[(size_t)ly * L.wpitch + lx];
+        const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + (size_t)ly * L.pitch + lx;
+        const size_t plane = (size_t)L.h * L.pitch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = (int16_t)(acc[c] + trunc_s16((float)p[c * plane] * w));
+    }
+    const float den = P.den[0][(size_t)y * P.dpitch[0] + x];
+    const bool m = P.mask[(size_t)y * P.mask_pitch + x] != 0;
+    int r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = m ? (int)trunc_s16((float)acc[c] / den) : 0;
+    if (out.p16[f]) {
+        int16_t *d = (int16_t *)((char *)out.p16[f] + (size_t)y * out.step16[f]) + 3 * x;
+        d[0] = (int16_t)r[0]; d[1] = (int16_t)r[1]; d[2] = (int16_t)r[2];
+    }
+    if (out.p8[f]) {
+        const int cx = x + P.canvas_x, cy = y + P.canvas_y;
+        if (cx >= 0 && cx < P.out_w && cy >= 0 && cy < P.out_h) {
+            uint8_t *d = out.p8[f] + (size_t)cy * out.step8[f] + 3 * (size_t)cx;
+            d[0] = (uint8_t)min(max(r[0], 0), 255); d[1] = (uint8_t)min(max(r[1], 0), 255); d[2] = (uint8_t)min(max(r[2], 0), 255);
+        }
+    }
+}
+
 // exhaustive check of DivBy against the compiler's IEEE division: all int16 numerators for each denominator
 __global__ void __launch_bounds__(256) k_selftest_divide(const float *__restrict__ dens, int n_dens, unsigned *mismatches)
 {
@@ -944,6 +981,7 @@ struct ms_ctx {
     bool blend_vec[MAX_LEVELS] = {};   // band l may use the 2x8 kernel
     // work lists (tiles that are actually needed)
     bool warp_tiled = false;
+    float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0;
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
@@ -1551,7 +1589,15 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         ViewDesc &V = c->h_views[v];
         ms_image mask{(uint8_t *)c->masks.p + c->mask_off[v], (size_t)V.aw, V.ah, V.aw, MS_8UC1};
         ms_image wmap{wm.p, (size_t)V.aw * sizeof(float), V.ah, V.aw, MS_32FC1};
-        if (int e = launch_convert(mask, wmap, 1. / 255., st)) return e;                       // blenders.cpp:412
+        if (c->feather_sharpness >= 0.f) {            // FeatherBlender::feed -> createWeightMap (blenders.cpp:156, 944-951), host side like the reference
+            std::vector<uint8_t> hm((size_t)V.aw * V.ah);
+            std::vector<float> hw((size_t)V.aw * V.ah);
+            MS_HIP(hipMemcpyAsync(hm.data(), mask.data, hm.size(), hipMemcpyDeviceToHost, st));
+            MS_HIP(hipStreamSynchronize(st));
+            feather_weight_map(hm.data(), V.ah, V.aw, c->feather_sharpness, hw.data());
+            MS_HIP(hipMemcpyAsync(wm.p, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            MS_HIP(hipStreamSynchronize(st));
+        } else if (int e = launch_convert(mask, wmap, 1. / 255., st)) return e;                // blenders.cpp:412
         auto level_img = [&](int l) {
             const LevelDesc &L = V.lv[l];
             return ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.h, L.w, MS_32FC1};
@@ -1603,6 +1649,16 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     if (int e = build_plan(c)) return e;
     c->blender_ready = true;
     return MS_OK;
+}
+
+int ms_init_feather(ms_ctx *c, float sharpness, ms_stream stream)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    if (!c->maps_built) return fail(MS_ERR_STATE, "ms_init_feather: maps and masks must be built first");
+    MS_CHECK(c->bg.num_bands == 0, "ms_init_feather: create the context with num_bands = 0 (FeatherBlender has a single band)");
+    MS_CHECK(sharpness > 0.f, "ms_init_feather: sharpness must be positive");
+    c->feather_sharpness = sharpness;
+    return ms_init_blender(c, stream);
 }
 
 // ---- CPW mesh maps ------------------------------------------------------------------------------
@@ -1799,11 +1855,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         if (int e = mark(down_names[l])) return e;
     }
     }   // S.mode != 2
-    if (nb == 0) {
-        // single band: out = mask ? trunc(sum/den) : 0 -- handled by the top kernel writing level 0 is not
-        // representable in the collapsed buffer; the path requires num_bands >= 1.
-        return fail(MS_ERR_UNSUPPORTED, "ms_stitch: num_bands resolved to 0 (pano smaller than 2 px?)");
-    }
+    if (nb == 0) {       // single band (FeatherBlender weights or plain mask weights): no pyramid, one pass over the pano
+        if (S.mode != 0) return fail(MS_ERR_UNSUPPORTED, "view sharding needs num_bands >= 1");
+        k_single_band<<<dim3(div_up(P.fw, 64), div_up(P.fh, 4), F), blk, 0, st>>>(vt, P, g0, c->g0_stride, out);
+        MS_LAUNCH_CHECK();
+        if (int e = mark("k_single_band")) return e;
+    } else {
 #define MS_MODE_LAUNCH(K, G, B, ...)                                     \
     do {                                                                \
         if (S.mode == 0) K<0><<<G, B, 0, st>>>(__VA_ARGS__);            \
@@ -1832,6 +1889,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark(blend_names[l])) return e;
     }
+    }   // nb > 0
     MS_HIP(hipEventRecord(c->last_stitch, st));
     c->stitch_pending = true;
 

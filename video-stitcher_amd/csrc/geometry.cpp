@@ -274,6 +274,18 @@ void seam_pair(uint8_t *m1, const ms_rect &r1, uint8_t *m2, const ms_rect &r2, c
 
 }  // namespace
 
+// createWeightMap (blenders.cpp:944-951): distanceTransform(mask, DIST_L1, 3) * sharpness, threshold(.., 1, THRESH_TRUNC); fp32
+void feather_weight_map(const uint8_t *mask, int rows, int cols, float sharpness, float *w)
+{
+    std::vector<uint8_t> m(mask, mask + (size_t)rows * cols);
+    std::vector<float> d;
+    dist_l1(m, rows, cols, d);
+    for (size_t i = 0; i < d.size(); ++i) {
+        const float t = d[i] * sharpness;
+        w[i] = t > 1.f ? 1.f : t;
+    }
+}
+
 void voronoi_seams(int n, const ms_rect *rois, uint8_t **masks)
 {
     for (int i = 0; i + 1 < n; ++i)
