@@ -134,6 +134,109 @@ __global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views
     gout[(size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + x] = sat_s16(rne_shift(acc, 8));
 }
 
+// 16 bytes from a 4-byte aligned address as one global_load_dwordx4
+__device__ __forceinline__ uint4 load16_a4(const void *p)
+{
+    uint4 r;
+    __builtin_memcpy(&r, __builtin_assume_aligned(p, 4), 16);
+    return r;
+}
+
+// ---- fused tail of the Gaussian pyramids: down steps l0 .. nb-1 of one (frame, view, colour plane) in one workgroup --------
+// The coarse levels are tiny (config 2: 148x80 and smaller): a launch per level is pure latency.  Level l0 is copied into LDS as
+// bytes (every Gaussian value is in [0,255]), each further level is computed LDS -> LDS and also stored to the pyramid
+// buffer for the band kernels.  Same exact integer arithmetic as k_down.
+// Wide views are cut into strips of TAIL_STRIP columns of the coarsest level; a strip recomputes the few halo columns it needs
+// at the intermediate levels and stores only the columns it owns.
+constexpr int TAIL_STRIP = 16;
+__host__ __device__ inline void tail_range(const int *w, int l0, int nb, int strip, int *a, int *b)
+{
+    a[nb] = strip * TAIL_STRIP; b[nb] = min(a[nb] + TAIL_STRIP, w[nb]);
+    for (int l = nb - 1; l >= l0; --l) { a[l] = max(2 * a[l + 1] - 2, 0); b[l] = min(2 * b[l + 1] + 2, w[l]); }
+}
+__global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ views, int n_views, int l0, int nb, int max_strips,
+                                                   int16_t *__restrict__ gl, long long gl_stride, unsigned own_mask)
+{
+    extern __shared__ uint8_t s_lv[];
+    const int strip = blockIdx.x % max_strips, z = blockIdx.x / max_strips;
+    const int c = z % 3, v = (z / 3) % n_views, f = z / (3 * n_views);
+    if (!((own_mask >> v) & 1u)) return;
+    const ViewDesc &V = views[v];
+    int w[MAX_LEVELS + 1], a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
+    for (int l = l0; l <= nb; ++l) w[l] = V.lv[l].w;
+    if (strip * TAIL_STRIP >= w[nb]) return;
+    tail_range(w, l0, nb, strip, a, b);
+    int16_t *base = gl + (size_t)f * gl_stride;
+    const int tx = threadIdx.x, ty = threadIdx.y;           // block 64 x 4
+    uint8_t *cur = s_lv;
+    {
+        const LevelDesc &La = V.lv[l0];
+        const int16_t *in = base + La.off + (size_t)c * La.h * La.pitch + a[l0];
+        const int wl = b[l0] - a[l0];
+        // 8 columns per 16-byte read (a[l0] is even: dword aligned), four reads in flight per lane before the first LDS write
+        const int nchunk = (wl + 7) >> 3, total = La.h * nchunk, tid = ty * 64 + tx;
+        for (int i0 = tid; i0 < total; i0 += 1024) {
+            uint4 q[4];
+            int yy[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, total - 1);
+                yy[u] = i / nchunk; cc[u] = i - yy[u] * nchunk;
+                q[u] = load16_a4(in + (size_t)yy[u] * La.pitch + 8 * cc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + 256 * u >= total) continue;
+                const unsigned d[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (8 * cc[u] + k < wl) cur[yy[u] * wl + 8 * cc[u] + k] = (uint8_t)((d[k >> 1] >> (16 * (k & 1))) & 0xffu);
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = l0; l < nb; ++l) {
+        const LevelDesc &Li = V.lv[l], &Lo = V.lv[l + 1];
+        const int wi = b[l] - a[l], wo = b[l + 1] - a[l + 1];
+        uint8_t *nxt = cur + ((wi * Li.h + 15) & ~15);
+        int16_t *out = base + Lo.off + (size_t)c * Lo.h * Lo.pitch;
+        const bool big = Li.h >= 3 && Li.w >= 3;           // |overshoot| <= 2 < len: BORDER_REFLECT_101 without the integer modulo
+        const int lr = Li.h - 1, lc = Li.w - 1;
+        const int own_a = min((strip * TAIL_STRIP) << (nb - l - 1), Lo.w);
+        const int own_b = (strip * TAIL_STRIP + TAIL_STRIP >= w[nb]) ? Lo.w : min(((strip + 1) * TAIL_STRIP) << (nb - l - 1), Lo.w);
+        for (int y = ty; y < Lo.h; y += 4) {
+            int ry[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int r = 2 * y - 2 + k;
+                ry[k] = big ? (abs(r) > lr ? 2 * lr - abs(r) : abs(r)) : r101(r, Li.h);
+            }
+            for (int xo = tx; xo < wo; xo += 64) {
+                const int x = a[l + 1] + xo;
+                int cx[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int q = 2 * x - 2 + k;
+                    cx[k] = (big ? (abs(q) > lc ? 2 * lc - abs(q) : abs(q)) : r101(q, Li.w)) - a[l];
+                }
+                const int wv[5] = {1, 4, 6, 4, 1};
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint8_t *r = cur + ry[j] * wi;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) acc += wv[j] * wv[k] * (int)r[cx[k]];
+                }
+                const int o = rne_shift(acc, 8);
+                nxt[y * wo + xo] = (uint8_t)o;
+                if (x >= own_a && x < own_b) out[(size_t)y * Lo.pitch + x] = (int16_t)o;
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
 // ---- vectorised pyrDown: 2 output rows x 4 output columns per thread --------------------------------
 // Needs input width % 8 == 0 (true for every level l <= nb-3 because padded views are multiples of 2^nb).
 // One input row contributes columns [8t-2, 8t+8]: a 16-byte (int16) / 8-byte (u8) aligned body plus a
@@ -431,13 +534,6 @@ __device__ __forceinline__ void unpack8(const uint2 b, int v[8])
 {
     v[0] = b.x & 0xff; v[1] = (b.x >> 8) & 0xff; v[2] = (b.x >> 16) & 0xff; v[3] = b.x >> 24;
     v[4] = b.y & 0xff; v[5] = (b.y >> 8) & 0xff; v[6] = (b.y >> 16) & 0xff; v[7] = b.y >> 24;
-}
-// 16 bytes from a 4-byte aligned address as one global_load_dwordx4
-__device__ __forceinline__ uint4 load16_a4(const void *p)
-{
-    uint4 r;
-    __builtin_memcpy(&r, __builtin_assume_aligned(p, 4), 16);
-    return r;
 }
 __device__ __forceinline__ uint2 load8_a1(const void *p)
 {
@@ -981,6 +1077,7 @@ struct ms_ctx {
     bool blend_vec[MAX_LEVELS] = {};   // band l may use the 2x8 kernel
     // work lists (tiles that are actually needed)
     bool warp_tiled = false;
+    int tail_l0 = -1, tail_lds = 0, tail_strips = 1;    // fused coarse-level reduce (k_down_tail): first level it reads, LDS bytes; -1 = off
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0;
@@ -1522,6 +1619,27 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         }
         c->down_vec[l] = ok;
     }
+    {   // coarse levels that the tile kernel cannot take (width not a multiple of 8) go to one fused launch if a plane chain fits in LDS
+        int t0 = 0;
+        while (t0 < nb && c->down_vec[t0]) ++t0;
+        c->tail_l0 = -1; c->tail_lds = 0;
+        if (t0 >= 1 && t0 < nb) {          // level t0 is int16 (t0 >= 1); the u8 level 0 never starts a tail
+            int need = 0, strips = 1;
+            for (int v = 0; v < N; ++v) {
+                int w[MAX_LEVELS + 1], a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
+                for (int l = t0; l <= nb; ++l) w[l] = c->h_views[v].lv[l].w;
+                const int ns = div_up(w[nb], TAIL_STRIP);
+                strips = std::max(strips, ns);
+                for (int sidx = 0; sidx < ns; ++sidx) {
+                    tail_range(w, t0, nb, sidx, a, b);
+                    int bytes = 0;
+                    for (int l = t0; l <= nb; ++l) bytes += ((b[l] - a[l]) * c->h_views[v].lv[l].h + 15) & ~15;
+                    need = std::max(need, bytes);
+                }
+            }
+            if (need <= 64 * 1024) { c->tail_l0 = t0; c->tail_lds = need; c->tail_strips = strips; }
+        }
+    }
     for (int l = 0; l < nb; ++l) {
         int qw = c->bg.dst_roi.width >> l, qh = c->bg.dst_roi.height >> l;
         bool ok = (qw % 8 == 0) && (qh % 2 == 0);
@@ -1841,6 +1959,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (int e = mark("k_warp")) return e;
 
     for (int l = 0; l < nb; ++l) {
+        if (l == c->tail_l0 && c->cfg.reserved[0] == 0) {
+            k_down_tail<<<dim3(F * N * 3 * c->tail_strips), blk, c->tail_lds, st>>>(vt, N, l, nb, c->tail_strips, gl, c->gl_stride, c->own_mask);
+            MS_LAUNCH_CHECK();
+            if (int e = mark("k_down_tail")) return e;
+            break;
+        }
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
         if (c->down_vec[l] && c->cfg.reserved[0] == 0) {   // level-l widths are multiples of 8: tile list, 2 rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
