@@ -112,7 +112,7 @@ def test_full_size_config2_matches_oracle(ms, cuda, oracle):
     comp.close()
 
 
-@pytest.mark.parametrize("rig,cpw", [("cfg2", False), ("mini6", True), ("mini4", False)])
+@pytest.mark.parametrize("rig,cpw", [("cfg2", False), ("cfg2", True), ("cfg5", False), ("mini6", True), ("mini4", False)])
 def test_tiled_kernels_equal_simple_kernels(ms, cuda, rig, cpw):
     """The work-list / multi-pixel-per-lane kernels against the one-pixel-per-lane kernels (same library,
     debug switch): identical 16S panorama, also where whole tiles are skipped as zero-weight."""
@@ -247,6 +247,37 @@ def test_feather_blender_matches_oracle(ms, cuda, oracle, rig):
         assert np.array_equal(host(out8[t]), canvas_from(ref16, pg, out[0], out[1]))
     # feathering really happens: inside the overlap the result mixes both views
     assert refmask.any() and (host(out16[0]) != 0).any()
+    comp.close()
+
+
+@pytest.mark.parametrize("proj", ["cylindrical", "plane"])
+def test_other_projections_match_oracle(ms, cuda, oracle, proj):
+    """The three *WarperGpu projections share the per-frame path (warpers_cuda.cpp:149-277): cylindrical on the 4-view rig,
+    plane on two views 30 deg apart (a plane cannot hold a full circle).  ROIs equal the oracle's warpRoi, the 16S result is exact."""
+    import math
+    if proj == "cylindrical":
+        pid, n, w, h, hfov = ms.PROJ_CYLINDRICAL, 4, 200, 150, 110.0
+        cams = [synth.camera(n, w, h, hfov, i) for i in range(n)]
+        sc, out = synth.warp_scale(512), (512, 256)
+    else:
+        pid, n, w, h = ms.PROJ_PLANE, 2, 240, 160
+        cams = [synth.camera(1, w, h, 70.0, 0, yaw=math.radians(a)) for a in (-15.0, 15.0)]
+        sc, out = 170.0, (0, 0)
+    gains = [1.0 - 0.03 * i for i in range(n)]
+    comp = ms.Compositor(n, (w, h), pid, sc, num_bands=3, out_size=out)
+    for i, (K, R) in enumerate(cams):
+        comp.set_camera(i, K, R); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    for i, (K, R) in enumerate(cams):
+        assert comp.view_geom(i).roi.tuple() == oracle.warp_roi(pid, K, R, sc, w, h)
+    frames = [synth.frame(w, h, i, 2) for i in range(n)]
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    ref16, refmask = run_oracle(oracle, comp, dict(n=n, num_bands=3), gains, frames)
+    assert np.array_equal(host(out16), ref16) and np.array_equal(host(comp.result_mask()), refmask)
+    assert refmask.mean() > 100          # most of the ROI is covered
     comp.close()
 
 
