@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--view-shards", type=int, default=1,
                     help="BASELINE configs[4]: split the VIEWS of every frame over this many ranks (partial int16 accumulators sent to the "
                          "group's sink rank, which finishes the frame); world must be a multiple of it (world 1 = both shards on one GPU)")
+    ap.add_argument("--recalib-every", type=int, default=60,
+                    help="cfg3 only: re-expand new CPW meshes (ms_set_mesh x views) every this many frames, inside the timed region "
+                         "(BASELINE configs[2]: recalibrate every 60 f); 0 = never")
     ap.add_argument("--streams", type=int, default=1, help="split the F frames of a step over this many contexts/HIP streams")
     args = ap.parse_args()
 
@@ -324,10 +327,25 @@ def main():
     pending = [None, None]
     y0 = pg.canvas_y
 
+    mesh_pool = []
+    if cpw and args.recalib_every > 0:       # pre-generated meshes (the optimiser that produces them is out of scope): 4 phases, cycled
+        for ph in range(4):
+            mesh_pool.append([synth.mesh(comp.view_geom(i).roi.width, comp.view_geom(i).roi.height, 40, 40, phase=0.1 * i + 0.7 * (ph + 1))
+                              for i in range(cfg["n"])])
+    recal = {"frames": 0, "count": 0}
+
     def step(s):
         b = s & 1
         if pending[b] is not None:
             pending[b].wait(); pending[b] = None
+        if mesh_pool:
+            recal["frames"] += F
+            if recal["frames"] >= args.recalib_every:
+                recal["frames"] -= args.recalib_every
+                for cc in comps:
+                    for i in range(cfg["n"]):
+                        cc.set_mesh(i, *mesh_pool[recal["count"] % 4][i])
+                recal["count"] += 1
         runs[b]()
         if gather:
             for j in range(F):   # the pano ROI rows of each canvas are one contiguous slab
@@ -407,10 +425,11 @@ def main():
             "ms_per_frame": round(elapsed / args.steps / F * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in / int16+fp32 pyramid arithmetic", "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, spherical, %d bands, CPW %s; "
+            "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, spherical, %d bands, CPW %s%s; "
                                    "%d frames per step per GPU on %d HIP stream(s), inputs resident in HBM"
                                    % (args.config, cfg["n"], cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"],
-                                      pg.num_bands, "on (40x40 mesh)" if cpw else "off", F, S),
+                                      pg.num_bands, "on (40x40 mesh)" if cpw else "off",
+                                      (", meshes re-expanded every %d frames" % args.recalib_every) if mesh_pool else "", F, S),
                        "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s%s" % (world, (", RCCL gather of the %s pano rows on rank 0 (%.1f MB/frame), overlapped" % (args.gather_format.upper(), slabs[0][0].numel() / 1e6)) if gather else "",
                                                                   " [DEBUG: ranks share one GPU, gloo]" if share else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
