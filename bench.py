@@ -98,7 +98,14 @@ def cpu_baseline(cfg, gains, comp, budget_s=12.0):
             break
     fps_all = n / el
     b.close()
-    return {"value": round(fps_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": round(fps_all, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": model,
             "sample": "%d config-2 frames (6x1080p -> 3839x627 pano ROI, 5 bands) in %.1f s with %d OpenMP threads "
                       "(best of 1/8/16/32/64 on a %d-CPU host); 1 thread: %.0f ms/frame" % (n, el, cores, ncpu, one_thread * 1e3)}
 
@@ -398,6 +405,9 @@ def main():
         for name, ms_t in comp.stitch_timed(frames[:Fs], out8u=outs[0][:Fs]):
             acc.setdefault(name, []).append(ms_t)
     kmean = {k: float(np.mean(v)) for k, v in acc.items()}
+    per_call = np.sum(np.array([acc[k] for k in acc]), axis=0)        # GPU ms of each instrumented ms_stitch call (sum of its kernels)
+    lat = {"gpu_ms_per_step_p50": round(float(np.percentile(per_call, 50)), 5), "gpu_ms_per_step_p95": round(float(np.percentile(per_call, 95)), 5),
+           "calls": int(per_call.size), "frames_per_call": Fs}
     kb, sumP, Q, A = kernel_bytes(comp, cfg, Fs, cpw)
     dom = max(kmean, key=kmean.get)
     achieved = kb[dom] / (kmean[dom] * 1e-3) / 1e9          # GB/s
@@ -440,6 +450,7 @@ def main():
                                "frac": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),
                                "wall_frac": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4)},
             "kernels_ms_per_step": {k: round(v, 5) for k, v in kmean.items()},
+            "latency": lat,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, gains, comp)
