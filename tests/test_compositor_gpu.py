@@ -133,6 +133,32 @@ def test_tiled_kernels_equal_simple_kernels(ms, cuda, rig, cpw):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("amp", [20.0, 60.0])
+def test_cpw_stage1_short_list_and_fallback(ms, cuda, oracle, amp):
+    """CPW stage 1 only warps the tiles stage 2 can reach while the mesh displaces by <= 32 px (measured at ms_set_mesh); a mesh that
+    moves samples further falls back to whole views.  Both sides of the threshold against the oracle, with a mesh change in between
+    (the stage buffer then holds stale tiles of the previous mesh, which must never be sampled)."""
+    comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    frames = [synth.frame(cfg["w"], cfg["h"], i, 3) for i in range(cfg["n"])]
+    for a in (60.0 if amp < 32 else 5.0, amp):          # first the other regime, then the one under test
+        meshes = []
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            mx, my = synth.mesh(r.width, r.height, 9, 11, phase=0.3 * i, amp=a)
+            comp.set_mesh(i, mx, my)
+            dmx, dmy = comp.mesh_maps(i)
+            meshes.append((host(dmx), host(dmy)))
+        comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+        torch.cuda.synchronize()
+        d = max(comp.mesh_displacement(i) for i in range(cfg["n"]))
+        assert (d > 32.0) == (a > 32.0) and 0.5 * a < d < 1.5 * a          # measured on the device at ms_set_mesh
+    ref16, refmask = run_oracle(oracle, comp, cfg, gains, frames, meshes=meshes)
+    assert np.array_equal(host(out16), ref16)
+    comp.close()
+
+
 @pytest.mark.parametrize("rig", ["cfg2", "mini4"])
 def test_lds_staged_warp_equals_direct(ms, cuda, rig):
     """Opt-in variant of the warp kernel that stages each tile's source bounding box through LDS (16-byte chunk copy,

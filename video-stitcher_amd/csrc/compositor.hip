@@ -1081,6 +1081,7 @@ struct ms_ctx {
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0;
+    DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
     size_t warp_lds_bytes = 0;         // dynamic LDS of k_warp_t: largest staged source tile
     int warp_lds_tiles = 0;
@@ -1094,6 +1095,12 @@ struct ms_ctx {
     std::mutex mesh_mu;
     hipEvent_t last_stitch = nullptr;
     bool stitch_pending = false;
+    // asynchronous recalibration: a mesh update only enqueues work; `mesh_ready[v]` is recorded behind it and the next ms_stitch makes
+    // its stream wait for it; `mesh_chain` orders updates among themselves (they share the scratch and the staging buffers)
+    hipEvent_t mesh_ready[MAX_VIEWS] = {}, mesh_chain = nullptr;
+    bool mesh_wait[MAX_VIEWS] = {}, mesh_chain_set = false;
+    float *mesh_stage = nullptr;       // pinned host staging of the vertex meshes
+    size_t mesh_stage_floats = 0;
     int canvas_x = 0, canvas_y = 0;
     // view sharding (ms_config.reserved[3] = shard count S, [4] = this shard's index): contiguous blocks of views per shard
     unsigned own_mask = 0xffffffffu;
@@ -1130,6 +1137,7 @@ namespace ms {
 namespace {
 
 using Bits = std::vector<uint8_t>;
+constexpr int CPW_DMAX = 32;      // px; meshes that displace further fall back to warping whole views in CPW stage 1
 
 Bits dilate(const Bits &s, int w, int h, int r)
 {
@@ -1265,12 +1273,39 @@ static int build_plan(ms_ctx *c)
         }
     }
     c->plan_fraction = tot0 > 0 ? need0 / tot0 : 1.0;
-    if (c->cfg.enable_cpw) {   // CPW stage 1 covers the whole warped view: the mesh (hence what stage 2 samples) changes at recalibration
+    if (c->cfg.enable_cpw) {
+        // CPW stage 1 covers the whole warped view (the mesh, hence what stage 2 samples, changes at recalibration), but while a mesh
+        // moves no sample further than CPW_DMAX px (measured on the device when it is set) stage 2 can only read stage-1 pixels
+        // within CPW_DMAX + 2 of the level-0 pixels some consumer needs: those tiles carry flag bit 1, the others exit early.
         std::vector<WarpTile> tiles;
-        for (int v = 0; v < N; ++v)
-            if ((c->own_mask >> v) & 1u)
-            for (int y0 = 0; y0 < c->h_views[v].ah; y0 += WARP_TH)
-                for (int x0 = 0; x0 < c->h_views[v].aw; x0 += WARP_TW) { WarpTile t{}; t.view = (short)v; t.x0 = (short)x0; t.y0 = (short)y0; tiles.push_back(t); }
+        for (int v = 0; v < N; ++v) {
+            if (!((c->own_mask >> v) & 1u)) continue;
+            const ViewDesc &V = c->h_views[v];
+            Bits a((size_t)V.aw * V.ah, 0);
+            for (int y = 0; y < V.ph; ++y)
+                for (int x = 0; x < V.pw; ++x)
+                    if (Nd[v][0][(size_t)y * V.pw + x]) {
+                        int ax = x - V.left, ay = y - V.top;      // BORDER_REFLECT back into the warped view
+                        ax = ax < 0 ? -ax - 1 : (ax >= V.aw ? 2 * V.aw - ax - 1 : ax);
+                        ay = ay < 0 ? -ay - 1 : (ay >= V.ah ? 2 * V.ah - ay - 1 : ay);
+                        a[(size_t)std::min(std::max(ay, 0), V.ah - 1) * V.aw + std::min(std::max(ax, 0), V.aw - 1)] = 1;
+                    }
+            const int D = CPW_DMAX + 2;
+            for (int y0 = 0; y0 < V.ah; y0 += WARP_TH)
+                for (int x0 = 0; x0 < V.aw; x0 += WARP_TW) {
+                    WarpTile t{}; t.view = (short)v; t.x0 = (short)x0; t.y0 = (short)y0;
+                    t.flags = any_in(a, V.aw, V.ah, x0 - D, y0 - D, WARP_TW + 2 * D, WARP_TH + 2 * D) ? 2 : 0;
+                    tiles.push_back(t);
+                }
+        }
+        if (getenv("MS_DEBUG_PLAN")) { int nf = 0; for (auto &t : tiles) nf += (t.flags & 2) != 0; fprintf(stderr, "[plan] stage-1 tiles %zu, reachable within %d px: %d\n", tiles.size(), CPW_DMAX, nf); }
+        {   // reachable tiles first, each part in XCD order on its own: when the others exit early every XCD still gets an equal share
+            std::vector<WarpTile> a, b;
+            for (const WarpTile &t : tiles) ((t.flags & 2) ? a : b).push_back(t);
+            if (c->cfg.reserved[2] == 0) { xcd_order(a); xcd_order(b); }
+            tiles = a;
+            tiles.insert(tiles.end(), b.begin(), b.end());
+        }
         c->n_stage1_tiles = (int)tiles.size();
         if (int e = c->stage1_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
         MS_HIP(hipMemcpy(c->stage1_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
@@ -1354,6 +1389,9 @@ void ms_destroy(ms_ctx *c)
     c->warp_tiles.release(); c->stage1_tiles.release();
     for (int l = 0; l < MAX_LEVELS; ++l) { c->down_tiles[l].release(); c->blend_tiles[l].release(); }
     if (c->last_stitch) (void)hipEventDestroy(c->last_stitch);
+    for (int v = 0; v < MAX_VIEWS; ++v) if (c->mesh_ready[v]) (void)hipEventDestroy(c->mesh_ready[v]);
+    if (c->mesh_chain) (void)hipEventDestroy(c->mesh_chain);
+    if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
     delete c;
 }
 
@@ -1779,6 +1817,35 @@ int ms_init_feather(ms_ctx *c, float sharpness, ms_stream stream)
     return ms_init_blender(c, stream);
 }
 
+// max over the view of |x_mesh - x|, |y_mesh - y| (NaN = hole of convertMeshesToMap: samples nothing, ignored); non-negative floats
+// order like their bit patterns, so one atomicMax on the bits reduces the launch
+__global__ void __launch_bounds__(256) k_mesh_disp(const float *__restrict__ mx, const float *__restrict__ my, int pitch, int ah, int aw, unsigned *out)
+{
+    float d = 0.f;
+    for (int y = blockIdx.x; y < ah; y += gridDim.x)            // a block walks rows, grid-stride: few atomics on the one result word
+        for (int x = threadIdx.x; x < aw; x += 256) {
+            const float a = fabsf(mx[(size_t)y * pitch + x] - (float)x), b = fabsf(my[(size_t)y * pitch + x] - (float)y);
+            d = fmaxf(d, fmaxf(a == a ? a : 0.f, b == b ? b : 0.f));
+        }
+    for (int o = 32; o > 0; o >>= 1) d = fmaxf(d, __shfl_xor(d, o));
+    if ((threadIdx.x & 63) == 0 && d > 0.f) atomicMax(out, __float_as_uint(d));
+}
+static int measure_mesh_disp(ms_ctx *c, int view, int tgt, hipStream_t st)
+{
+    if (!c->disp_dev.p) {
+        if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
+        MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));      // "unbounded" until measured
+    }
+    const int aw = c->roi[view].width, ah = c->roi[view].height;
+    const float *base = (const float *)c->mesh[tgt].p + c->mesh_off[view];
+    unsigned *word = (unsigned *)c->disp_dev.p + 2 * view + tgt;
+    MS_HIP(hipMemsetAsync(word, 0, sizeof(unsigned), st));
+    k_mesh_disp<<<std::min(ah, 128), 256, 0, st>>>(base, base + (size_t)ah * c->map_pitch[view], c->map_pitch[view], ah, aw, word);
+    MS_LAUNCH_CHECK();
+    MS_HIP(hipStreamSynchronize(st));
+    return MS_OK;
+}
+
 // ---- CPW mesh maps ------------------------------------------------------------------------------
 static ms_image mesh_image(const ms_ctx *c, int buf, int v, int which)
 {
@@ -1787,12 +1854,27 @@ static ms_image mesh_image(const ms_ctx *c, int buf, int v, int which)
     return ms_image{base, (size_t)c->map_pitch[v] * sizeof(float), ah, aw, MS_32FC1};
 }
 
-static int mesh_begin_update(ms_ctx *c, int view, int *target)
+static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st)
 {
     if (!c->blender_ready || !c->cfg.enable_cpw) return fail(MS_ERR_STATE, "mesh update needs enable_cpw and ms_init_blender");
     *target = c->mesh_set[view] ? 1 - c->mesh_active[view] : c->mesh_active[view];
-    // the inactive buffer may still be read by a stitch enqueued before the previous swap
-    if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
+    if (!c->mesh_ready[view]) MS_HIP(hipEventCreateWithFlags(&c->mesh_ready[view], hipEventDisableTiming));
+    if (!c->mesh_chain) MS_HIP(hipEventCreateWithFlags(&c->mesh_chain, hipEventDisableTiming));
+    // the inactive buffer may still be read by a stitch enqueued before the previous swap: the update waits for it ON THE GPU
+    // (the reference releases its mutex before the async remap finishes, timed.cpp:98-103); no host synchronisation anywhere
+    if (c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
+    if (c->mesh_chain_set) MS_HIP(hipStreamWaitEvent(st, c->mesh_chain, 0));
+    return MS_OK;
+}
+static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st)
+{
+    if (int e = measure_mesh_disp(c, view, tgt, st)) return e;
+    MS_HIP(hipEventRecord(c->mesh_ready[view], st));
+    MS_HIP(hipEventRecord(c->mesh_chain, st));
+    c->mesh_chain_set = true;
+    c->mesh_wait[view] = true;
+    c->mesh_active[view] = tgt;
+    c->mesh_set[view] = true;
     return MS_OK;
 }
 
@@ -1802,18 +1884,15 @@ int ms_set_mesh_maps(ms_ctx *c, int view, const ms_image *xm, const ms_image *ym
     MS_CHECK(xm && ym && xm->data && ym->data, "ms_set_mesh_maps: null image");
     std::lock_guard<std::mutex> lk(c->mesh_mu);
     int tgt;
-    if (int e = mesh_begin_update(c, view, &tgt)) return e;
+    hipStream_t st = as_stream(stream);
     const int aw = c->roi[view].width, ah = c->roi[view].height;
     MS_CHECK(xm->rows == ah && xm->cols == aw && ym->rows == ah && ym->cols == aw && xm->type == MS_32FC1 && ym->type == MS_32FC1,
              "ms_set_mesh_maps: maps must be 32FC1 %dx%d", aw, ah);
-    hipStream_t st = as_stream(stream);
+    if (int e = mesh_begin_update(c, view, &tgt, st)) return e;
     ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
     MS_HIP(hipMemcpy2DAsync(dx.data, dx.step, xm->data, xm->step, (size_t)aw * 4, ah, hipMemcpyDeviceToDevice, st));
     MS_HIP(hipMemcpy2DAsync(dy.data, dy.step, ym->data, ym->step, (size_t)aw * 4, ah, hipMemcpyDeviceToDevice, st));
-    MS_HIP(hipStreamSynchronize(st));
-    c->mesh_active[view] = tgt;
-    c->mesh_set[view] = true;
-    return MS_OK;
+    return mesh_end_update(c, view, tgt, st);
 }
 
 int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, int N, int M, ms_stream stream)
@@ -1822,18 +1901,32 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     MS_CHECK(mesh_x && mesh_y && N >= 2 && M >= 2, "ms_set_mesh: need an N x M (>= 2x2) vertex mesh");
     std::lock_guard<std::mutex> lk(c->mesh_mu);
     int tgt;
-    if (int e = mesh_begin_update(c, view, &tgt)) return e;
     hipStream_t st = as_stream(stream);
     const int aw = c->roi[view].width, ah = c->roi[view].height, hw = aw / 2, hh = ah / 2;
     MS_CHECK(hw >= 2 && hh >= 2, "ms_set_mesh: view too small");
     // scratch: small mesh x|y, big x|y (ah x aw), half-res sum_x|sum_y|cnt
     const size_t n_small = (size_t)N * M, n_big = (size_t)aw * ah, n_half = (size_t)hw * hh;
     const size_t need = (2 * n_small + 2 * n_big + 3 * n_half) * sizeof(float);
-    if (c->mesh_tmp.bytes < need) if (int e = c->mesh_tmp.alloc(need)) return e;
+    if (c->mesh_tmp.bytes < need || c->mesh_stage_floats < 2 * n_small) {     // (re)allocation: first call or a larger mesh -- drain earlier updates first
+        if (c->mesh_chain_set) MS_HIP(hipEventSynchronize(c->mesh_chain));
+        if (c->mesh_tmp.bytes < need) if (int e = c->mesh_tmp.alloc(need)) return e;
+        if (c->mesh_stage_floats < 2 * n_small) {
+            if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
+            c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
+            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, 2 * n_small * sizeof(float) * MAX_VIEWS, hipHostMallocDefault));
+            c->mesh_stage_floats = 2 * n_small;
+        }
+    }
+    if (int e = mesh_begin_update(c, view, &tgt, st)) return e;
     float *sm_x = (float *)c->mesh_tmp.p, *sm_y = sm_x + n_small, *big_x = sm_y + n_small, *big_y = big_x + n_big;
     float *sx = big_y + n_big, *sy = sx + n_half, *cnt = sy + n_half;
-    MS_HIP(hipMemcpyAsync(sm_x, mesh_x, n_small * 4, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(sm_y, mesh_y, n_small * 4, hipMemcpyHostToDevice, st));
+    // the caller's arrays may be freed right after return: stage them in pinned memory (one slot per view; a slot is reused only by
+    // the next update of the same view, whose copy of the previous one finished long before -- checked on its event)
+    if (c->mesh_wait[view] || c->mesh_set[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    float *stg = c->mesh_stage + (size_t)view * c->mesh_stage_floats;
+    memcpy(stg, mesh_x, n_small * 4);
+    memcpy(stg + n_small, mesh_y, n_small * 4);
+    MS_HIP(hipMemcpyAsync(sm_x, stg, 2 * n_small * 4, hipMemcpyHostToDevice, st));
     MS_HIP(hipMemsetAsync(sx, 0, 3 * n_half * 4, st));
     ms_image smx{sm_x, (size_t)M * 4, N, M, MS_32FC1}, smy{sm_y, (size_t)M * 4, N, M, MS_32FC1};
     ms_image bx{big_x, (size_t)aw * 4, ah, aw, MS_32FC1}, by{big_y, (size_t)aw * 4, ah, aw, MS_32FC1};
@@ -1847,9 +1940,17 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
     if (int e = launch_custom_resize(hx, dx, st)) return e;             // :880,883
     if (int e = launch_custom_resize(hy, dy, st)) return e;
-    MS_HIP(hipStreamSynchronize(st));
-    c->mesh_active[view] = tgt;
-    c->mesh_set[view] = true;
+    return mesh_end_update(c, view, tgt, st);
+}
+
+int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    MS_CHECK(out_px != nullptr, "ms_get_mesh_displacement: null output");
+    std::lock_guard<std::mutex> lk(c->mesh_mu);
+    if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view] || !c->disp_dev.p) return fail(MS_ERR_STATE, "ms_get_mesh_displacement: no mesh set for view %d", view);
+    MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    MS_HIP(hipMemcpy(out_px, (const unsigned *)c->disp_dev.p + 2 * view + c->mesh_active[view], sizeof(float), hipMemcpyDeviceToHost));
     return MS_OK;
 }
 
@@ -1897,10 +1998,14 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     }
     MeshTable mesh{};
     const bool cpw = c->cfg.enable_cpw != 0;
+    DispTable disp{};
+    { const float lim = (float)CPW_DMAX; memcpy(&disp.limit_bits, &lim, 4); }
     if (cpw) {
         std::lock_guard<std::mutex> lk(c->mesh_mu);
         for (int v = 0; v < N; ++v) {
             if (!c->mesh_set[v]) return fail(MS_ERR_STATE, "ms_stitch: enable_cpw is set but view %d has no mesh", v);
+            disp.p[v] = (const unsigned *)c->disp_dev.p + 2 * v + c->mesh_active[v];
+            if (c->mesh_wait[v]) { MS_HIP(hipStreamWaitEvent(st, c->mesh_ready[v], 0)); c->mesh_wait[v] = false; }
             ms_image mx = mesh_image(c, c->mesh_active[v], v, 0), my = mesh_image(c, c->mesh_active[v], v, 1);
             mesh.x[v] = (const float *)mx.data; mesh.y[v] = (const float *)my.data; mesh.pitch[v] = c->map_pitch[v];
         }
@@ -1930,7 +2035,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (cpw) {
         if (c->cfg.reserved[0] == 0)
             k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(16, 16), 0, st>>>(
-                (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
+                (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
@@ -2126,6 +2231,7 @@ int ms_get_mesh_maps(const ms_ctx *c, int view, ms_image *xm, ms_image *ym)
 {
     if (int e = ctx_check_view(c, view)) return e;
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view]) return fail(MS_ERR_STATE, "ms_get_mesh_maps: no mesh set for view %d", view);
+    if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));       // updates are asynchronous: the maps are final after this
     if (xm) *xm = mesh_image(c, c->mesh_active[view], view, 0);
     if (ym) *ym = mesh_image(c, c->mesh_active[view], view, 1);
     return MS_OK;

@@ -58,6 +58,9 @@ struct ShardArgs {
 };
 struct SrcTable { const uint8_t *p[MAX_SRC]; unsigned step[MAX_SRC]; };
 struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pitch[MAX_VIEWS]; };
+// max |mesh map - identity| of the active mesh of each view, as float bits in device memory (written by ms_set_mesh), and the bound
+// under which CPW stage 1 may skip the tiles stage 2 cannot reach (WarpTile::flags bit 1 = reachable within that bound)
+struct DispTable { const unsigned *p[MAX_VIEWS]; unsigned limit_bits; };
 struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *p16[MAX_FRAMES]; unsigned step16[MAX_FRAMES]; };
 
 

@@ -400,10 +400,12 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
 // ---- CPW stage 1: images[i] = gain(remap(full_img, x_map, y_map)) (timed.cpp:90-94), 4 px per lane --------------
 // Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).
 __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
-                                                  SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
+                                                  SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp)
 {
     const WarpTile T = tiles[blockIdx.x];
     const int f = blockIdx.z, v = T.view;
+    // the mesh of this view moves no sample further than the bound the plan assumed: stage 2 never reads this tile
+    if (!(T.flags & 2) && *disp.p[v] <= disp.limit_bits) return;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
     if (x >= V.aw || y >= V.ah) return;
