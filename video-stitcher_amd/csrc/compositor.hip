@@ -1264,7 +1264,7 @@ static int build_plan(ms_ctx *c)
         if (!tiles.empty()) {
             MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
             if (c->warp_tiled) {   // source bounding box of every tile (static: the projection maps do not change per frame)
-                k_tile_bbox<<<c->n_warp_tiles, dim3(16, 16)>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width);
+                k_tile_bbox<<<c->n_warp_tiles, dim3(WARP_BX, WARP_TH)>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width);
                 MS_LAUNCH_CHECK();
                 MS_HIP(hipMemcpy(tiles.data(), c->warp_tiles.p, tiles.size() * sizeof(WarpTile), hipMemcpyDeviceToHost));
                 for (const WarpTile &t : tiles)
@@ -2034,7 +2034,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
         if (c->cfg.reserved[0] == 0)
-            k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(16, 16), 0, st>>>(
+            k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, WARP_TH), 0, st>>>(
                 (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
@@ -2042,7 +2042,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
-            k_warp_t<true, false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), 0, st>>>(
+            k_warp_t<true, false><<<dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st>>>(
                 (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
@@ -2051,10 +2051,10 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         int lds_ok = c->cfg.reserved[1] != 0 && c->warp_lds_bytes > 0;   // opt-in: LDS staging of the source tiles (measured slower than direct gathers)
         for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
         if (lds_ok)
-            k_warp_t<false, true><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), c->warp_lds_bytes, st>>>(
+            k_warp_t<false, true><<<dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st>>>(
                 (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1);
         else
-            k_warp_t<false, false><<<dim3(c->n_warp_tiles, 1, F), dim3(16, WARP_BY), 0, st>>>(
+            k_warp_t<false, false><<<dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st>>>(
                 (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(

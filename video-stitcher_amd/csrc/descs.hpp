@@ -72,7 +72,12 @@ struct WarpTile { short view, flags; short x0, y0; short sx0, sy0, sw, sh; };   
 struct DownTile { short view, pad; short x0, y0; };                              // output (level l+1) tile origin
 struct BlendTile { short x0, y0; unsigned view_mask; };                          // pano tile origin + contributing views
 
-constexpr int WARP_TW = 64, WARP_TH = 16;      // k_warp_t tile (4 px per thread, 16 x 16 threads)
+#ifndef MS_WARP_TW
+#define MS_WARP_TW 32
+#define MS_WARP_TH 16
+#endif
+constexpr int WARP_TW = MS_WARP_TW, WARP_TH = MS_WARP_TH;      // k_warp_t tile (4 px per lane)
+constexpr int WARP_BX = WARP_TW / 4;            // lanes across a tile row
 constexpr int DOWN_TW = 128, DOWN_TH = 16;     // k_down_t output tile (4 x 2 px per thread, 32 x 8 threads)
 constexpr int BLEND_TW = 256, BLEND_TH = 16;   // k_blend8_t tile (8 x 2 px per thread, 32 x 8 threads)
 

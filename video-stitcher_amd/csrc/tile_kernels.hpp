@@ -208,10 +208,10 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
 #define MS_WARP_NG 2
 #endif
 constexpr int WARP_NG = MS_WARP_NG;
-constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = 16 x WARP_BY lanes
+constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = WARP_BX x WARP_BY lanes
 
 template <bool CPW, bool STAGED>
-__global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+__global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
                                                          uint8_t *__restrict__ g0, long long g0_stride, int lds_ok)
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(16 * WARP_BY) k_warp_t(const WarpTile *__restr
         for (int r = (int)threadIdx.y; r < T.sh; r += WARP_BY) {
             const uint8_t *row = tile0 + (size_t)r * sstep;
             const uint8_t *arow = row - ((size_t)row & 15);
-            for (int ch = (int)threadIdx.x; ch < nch; ch += 16) {
+            for (int ch = (int)threadIdx.x; ch < nch; ch += WARP_BX) {
                 const uint8_t *p = arow + 16 * ch;
                 uint4 q;
                 if (p + 16 <= img_end) q = *reinterpret_cast<const uint4 *>(p);
