@@ -15,4 +15,8 @@ for f in prims.hip compositor.hip api.cpp geometry.cpp; do
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || { echo "compile failed" >&2; exit 1; }; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmsstitch.so ../build/prims.o ../build/compositor.o ../build/api.o ../build/geometry.o
+# C++ host pipeline over the C-ABI (thread / queue graph of the reference's timed.cpp); host code only, links the library above
+if [ ! -f ../stitch_app ] || [ ../host/stitch_app.cpp -nt ../stitch_app ] || [ ../shim/ms_shim.hpp -nt ../stitch_app ] || [ ../../include/ms_stitch.h -nt ../stitch_app ]; then
+  $HIPCC -O2 -std=c++17 -Wall -Wno-unused-result -pthread ../host/stitch_app.cpp -I../../include -L.. -lmsstitch -Wl,-rpath,'$ORIGIN' -o ../stitch_app
+fi
 echo "built $(cd .. && pwd)/libmsstitch.so"

@@ -1,0 +1,279 @@
+// stitch_app.cpp -- C++ host pipeline over the C-ABI, with the thread / queue graph of the reference's main loop
+// (360_stitcher/timed.cpp): capture -> LockableVector of the newest frame per camera -> stitch_one (upload, compositor,
+// push) -> BlockingQueue -> consume (8U panorama, optional I420 for the encoder) and a recalibration thread that swaps
+// CPW meshes while frames keep flowing.  No OpenCV: device images are plain HIP allocations wrapped as ms_image.
+//
+//   reference                                   here
+//   ------------------------------------------  ---------------------------------------------------------------
+//   stitch_calib / warpImages (calibration.cpp)  calibrate(): ms_set_camera/gain, ms_build_maps, ms_build_masks, ms_init_blender
+//   LockableVector<Mat> imgs (lockablevector.h)  Lockable<std::vector<HostFrame>>
+//   capture threads (networking.cpp / debug)     capture(): synthetic frames (same pattern as video-stitcher_amd/synth.py, noise off)
+//   stitch_one (timed.cpp:123-152)               stitch_one(): hipMemcpy2DAsync x N + msshim::Compositor::stitch_one + results.push
+//   BlockingQueue<GpuMat> results                BlockingQueue<Slot*>
+//   consume (timed.cpp:232-330)                  consume(): optional ms_bgr_to_i420, download, checksum / dump
+//   recalibrate thread (timed.cpp:414-463)       recalibrate(): ms_set_mesh per view from its own stream
+//
+// Usage: stitch_app [--views 6] [--size 1920x1080] [--out 3840x1920] [--hfov 90] [--bands 5] [--frames 300] [--cpw]
+//                   [--i420] [--dump pano.bin] [--no-upload]
+// Prints one JSON line: end-to-end frames/s INCLUDING the PCIe upload of every source frame (unlike bench.py).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../shim/ms_shim.hpp"
+
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+// ---- the two containers of the reference's thread graph -------------------------------------------------------
+template <class T> struct Lockable {           // lockablevector.h: a value + the mutex every user takes
+    T v;
+    std::mutex mu;
+};
+template <class T> class BlockingQueue {       // blockingqueue.h: unbounded push, blocking pop
+public:
+    void push(T x) { { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(x)); } cv_.notify_one(); }
+    T pop() { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return !q_.empty(); }); T x = std::move(q_.front()); q_.pop_front(); return x; }
+private:
+    std::mutex mu_; std::condition_variable cv_; std::deque<T> q_;
+};
+
+// ---- a device image with the fields the shim expects (cv::cuda::GpuMat's) -------------------------------------
+struct DevMat {
+    int rows = 0, cols = 0, flags = 0;
+    size_t step = 0;
+    unsigned char *data = nullptr;
+    int type() const { return flags; }
+    void create(int r, int c, int t, int elem, bool contiguous = false)
+    {
+        if (data && r == rows && c == cols && t == flags) return;       // GpuMat::create is a no-op when nothing changes
+        if (data) HIPCHECK(hipFree(data));
+        size_t pitch = (size_t)c * elem;
+        if (contiguous) HIPCHECK(hipMalloc((void **)&data, pitch * r));  // (the I420 planes are one contiguous buffer, like the Mat cvtColor fills)
+        else HIPCHECK(hipMallocPitch((void **)&data, &pitch, (size_t)c * elem, r));
+        rows = r; cols = c; flags = t; step = pitch;
+    }
+};
+struct HostFrame { unsigned char *p = nullptr; int w = 0, h = 0; long long seq = -1; };   // pinned BGR frame
+
+struct Options {
+    int views = 6, w = 1920, h = 1080, out_w = 3840, out_h = 1920, bands = 5, frames = 300;
+    double hfov = 90.0;
+    bool cpw = false, i420 = false, upload = true;
+    std::string dump;
+};
+
+// same pattern as synth.frame(w, h, i, t, noise=False): clip(rint(128 + 60 sin(2pi(x/97 + y/61 + i/7 + c/3)) + 40 checker))
+static void synth_frame(unsigned char *dst, int w, int h, int view)
+{
+    const double two_pi = 2.0 * M_PI;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const double phase = x / 97.0 + y / 61.0 + view / 7.0;
+            const double chk = 40.0 * (((x / 32) + (y / 32)) & 1);
+            for (int c = 0; c < 3; ++c) {
+                double v = 128.0 + 60.0 * std::sin(two_pi * (phase + c / 3.0)) + chk;
+                v = std::nearbyint(v);
+                dst[((size_t)y * w + x) * 3 + c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+}
+
+// calibrateCameras (calibration.cpp:28-68): R = R_y(2 pi i / N), principal point at the centre, focal from the field of view
+static void rig_camera(const Options &o, int i, float K[9], float R[9])
+{
+    const float rot = (float)(2.0 * M_PI * (double)(float)i / o.views);
+    const double c = std::cos((double)rot), s = std::sin((double)rot);
+    const float r[9] = {(float)c, 0, (float)s, 0, 1, 0, (float)-s, 0, (float)c};
+    const double f = (o.w / 2.0) / std::tan(o.hfov * M_PI / 180.0 / 2.0);
+    const float k[9] = {(float)f, 0, (float)(o.w / 2.0), 0, (float)f, (float)(o.h / 2.0), 0, 0, 1};
+    memcpy(K, k, sizeof k); memcpy(R, r, sizeof r);
+}
+
+// a smooth synthetic CPW mesh (the optimiser that produces real ones is out of scope): identity + amp sin(2 pi u + phase) sin(pi v)
+static void make_mesh(int aw, int ah, int N, int M, double phase, double amp, std::vector<float> &mx, std::vector<float> &my)
+{
+    mx.resize((size_t)N * M); my.resize((size_t)N * M);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < M; ++j) {
+            const double u = (double)j / (M - 1), v = (double)i / (N - 1);
+            const double d = amp * std::sin(2.0 * M_PI * u + phase) * std::sin(M_PI * v);
+            mx[(size_t)i * M + j] = (float)(u * (aw - 1) + d);
+            my[(size_t)i * M + j] = (float)(v * (ah - 1) + 0.5 * d);
+        }
+}
+
+struct Slot {                 // one entry of the ring of caller-owned outputs (no per-frame allocation)
+    DevMat pano8u, i420;
+    hipEvent_t done = nullptr;
+    long long seq = -1;
+};
+
+int main(int argc, char **argv)
+{
+    Options o;
+    for (int a = 1; a < argc; ++a) {
+        std::string k = argv[a];
+        auto next = [&]() -> const char * { if (a + 1 >= argc) { fprintf(stderr, "missing value for %s\n", k.c_str()); exit(2); } return argv[++a]; };
+        if (k == "--views") o.views = atoi(next());
+        else if (k == "--size") sscanf(next(), "%dx%d", &o.w, &o.h);
+        else if (k == "--out") sscanf(next(), "%dx%d", &o.out_w, &o.out_h);
+        else if (k == "--hfov") o.hfov = atof(next());
+        else if (k == "--bands") o.bands = atoi(next());
+        else if (k == "--frames") o.frames = atoi(next());
+        else if (k == "--cpw") o.cpw = true;
+        else if (k == "--i420") o.i420 = true;
+        else if (k == "--no-upload") o.upload = false;
+        else if (k == "--dump") o.dump = next();
+        else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "stitch_app: no HIP device (libmsstitch has no CPU fallback)\n"); return 3; }
+
+    try {
+        // ---- stitch_calib ------------------------------------------------------------------------------------
+        const float warp_scale = (float)(o.out_w / (2.0 * M_PI));
+        msshim::Compositor comp(o.views, o.w, o.h, MS_PROJ_SPHERICAL, warp_scale, o.bands, o.cpw, o.out_w, o.out_h, 1);
+        for (int i = 0; i < o.views; ++i) {
+            float K[9], R[9];
+            rig_camera(o, i, K, R);
+            comp.setCamera(i, K, R);
+            comp.setGain(i, 1.0 + 0.02 * (i - (o.views - 1) / 2.0));
+        }
+        comp.buildMaps();
+        comp.buildMasks(true);
+        comp.init_gpu();
+        hipStream_t stitch_stream, recal_stream;
+        HIPCHECK(hipStreamCreateWithFlags(&stitch_stream, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&recal_stream, hipStreamNonBlocking));
+        if (o.cpw)
+            for (int i = 0; i < o.views; ++i) {
+                const ms_view_geom g = comp.viewGeom(i);
+                std::vector<float> mx, my;
+                make_mesh(g.roi.width, g.roi.height, 10, 10, 0.1 * i, 6.0, mx, my);
+                comp.convertMeshToMap(i, mx.data(), my.data(), 10, 10, recal_stream);
+            }
+
+        // ---- capture side: the newest frame of every camera, in pinned memory ----------------------------------------
+        Lockable<std::vector<HostFrame>> imgs;
+        imgs.v.resize(o.views);
+        for (int i = 0; i < o.views; ++i) {
+            HostFrame &f = imgs.v[i];
+            f.w = o.w; f.h = o.h;
+            HIPCHECK(hipHostMalloc((void **)&f.p, (size_t)o.w * o.h * 3, hipHostMallocDefault));
+            synth_frame(f.p, o.w, o.h, i);
+            f.seq = 0;
+        }
+        std::atomic<bool> running{true};
+        std::thread capture([&] {                       // "cameras": bump the sequence number of the frames at their own pace
+            while (running.load()) {
+                { std::lock_guard<std::mutex> lk(imgs.mu); for (auto &f : imgs.v) ++f.seq; }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        });
+
+        // ---- stitch_one + results queue + consume -----------------------------------------------------------------
+        std::vector<DevMat> full_imgs(o.views);
+        for (auto &m : full_imgs) m.create(o.h, o.w, MS_8UC3, 3);
+        const int RING = 4;
+        std::vector<Slot> ring(RING);
+        const ms_pano_geom pg = comp.panoGeom();
+        const int ya = pg.canvas_y & ~1, yb = std::min(o.out_h, (pg.canvas_y + pg.dst_roi_final.height + 1) & ~1);
+        for (auto &s : ring) {
+            s.pano8u.create(o.out_h, o.out_w, MS_8UC3, 3);
+            HIPCHECK(hipMemset2D(s.pano8u.data, s.pano8u.step, 0, (size_t)o.out_w * 3, o.out_h));
+            if (o.i420) s.i420.create((yb - ya) * 3 / 2, o.out_w, MS_8UC1, 1, true);
+            HIPCHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+        BlockingQueue<Slot *> results, free_slots;
+        for (auto &s : ring) free_slots.push(&s);
+
+        std::vector<unsigned char> last_pano((size_t)o.out_w * o.out_h * 3);
+        unsigned long long checksum = 0;
+        long long consumed = 0;
+        std::thread consumer([&] {                      // consume(): wait for the frame, (I420,) bring it to the host side
+            for (;;) {
+                Slot *s = results.pop();
+                if (!s) break;
+                HIPCHECK(hipEventSynchronize(s->done));
+                if (s->seq == o.frames - 1) {           // keep the last panorama for the checksum / dump
+                    HIPCHECK(hipMemcpy2D(last_pano.data(), (size_t)o.out_w * 3, s->pano8u.data, s->pano8u.step, (size_t)o.out_w * 3, o.out_h, hipMemcpyDeviceToHost));
+                }
+                ++consumed;
+                free_slots.push(s);
+            }
+        });
+
+        std::thread recalibrater;
+        std::atomic<int> recalibrations{0};
+        if (o.cpw)
+            recalibrater = std::thread([&] {            // timed.cpp:414-463: new meshes while the stitcher keeps running
+                int round = 1;
+                while (running.load()) {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                    for (int i = 0; i < o.views && running.load(); ++i) {
+                        const ms_view_geom g = comp.viewGeom(i);
+                        std::vector<float> mx, my;
+                        make_mesh(g.roi.width, g.roi.height, 10, 10, 0.1 * i + 0.37 * round, 6.0, mx, my);
+                        comp.convertMeshToMap(i, mx.data(), my.data(), 10, 10, recal_stream);
+                    }
+                    ++round; ++recalibrations;
+                }
+            });
+
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string failure;
+        try {
+        for (int t = 0; t < o.frames; ++t) {            // main loop: stitch_one per frame
+            Slot *s = free_slots.pop();
+            if (o.upload || t == 0) {
+                std::lock_guard<std::mutex> lk(imgs.mu);                                  // imgs.lock() ... imgs.unlock()
+                for (int i = 0; i < o.views; ++i)
+                    HIPCHECK(hipMemcpy2DAsync(full_imgs[i].data, full_imgs[i].step, imgs.v[i].p, (size_t)o.w * 3, (size_t)o.w * 3, o.h,
+                                              hipMemcpyHostToDevice, stitch_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
+            }
+            comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
+            if (o.i420) {
+                ms_image rows{s->pano8u.data + (size_t)ya * s->pano8u.step, s->pano8u.step, yb - ya, o.out_w, MS_8UC3};
+                ms_image dst = msshim::wrap(s->i420);
+                msshim::check(ms_bgr_to_i420(&rows, &dst, (ms_stream)stitch_stream));       // cvtColor(BGR2YUV_I420), timed.cpp:308-316
+            }
+            s->seq = t;
+            HIPCHECK(hipEventRecord(s->done, stitch_stream));
+            results.push(s);
+        }
+        } catch (const msshim::Error &e) { failure = e.what(); }        // threads must be joined before the error is reported
+        results.push(nullptr);
+        consumer.join();
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        running.store(false);
+        capture.join();
+        if (recalibrater.joinable()) recalibrater.join();
+        HIPCHECK(hipDeviceSynchronize());
+        if (!failure.empty()) { fprintf(stderr, "stitch_app: %s\n", failure.c_str()); return 1; }
+
+        for (unsigned char b : last_pano) checksum = (checksum ^ b) * 1099511628211ull;   // FNV-1a over the last 8U panorama
+        if (!o.dump.empty()) {
+            FILE *f = fopen(o.dump.c_str(), "wb");
+            if (!f || fwrite(last_pano.data(), 1, last_pano.size(), f) != last_pano.size()) { fprintf(stderr, "cannot write %s\n", o.dump.c_str()); return 2; }
+            fclose(f);
+        }
+        printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"upload\": %s, "
+               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"checksum\": \"%016llx\"}\n",
+               o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.upload ? "true" : "false",
+               consumed, secs, consumed / secs, recalibrations.load(), checksum);
+    } catch (const msshim::Error &e) {
+        fprintf(stderr, "stitch_app: msstitch error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+    return 0;
+}
