@@ -227,6 +227,10 @@ MS_API int ms_init_blender(ms_ctx *ctx, ms_stream stream);
  * L1 distance transform * sharpness, truncated at 1; OpenCV's default sharpness is 0.02) instead of mask/255; ms_stitch then runs
  * feed x N + blend as one single-band pass. */
 MS_API int ms_init_feather(ms_ctx *ctx, float sharpness, ms_stream stream);
+/* MeshWarper::interpolateMesh (meshwarper.cpp:337-354) followed by convertMeshesToMap: mesh = start + (end - start) * progress (fp32), the
+ * RECALIB_INTERP branch of the recalibration thread (timed.cpp:449-457).  HOST vertex meshes, same conventions as ms_set_mesh. */
+MS_API int ms_set_mesh_interp(ms_ctx *ctx, int view, const float *start_x, const float *start_y, const float *end_x, const float *end_y,
+                              int N, int M, float progress, ms_stream stream);
 /* Largest |x_mesh - x| / |y_mesh - y| (pixels) of the active CPW mesh of `view`, measured on the device by ms_set_mesh / ms_set_mesh_maps.
  * While it stays <= 32 the first CPW remap (timed.cpp:90-94) skips the tiles the mesh remap cannot reach; larger meshes warp whole views. */
 MS_API int ms_get_mesh_displacement(ms_ctx *ctx, int view, float *out_px);

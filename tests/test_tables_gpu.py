@@ -127,6 +127,22 @@ def test_mesh_to_map_vs_oracle(ms, cuda, oracle, nm):
     comp.close()
 
 
+def test_mesh_interpolation_equals_host_lerp(ms, cuda):
+    """ms_set_mesh_interp = interpolateMesh (meshwarper.cpp:337-354: start + (end - start) * progress in fp32) + ms_set_mesh."""
+    comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)
+    r = comp.view_geom(2).roi
+    a = synth.mesh(r.width, r.height, 9, 7, phase=0.2, amp=5.0)
+    b = synth.mesh(r.width, r.height, 9, 7, phase=1.1, amp=9.0)
+    p = np.float32(0.37)
+    comp.set_mesh_interp(2, a, b, float(p))
+    got = [host(m).copy() for m in comp.mesh_maps(2)]
+    lerp = [(s + (e - s) * p).astype(np.float32) for s, e in zip(a, b)]
+    comp.set_mesh(2, *lerp)
+    want = [host(m) for m in comp.mesh_maps(2)]
+    assert np.array_equal(got[0], want[0], equal_nan=True) and np.array_equal(got[1], want[1], equal_nan=True)
+    comp.close()
+
+
 def test_mesh_double_buffering(ms, cuda):
     """ms_set_mesh from the recalibration side takes effect at the next ms_stitch and never tears a frame."""
     comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)

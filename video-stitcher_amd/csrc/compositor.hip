@@ -1943,6 +1943,19 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     return mesh_end_update(c, view, tgt, st);
 }
 
+// MeshWarper::interpolateMesh (meshwarper.cpp:337-354) + convertMeshesToMap: the RECALIB_INTERP branch of the recalibration thread
+// (timed.cpp:449-457) re-expands start + (end - start) * progress every 30 ms
+int ms_set_mesh_interp(ms_ctx *c, int view, const float *x0, const float *y0, const float *x1, const float *y1, int N, int M, float progress, ms_stream stream)
+{
+    MS_CHECK(x0 && y0 && x1 && y1 && N >= 2 && M >= 2, "ms_set_mesh_interp: need two N x M (>= 2x2) vertex meshes");
+    std::vector<float> mx((size_t)N * M), my((size_t)N * M);
+    for (size_t i = 0; i < mx.size(); ++i) {
+        mx[i] = x0[i] + (x1[i] - x0[i]) * progress;        // fp32, in this order (-ffp-contract=off)
+        my[i] = y0[i] + (y1[i] - y0[i]) * progress;
+    }
+    return ms_set_mesh(c, view, mx.data(), my.data(), N, M, stream);
+}
+
 int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
 {
     if (int e = ctx_check_view(c, view)) return e;
