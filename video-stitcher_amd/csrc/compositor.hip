@@ -1264,7 +1264,7 @@ static int build_plan(ms_ctx *c)
         if (!tiles.empty()) {
             MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
             if (c->warp_tiled) {   // source bounding box of every tile (static: the projection maps do not change per frame)
-                k_tile_bbox<<<c->n_warp_tiles, dim3(WARP_BX, WARP_TH)>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width);
+                k_tile_bbox<<<c->n_warp_tiles, dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX))>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width);
                 MS_LAUNCH_CHECK();
                 MS_HIP(hipMemcpy(tiles.data(), c->warp_tiles.p, tiles.size() * sizeof(WarpTile), hipMemcpyDeviceToHost));
                 for (const WarpTile &t : tiles)
@@ -2047,7 +2047,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
         if (c->cfg.reserved[0] == 0)
-            k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, WARP_TH), 0, st>>>(
+            k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX)), 0, st>>>(
                 (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(

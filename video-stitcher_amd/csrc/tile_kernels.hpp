@@ -157,6 +157,21 @@ __device__ __forceinline__ void warp_coords4(const ViewDesc &V, const MeshTable 
     }
 }
 
+// Column terms of the 4 pixels of a lane (they do not depend on the row: loaded once per tile, not once per row group)
+__device__ __forceinline__ void warp_coltab4(const ViewDesc &V, int x, float2 ct[4])
+{
+    const int i0 = x - V.left;
+    if (i0 >= 0 && i0 + 3 < V.aw) {
+        float4 a, b;
+        __builtin_memcpy(&a, __builtin_assume_aligned(V.coltab + i0, 8), 16);
+        __builtin_memcpy(&b, __builtin_assume_aligned(V.coltab + i0 + 2, 8), 16);
+        ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ct[k] = V.coltab[reflect_fast(i0 + k, V.aw)];
+    }
+}
+
 // Staged source tile: the tile's source bounding box is copied row by row, PACKED (3 B/px), in 16-byte chunks that are
 // 16-byte aligned in global memory; LDS row pitch in bytes = chunks * 16 with an odd chunk count (bank spread).
 __host__ __device__ __forceinline__ int warp_lds_pitch(int sw)
@@ -174,7 +189,8 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
     const ViewDesc &V = views[T.view];
     if (threadIdx.x == 0 && threadIdx.y == 0) { s_box[0] = s_box[2] = 0x7fffffff; s_box[1] = s_box[3] = -1; }
     __syncthreads();
-    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
+    const int x = T.x0 + 4 * (int)threadIdx.x;
+    for (int y = T.y0 + (int)threadIdx.y; y < T.y0 + WARP_TH; y += (int)blockDim.y)
     if (x < V.pw && y < V.ph) {
         float xc[4], yc[4];
         MeshTable none{};
@@ -239,16 +255,38 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
     const size_t plane = (size_t)L.h * L.pitch;
     float xc[2][4], yc[2][4];
     Px2 r1[2][4], r2[2][4];
+    // the 1-D tables of the projection are read ONCE, up front (column terms of the lane's 4 pixels, row term of each row group):
+    // building the coordinates of a group is then pure arithmetic, with no load between it and the tap reads
+    float2 ct[4], rt[WARP_NG];
+    if (!CPW) {
+        warp_coltab4(V, min(x, V.pw - 4), ct);
+#pragma unroll
+        for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
+    }
     auto issue = [&](int g) {
         const int b = g & 1;
-        if (active[g]) warp_coords4<CPW>(V, mesh, v, x, ys[g], xc[b], yc[b]);
+#if defined(MS_PROBE) && MS_PROBE == 3       // roofline probe: affine coordinates instead of the projection (same gather density)
+        if (active[g]) { for (int k = 0; k < 4; ++k) { xc[b][k] = 1.55f * (float)(x + k - V.left) + 20.3f; yc[b][k] = 1.6f * (float)(ys[g] - V.top) + 10.7f; } }
+#else
+        if (active[g]) {
+            if (CPW) warp_coords4<CPW>(V, mesh, v, x, ys[g], xc[b], yc[b]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) warp_combine(V.proj, ct[k], rt[g], V.wp, xc[b][k], yc[b][k]);
+            }
+        }
+#endif
         else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) xc[b][k] = yc[b][k] = -1.f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#if defined(MS_PROBE) && MS_PROBE == 1       // roofline probe: same instructions, every tap read from one 4 KiB window (cache resident)
+            const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep) & 0xfffu;
+#else
             const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
+#endif
             r1[b][k] = load_px2(sp, off);
             r2[b][k] = load_px2(sp + sstep, off);
         }
@@ -270,7 +308,12 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
                     t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
                     if (!t[j].fast) fix_border_taps(r1[b][k + j], r2[b][k + j], t[j].x1, t[j].y1, srows, scols);
                 }
+    #if defined(MS_PROBE) && MS_PROBE == 2       // roofline probe: real addresses and loads, no bilinear arithmetic
+                for (int j = 0; j < 2; ++j)
+                    for (int c = 0; c < 3; ++c) o[j][c] = (float)((r1[b][k + j].lo >> (8 * c)) & 0xff) + (float)(r2[b][k + j].hi & 1);
+#else
                 blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -407,10 +450,11 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
     // the mesh of this view moves no sample further than the bound the plan assumed: stage 2 never reads this tile
     if (!(T.flags & 2) && *disp.p[v] <= disp.limit_bits) return;
     const ViewDesc &V = views[v];
-    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
-    if (x >= V.aw || y >= V.ah) return;
+    const int x = T.x0 + 4 * (int)threadIdx.x;
     const uint8_t *sp = src.p[f * n_views + v];
     const unsigned sstep = src.step[f * n_views + v];
+    for (int y = T.y0 + (int)threadIdx.y; y < T.y0 + WARP_TH; y += (int)blockDim.y) {
+    if (x >= V.aw || y >= V.ah) continue;
     const float2 rt = V.rowtab[y];
     float xc[4], yc[4];
 #pragma unroll
@@ -445,6 +489,7 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
         __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
     } else {
         for (int k = 0; k < 4 && x + k < V.aw; ++k) { d[3 * k] = o8[3 * k]; d[3 * k + 1] = o8[3 * k + 1]; d[3 * k + 2] = o8[3 * k + 2]; }
+    }
     }
 }
 
