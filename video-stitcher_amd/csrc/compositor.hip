@@ -619,6 +619,11 @@ __device__ __forceinline__ void up_2x8_pk(const int16_t *__restrict__ cs, int cp
 // range: add a bias of 384 and use the same packed arithmetic when all 18 taps of the lane are in [-384, 639]
 // (pyrUp's weights sum to 64 and 384 is even, so rne(S + 64*384, 6) == rne(S, 6) + 384 exactly); lanes with a tap outside
 // that range take the 32-bit up_2x8.  Returns false if the lane must fall back.  Outputs are biased: value + 384.
+#ifdef MS_BLEND_WAVES
+#define MS_BLEND_OCC __attribute__((amdgpu_waves_per_eu(MS_BLEND_WAVES, 8)))
+#else
+#define MS_BLEND_OCC
+#endif
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned add_pk_u16(unsigned a, unsigned b)      // v_pk_add_u16: halves add independently (wrap)
 {
@@ -664,7 +669,7 @@ __device__ __forceinline__ bool up_2x8_pkb(const int16_t *__restrict__ cs, int c
 }
 
 template <bool L0, int MODE>
-__global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
+__global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
                                                 const int16_t *__restrict__ gl, long long gl_stride,
                                                 int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
@@ -673,11 +678,14 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
     const int f = blockIdx.z;
     const int x0 = T.x0 + 8 * (int)threadIdx.x, y0 = T.y0 + 2 * (int)threadIdx.y;   // block 32 x 8 lanes = 256 x 16 px
     if (x0 >= P.qw[l] || y0 >= P.qh[l]) return;
-    int acc[3][2][8];
+    // The accumulators are the reference's int16 `dst += (short)(v * w)` themselves: two pixels per register, added with the packed 16-bit
+    // add (wraps per half exactly like `short +=`).  Pixel order of the four registers of a row: (0,2) (1,3) (4,6) (5,7), the order
+    // the packed pyrUp produces.  Half as many accumulator registers = more waves in flight (the kernel waits on memory, not on VALU).
+    unsigned accp[3][2][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[c][0][k] = acc[c][1][k] = 0;
+        for (int q = 0; q < 4; ++q) accp[c][0][q] = accp[c][1][q] = 0u;
 
     const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y0 * P.qpitch[l] + x0;
     if (MODE == 2) {
@@ -686,10 +694,11 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    int pv[8];
-                    unpack8(*reinterpret_cast<const uint4 *>(S.part[s] + po + c * pplane + (size_t)r * P.qpitch[l]), pv);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[c][r][k] += pv[k];
+                    const uint4 b = *reinterpret_cast<const uint4 *>(S.part[s] + po + c * pplane + (size_t)r * P.qpitch[l]);   // natural order (0,1) (2,3) ..
+                    accp[c][r][0] = add_pk_u16(accp[c][r][0], __builtin_amdgcn_perm(b.y, b.x, 0x05040100u));
+                    accp[c][r][1] = add_pk_u16(accp[c][r][1], __builtin_amdgcn_perm(b.y, b.x, 0x07060302u));
+                    accp[c][r][2] = add_pk_u16(accp[c][r][2], __builtin_amdgcn_perm(b.w, b.z, 0x05040100u));
+                    accp[c][r][3] = add_pk_u16(accp[c][r][3], __builtin_amdgcn_perm(b.w, b.z, 0x07060302u));
                 }
     }
     for (unsigned vm = (MODE == 2) ? 0u : (MODE == 1 ? (T.view_mask & S.own_mask) : T.view_mask); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
@@ -700,9 +709,10 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         float w[2][8];
         if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
             const uint8_t *mp = views[v].wm0 + (size_t)ly * views[v].wm0_pitch + lx;
+            const uint2 ma = *reinterpret_cast<const uint2 *>(mp), mb = *reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch);
+            if ((ma.x | ma.y | mb.x | mb.y) == 0u) continue;          // all 16 weights zero: (short)(L * 0) == 0
             int m0[8], m1[8];
-            unpack8(*reinterpret_cast<const uint2 *>(mp), m0);
-            unpack8(*reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch), m1);
+            unpack8(ma, m0); unpack8(mb, m1);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 w[0][k] = __builtin_fmaf(P.alpha, (float)m0[k], 0.f);
@@ -714,19 +724,14 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
             const float4 wc = *reinterpret_cast<const float4 *>(wp + L.wpitch), wd = *reinterpret_cast<const float4 *>(wp + L.wpitch + 4);
             w[0][0] = wa.x; w[0][1] = wa.y; w[0][2] = wa.z; w[0][3] = wa.w; w[0][4] = wb.x; w[0][5] = wb.y; w[0][6] = wb.z; w[0][7] = wb.w;
             w[1][0] = wc.x; w[1][1] = wc.y; w[1][2] = wc.z; w[1][3] = wc.w; w[1][4] = wd.x; w[1][5] = wd.y; w[1][6] = wd.z; w[1][7] = wd.w;
-        }
-        float wsum = 0.f;
+            float wsum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wsum += w[0][k] + w[1][k];      // weights are >= 0
-        if (wsum == 0.f) continue;
+            for (int k = 0; k < 8; ++k) wsum += w[0][k] + w[1][k];      // weights are >= 0
+            if (wsum == 0.f) continue;
+        }
         const LevelDesc &C = views[v].lv[l + 1];
         const size_t fplane = (size_t)L.h * L.pitch, cplane = (size_t)C.h * C.pitch;
         const size_t fo = (size_t)ly * L.pitch + lx;
-        float nw[2][8];                       // -256 w (exact): fma(256 + L, w, -256 w) rounds the exact product L*w once
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) nw[r][k] = -256.f * w[r][k];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             unsigned up[2][4];
@@ -753,12 +758,13 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    // Laplacian L = g - up in [-255,255], kept as 256 + L per half (no borrow between halves);
+                    // Laplacian L = g - up in [-255,255], formed as 256 + L per half (no borrow between the halves);
                     // |L*w| <= 255: neither saturate_cast of the reference chain (sub_mat.cu:59-65, multiband_blend.cu:46-49) can trigger
                     const unsigned d = (g[r][q] | 0x01000100u) - up[r][q];
                     const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
-                    acc[c][r][k0] += (int)__builtin_fmaf((float)(d & 0xffffu), w[r][k0], nw[r][k0]);
-                    acc[c][r][k1] += (int)__builtin_fmaf((float)(d >> 16), w[r][k1], nw[r][k1]);
+                    const int t0 = (int)((float)((int)(d & 0xffffu) - 256) * w[r][k0]);
+                    const int t1 = (int)((float)((int)(d >> 16) - 256) * w[r][k1]);
+                    accp[c][r][q] = add_pk_u16(accp[c][r][q], __builtin_amdgcn_perm((unsigned)t1, (unsigned)t0, 0x05040100u));
                 }
         }
     }
@@ -768,11 +774,11 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                uint4 o;
-                o.x = (unsigned)(uint16_t)acc[c][r][0] | ((unsigned)(uint16_t)acc[c][r][1] << 16);
-                o.y = (unsigned)(uint16_t)acc[c][r][2] | ((unsigned)(uint16_t)acc[c][r][3] << 16);
-                o.z = (unsigned)(uint16_t)acc[c][r][4] | ((unsigned)(uint16_t)acc[c][r][5] << 16);
-                o.w = (unsigned)(uint16_t)acc[c][r][6] | ((unsigned)(uint16_t)acc[c][r][7] << 16);
+                uint4 o;                      // back to natural pixel order
+                o.x = __builtin_amdgcn_perm(accp[c][r][1], accp[c][r][0], 0x05040100u);   // px 0, 1
+                o.y = __builtin_amdgcn_perm(accp[c][r][1], accp[c][r][0], 0x07060302u);   // px 2, 3
+                o.z = __builtin_amdgcn_perm(accp[c][r][3], accp[c][r][2], 0x05040100u);   // px 4, 5
+                o.w = __builtin_amdgcn_perm(accp[c][r][3], accp[c][r][2], 0x07060302u);   // px 6, 7
                 *reinterpret_cast<uint4 *>(S.pout + po + c * pplane + (size_t)r * P.qpitch[l]) = o;
             }
         return;
@@ -783,12 +789,12 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
     const float den[2][8] = {{da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w}, {dc.x, dc.y, dc.z, dc.w, dd.x, dd.y, dd.z, dd.w}};
     const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
     const int16_t *cc = cl + (size_t)f * cl_stride + P.coff[l + 1];
-    int res[3][2][8];
     float rcp[2][8];                      // refined reciprocals, shared by the three colour planes (DivBy)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int k = 0; k < 8; ++k) rcp[r][k] = DivBy(den[r][k]).r;
+    unsigned resp[3][2][4];               // results as int16 pairs, natural pixel order (px 2j, 2j+1): half the registers of 48 ints
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         int up[2][8];
@@ -810,8 +816,14 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
 #pragma unroll
             for (int k = 0; k < 8; ++k) {   // int16 accumulation wraps: (short)(sum) == successive `short +=`
                 DivBy dv(1.f); dv.d = den[r][k]; dv.r = rcp[r][k];
-                res[c][r][k] = sat_s16(up[r][k] + (int)trunc_s16(dv((float)(int)(int16_t)acc[c][r][k])));
+                const unsigned ap = accp[c][r][(k >> 2) * 2 + (k & 1)];          // pixel k lives in register (k/4)*2 + (k&1), half (k>>1)&1
+                const int a = ((k >> 1) & 1) ? ((int)ap >> 16) : (int)(int16_t)(ap & 0xffffu);
+                up[r][k] = sat_s16(up[r][k] + (int)trunc_s16(dv((float)a)));        // (the result replaces the expanded coarser level)
             }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) resp[c][r][j] = ((unsigned)up[r][2 * j] & 0xffffu) | ((unsigned)up[r][2 * j + 1] << 16);
     }
 
     if (!L0) {
@@ -821,12 +833,7 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                uint4 o;
-                o.x = (unsigned)(uint16_t)res[c][r][0] | ((unsigned)(uint16_t)res[c][r][1] << 16);
-                o.y = (unsigned)(uint16_t)res[c][r][2] | ((unsigned)(uint16_t)res[c][r][3] << 16);
-                o.z = (unsigned)(uint16_t)res[c][r][4] | ((unsigned)(uint16_t)res[c][r][5] << 16);
-                o.w = (unsigned)(uint16_t)res[c][r][6] | ((unsigned)(uint16_t)res[c][r][7] << 16);
-                *reinterpret_cast<uint4 *>(d + c * plane + (size_t)r * P.qpitch[l]) = o;
+                *reinterpret_cast<uint4 *>(d + c * plane + (size_t)r * P.qpitch[l]) = make_uint4(resp[c][r][0], resp[c][r][1], resp[c][r][2], resp[c][r][3]);
             }
     } else {
 #pragma unroll
@@ -846,7 +853,7 @@ __global__ void __launch_bounds__(256) k_blend8(const BlendTile *__restrict__ ti
             for (int k = 0; k < 8; ++k) {
                 const bool m = mk[k] != 0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) px[k][c] = m ? res[c][r][k] : 0;
+                for (int c = 0; c < 3; ++c) px[k][c] = m ? ((k & 1) ? ((int)resp[c][r][k >> 1] >> 16) : (int)(int16_t)(resp[c][r][k >> 1] & 0xffffu)) : 0;
             }
             if (out.p16[f]) {
                 int16_t *d = (int16_t *)((char *)out.p16[f] + (size_t)y * out.step16[f]) + 3 * x0;
