@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(256) k_down_vec(const ViewDesc *__restrict__ v
 }
 
 }  // namespace ms
+#include <type_traits>
 #include "tile_kernels.hpp"
 namespace ms {
 
@@ -584,14 +585,15 @@ __device__ __forceinline__ unsigned rne6_pk(unsigned s)
     return ((s + t + 0x001f001fu) >> 6) & 0x03ff03ffu;
 }
 // pixel order of the four output registers of a row: (0,2) (1,3) (4,6) (5,7)  [low half, high half]
-__device__ __forceinline__ void up_2x8_pk(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
-                                          unsigned ue[4], unsigned uo[4])
+__device__ __forceinline__ void up_rows_load(const int16_t *__restrict__ cs, int cpitch, int ch, int i, int j0, uint4 raw[3])
 {
     const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
     const int jb = max(j0 - 2, 0);
-    uint4 raw[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
+}
+__device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
+{
     unsigned he[3][2], ho[3][2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -634,14 +636,8 @@ __device__ __forceinline__ unsigned add_pk_u16(unsigned a, unsigned b)      // v
     return a;
 }
 constexpr int UP_BIAS = 384;
-__device__ __forceinline__ bool up_2x8_pkb(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
-                                           unsigned ue[4], unsigned uo[4])
+__device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
 {
-    const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
-    const int jb = max(j0 - 2, 0);
-    uint4 raw[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
     unsigned he[3][2], ho[3][2], bad = 0u;
     const unsigned bias = (unsigned)UP_BIAS * 0x00010001u;
 #pragma unroll
@@ -732,26 +728,40 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
         const LevelDesc &C = views[v].lv[l + 1];
         const size_t fplane = (size_t)L.h * L.pitch, cplane = (size_t)C.h * C.pitch;
         const size_t fo = (size_t)ly * L.pitch + lx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            unsigned up[2][4];
-            up_2x8_pk(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up[0], up[1]);
-            unsigned g[2][4];                 // same pixel order as up: (0,2) (1,3) (4,6) (5,7)
+        // the three colour planes are software-pipelined: the reads of plane c+1 (3 coarse rows + 2 fine rows) are issued before
+        // plane c is computed, so a view costs about one memory round trip instead of three
+        uint4 craw[2][3];
+        typename std::conditional<L0, uint2, uint4>::type fraw[2][2];
+        auto issue = [&](int c, int b) {
+            up_rows_load(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, ly >> 1, lx >> 1, craw[b]);
             if (L0) {
                 const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + c * fplane + fo;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint2 b = *reinterpret_cast<const uint2 *>(p + (size_t)r * L.pitch);
-                    g[r][0] = b.x & 0x00ff00ffu; g[r][1] = (b.x >> 8) & 0x00ff00ffu;
-                    g[r][2] = b.y & 0x00ff00ffu; g[r][3] = (b.y >> 8) & 0x00ff00ffu;
-                }
+                for (int r = 0; r < 2; ++r) __builtin_memcpy(&fraw[b][r], __builtin_assume_aligned(p + (size_t)r * L.pitch, 8), sizeof(fraw[b][r]));
             } else {
                 const int16_t *p = gl + (size_t)f * gl_stride + L.off + c * fplane + fo;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint4 b = *reinterpret_cast<const uint4 *>(p + (size_t)r * L.pitch);
-                    g[r][0] = __builtin_amdgcn_perm(b.y, b.x, 0x05040100u); g[r][1] = __builtin_amdgcn_perm(b.y, b.x, 0x07060302u);
-                    g[r][2] = __builtin_amdgcn_perm(b.w, b.z, 0x05040100u); g[r][3] = __builtin_amdgcn_perm(b.w, b.z, 0x07060302u);
+                for (int r = 0; r < 2; ++r) __builtin_memcpy(&fraw[b][r], __builtin_assume_aligned(p + (size_t)r * L.pitch, 16), sizeof(fraw[b][r]));
+            }
+        };
+        issue(0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int b = c & 1;
+            if (c + 1 < 3) issue(c + 1, b ^ 1);
+            unsigned up[2][4];
+            up_2x8_pk(craw[b], C.w, lx >> 1, up[0], up[1]);
+            unsigned g[2][4];                 // same pixel order as up: (0,2) (1,3) (4,6) (5,7)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned wds[4];
+                __builtin_memcpy(wds, &fraw[b][r], sizeof(fraw[b][r]));
+                if (L0) {
+                    g[r][0] = wds[0] & 0x00ff00ffu; g[r][1] = (wds[0] >> 8) & 0x00ff00ffu;
+                    g[r][2] = wds[1] & 0x00ff00ffu; g[r][3] = (wds[1] >> 8) & 0x00ff00ffu;
+                } else {
+                    g[r][0] = __builtin_amdgcn_perm(wds[1], wds[0], 0x05040100u); g[r][1] = __builtin_amdgcn_perm(wds[1], wds[0], 0x07060302u);
+                    g[r][2] = __builtin_amdgcn_perm(wds[3], wds[2], 0x05040100u); g[r][3] = __builtin_amdgcn_perm(wds[3], wds[2], 0x07060302u);
                 }
             }
 #pragma unroll
@@ -795,11 +805,14 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
 #pragma unroll
         for (int k = 0; k < 8; ++k) rcp[r][k] = DivBy(den[r][k]).r;
     unsigned resp[3][2][4];               // results as int16 pairs, natural pixel order (px 2j, 2j+1): half the registers of 48 ints
+    uint4 ccraw[2][3];                    // the three planes of the collapsed coarser level are pipelined like the view planes above
+    up_rows_load(cc, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[0]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        if (c + 1 < 3) up_rows_load(cc + (c + 1) * cplane, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[(c + 1) & 1]);
         int up[2][8];
         unsigned upk[2][4];
-        if (up_2x8_pkb(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, upk[0], upk[1])) {
+        if (up_2x8_pkb(ccraw[c & 1], P.qw[l + 1], x0 >> 1, upk[0], upk[1])) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
