@@ -635,6 +635,14 @@ __device__ __forceinline__ unsigned add_pk_u16(unsigned a, unsigned b)      // v
     __builtin_memcpy(&a, &x, 4);
     return a;
 }
+__device__ __forceinline__ unsigned sub_pk_u16(unsigned a, unsigned b)      // v_pk_sub_u16
+{
+    u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    x -= y;
+    __builtin_memcpy(&a, &x, 4);
+    return a;
+}
 constexpr int UP_BIAS = 384;
 __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
 {
@@ -672,8 +680,15 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
 {
     const BlendTile T = tiles[blockIdx.x];
     const int f = blockIdx.z;
-    const int x0 = T.x0 + 8 * (int)threadIdx.x, y0 = T.y0 + 2 * (int)threadIdx.y;   // block 32 x 8 lanes = 256 x 16 px
+    // block 32 x 8 lanes = 256 x 16 px; wave w covers the 64 x 16 px cell w of the tile (8 lanes x 8 lane-rows), so that a whole wave
+    // usually lies inside one view's exclusive region and can take the single-view path below
+    const int tid = (int)threadIdx.y * 32 + (int)threadIdx.x, lane = tid & 63;
+    const int x0 = T.x0 + 64 * (tid >> 6) + 8 * (lane & 7), y0 = T.y0 + 2 * (lane >> 3);
     if (x0 >= P.qw[l] || y0 >= P.qh[l]) return;
+    // owner of this wave's cell: the one view with non-zero weights there, all exactly 1 -- then (short)(L * 1.f) = L and the weight sum
+    // is exactly 1.00001f; 255 = general case.  Wave-uniform by construction (one byte per 64 x 16 cell).
+    int owner = 255;
+    if (MODE == 0 && P.pure[l]) owner = __builtin_amdgcn_readfirstlane((int)P.pure[l][(size_t)(y0 >> 4) * P.ppitch[l] + (x0 >> 6)]);
     // The accumulators are the reference's int16 `dst += (short)(v * w)` themselves: two pixels per register, added with the packed 16-bit
     // add (wraps per half exactly like `short +=`).  Pixel order of the four registers of a row: (0,2) (1,3) (4,6) (5,7), the order
     // the packed pyrUp produces.  Half as many accumulator registers = more waves in flight (the kernel waits on memory, not on VALU).
@@ -697,13 +712,16 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                     accp[c][r][3] = add_pk_u16(accp[c][r][3], __builtin_amdgcn_perm(b.w, b.z, 0x07060302u));
                 }
     }
-    for (unsigned vm = (MODE == 2) ? 0u : (MODE == 1 ? (T.view_mask & S.own_mask) : T.view_mask); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
+    for (unsigned vm = (MODE == 2) ? 0u : (MODE == 1 ? (T.view_mask & S.own_mask) : (owner != 255 ? (1u << owner) : T.view_mask)); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
         const int v = __builtin_ctz(vm);
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
         float w[2][8];
-        if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
+        if (owner != 255) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[0][k] = w[1][k] = 1.f;       // (unused: the owner path adds L itself)
+        } else if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
             const uint8_t *mp = views[v].wm0 + (size_t)ly * views[v].wm0_pitch + lx;
             const uint2 ma = *reinterpret_cast<const uint2 *>(mp), mb = *reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch);
             if ((ma.x | ma.y | mb.x | mb.y) == 0u) continue;          // all 16 weights zero: (short)(L * 0) == 0
@@ -771,6 +789,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                     // Laplacian L = g - up in [-255,255], formed as 256 + L per half (no borrow between the halves);
                     // |L*w| <= 255: neither saturate_cast of the reference chain (sub_mat.cu:59-65, multiband_blend.cu:46-49) can trigger
                     const unsigned d = (g[r][q] | 0x01000100u) - up[r][q];
+                    if (owner != 255) { accp[c][r][q] = sub_pk_u16(d, 0x01000100u); continue; }     // weight exactly 1: (short)(L * 1.f) == L
                     const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
                     const int t0 = (int)((float)((int)(d & 0xffffu) - 256) * w[r][k0]);
                     const int t1 = (int)((float)((int)(d >> 16) - 256) * w[r][k1]);
@@ -793,17 +812,24 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
             }
         return;
     }
-    const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
-    const float4 da = *reinterpret_cast<const float4 *>(dp), db = *reinterpret_cast<const float4 *>(dp + 4);
-    const float4 dc = *reinterpret_cast<const float4 *>(dp + P.dpitch[l]), dd = *reinterpret_cast<const float4 *>(dp + P.dpitch[l] + 4);
-    const float den[2][8] = {{da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w}, {dc.x, dc.y, dc.z, dc.w, dd.x, dd.y, dd.z, dd.w}};
+    float den[2][8];
+    if (owner == 255) {
+        const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
+        const float4 da = *reinterpret_cast<const float4 *>(dp), db = *reinterpret_cast<const float4 *>(dp + 4);
+        const float4 dc = *reinterpret_cast<const float4 *>(dp + P.dpitch[l]), dd = *reinterpret_cast<const float4 *>(dp + P.dpitch[l] + 4);
+        den[0][0] = da.x; den[0][1] = da.y; den[0][2] = da.z; den[0][3] = da.w; den[0][4] = db.x; den[0][5] = db.y; den[0][6] = db.z; den[0][7] = db.w;
+        den[1][0] = dc.x; den[1][1] = dc.y; den[1][2] = dc.z; den[1][3] = dc.w; den[1][4] = dd.x; den[1][5] = dd.y; den[1][6] = dd.z; den[1][7] = dd.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) den[0][k] = den[1][k] = 1.f;
+    }
     const size_t cplane = (size_t)P.qh[l + 1] * P.qpitch[l + 1];
     const int16_t *cc = cl + (size_t)f * cl_stride + P.coff[l + 1];
     float rcp[2][8];                      // refined reciprocals, shared by the three colour planes (DivBy)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rcp[r][k] = DivBy(den[r][k]).r;
+        for (int k = 0; k < 8; ++k) rcp[r][k] = owner == 255 ? DivBy(den[r][k]).r : 1.f;
     unsigned resp[3][2][4];               // results as int16 pairs, natural pixel order (px 2j, 2j+1): half the registers of 48 ints
     uint4 ccraw[2][3];                    // the three planes of the collapsed coarser level are pipelined like the view planes above
     up_rows_load(cc, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[0]);
@@ -831,7 +857,10 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                 DivBy dv(1.f); dv.d = den[r][k]; dv.r = rcp[r][k];
                 const unsigned ap = accp[c][r][(k >> 2) * 2 + (k & 1)];          // pixel k lives in register (k/4)*2 + (k&1), half (k>>1)&1
                 const int a = ((k >> 1) & 1) ? ((int)ap >> 16) : (int)(int16_t)(ap & 0xffffu);
-                up[r][k] = sat_s16(up[r][k] + (int)trunc_s16(dv((float)a)));        // (the result replaces the expanded coarser level)
+                // owner cells: a / 1.00001f for an integer |a| <= 255 lies strictly between a - sign(a) and a, further than half an ulp from a,
+                // so the correctly rounded quotient truncates to a - sign(a): the division is an integer subtraction there
+                up[r][k] = owner != 255 ? sat_s16(up[r][k] + (a - min(max(a, -1), 1)))
+                                        : sat_s16(up[r][k] + (int)trunc_s16(dv((float)a)));        // (the result replaces the expanded coarser level)
             }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -1101,6 +1130,7 @@ struct ms_ctx {
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0;
+    DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
     size_t warp_lds_bytes = 0;         // dynamic LDS of k_warp_t: largest staged source tile
@@ -1221,6 +1251,8 @@ static void xcd_order(std::vector<T> &tiles)
     for (size_t i = 0; i < n; ++i) if (!used[i]) out.push_back(tiles[i]);
     tiles.swap(out);
 }
+
+static bool sharded_ctx(const ms_ctx *c) { return c->own_mask != ((c->N >= 32) ? 0xffffffffu : ((1u << c->N) - 1u)); }
 
 static int build_plan(ms_ctx *c)
 {
@@ -1363,6 +1395,41 @@ static int build_plan(ms_ctx *c)
         c->n_blend_tiles[l] = (int)tiles.size();
         if (int e = c->blend_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(BlendTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->blend_tiles[l].p, tiles.data(), tiles.size() * sizeof(BlendTile), hipMemcpyHostToDevice));
+    }
+    // owner maps: 64 x 16 cells of a band where exactly one view has non-zero weights, every one of them exactly 1.0f
+    {
+        std::vector<uint8_t> all;
+        size_t off[MAX_LEVELS] = {};
+        for (int l = 0; l < nb; ++l) {
+            c->pano.pure[l] = nullptr; c->pano.ppitch[l] = 0;
+            if (!c->blend_vec[l] || sharded_ctx(c) || c->cfg.reserved[0] != 0) continue;
+            const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
+            off[l] = all.size() + 1;          // (+1: 0 means "no map")
+            c->pano.ppitch[l] = pw_;
+            for (int cy = 0; cy < ph_; ++cy)
+                for (int cx = 0; cx < pw_; ++cx) {
+                    const int x0 = cx * 64, y0 = cy * 16;
+                    int owner = -1, cnt = 0;
+                    for (int v = 0; v < N; ++v) {
+                        const LevelDesc &L = c->h_views[v].lv[l];
+                        if (any_in(W[v][l], L.w, L.h, x0 - L.x_tl, y0 - L.y_tl, 64, 16)) { owner = v; ++cnt; }
+                    }
+                    bool ok = cnt == 1 && x0 + 64 <= c->pano.qw[l] && y0 + 16 <= c->pano.qh[l];
+                    if (ok) {
+                        const LevelDesc &L = c->h_views[owner].lv[l];
+                        const float *wp = hw.data() + c->w_off[owner][l];
+                        ok = x0 - L.x_tl >= 0 && y0 - L.y_tl >= 0 && x0 - L.x_tl + 64 <= L.w && y0 - L.y_tl + 16 <= L.h;
+                        for (int y = 0; ok && y < 16; ++y)
+                            for (int x = 0; ok && x < 64; ++x) ok = wp[(size_t)(y0 - L.y_tl + y) * L.wpitch + (x0 - L.x_tl + x)] == 1.0f;
+                    }
+                    all.push_back(ok ? (uint8_t)owner : (uint8_t)255);
+                }
+        }
+        if (!all.empty()) {
+            if (int e = c->pure_maps.alloc(all.size())) return e;
+            MS_HIP(hipMemcpy(c->pure_maps.p, all.data(), all.size(), hipMemcpyHostToDevice));
+            for (int l = 0; l < nb; ++l) if (off[l]) c->pano.pure[l] = (const uint8_t *)c->pure_maps.p + (off[l] - 1);
+        }
     }
     return MS_OK;
 }

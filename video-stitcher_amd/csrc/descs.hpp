@@ -44,6 +44,10 @@ struct PanoDesc {
     int mask_pitch;
     int fw, fh;                   // dst_roi_final size
     int canvas_x, canvas_y, out_w, out_h;
+    // per level: one byte per 64 x 16 cell of the pano = the view that OWNS it (exactly one view has non-zero weights there, all of them
+    // exactly 1.0f, hence w_sum + 1e-5 == 1.00001f), or 255.  nullptr where the level has no such map.
+    const uint8_t *pure[MAX_LEVELS];
+    int ppitch[MAX_LEVELS];
 };
 // View sharding (BASELINE configs[4]): the weighted accumulation over views is a sum of int16 terms, so a
 // rank that owns a subset of the views writes its partial sums (mode 1) and the sink adds the partials of all ranks
