@@ -6,11 +6,11 @@ set -euo pipefail
 TAG=${1:-r01}; CFG=${2:-cfg2}; F=${3:-16}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
-B="python bench.py --steps 12 --warmup 3 --no-cpu-baseline --frames $F --config $CFG --calib"
+B="python bench.py --steps 12 --warmup 3 --no-cpu-baseline --frames $F --streams 1 --config $CFG --calib"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $B > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $B > $OUT/bench_write.log 2>&1
-python bench.py --frames $F --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err || true
+python bench.py --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err || true
 python tools/summarize_traffic.py $OUT $TAG $CFG $F
 # gpurun only merges gpurun_out/ back: park the summaries there (copy them into profiles/ and commit)
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/traffic_latest.json gpurun_out/profiles_out/

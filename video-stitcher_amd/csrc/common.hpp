@@ -107,8 +107,11 @@ __device__ __forceinline__ void warp_combine(int proj, const float2 c, const flo
     ox = __builtin_fmaf(P.k[2], z_, __builtin_fmaf(P.k[1], y_, P.k[0] * x_));
     oy = __builtin_fmaf(P.k[5], z_, __builtin_fmaf(P.k[4], y_, P.k[3] * x_));
     const float oz = __builtin_fmaf(P.k[8], z_, __builtin_fmaf(P.k[7], y_, P.k[6] * x_));
-    if (proj == MS_PROJ_PLANE || oz > 0) { ox /= oz; oy /= oz; }
-    else ox = oy = -1.f;
+    // divide unconditionally and select (no trap on the GPU; same results): straight-line code instead of a divergent block per pixel
+    const bool ok = proj == MS_PROJ_PLANE || oz > 0;
+    const float qx = ox / oz, qy = oy / oz;
+    ox = ok ? qx : -1.f;
+    oy = ok ? qy : -1.f;
 }
 
 // ---- IEEE fp32 division with the reciprocal shared between numerators -----------------------------------

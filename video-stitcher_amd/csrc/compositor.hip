@@ -2055,6 +2055,16 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
 }
 
 // ---- the per-frame path --------------------------------------------------------------------------
+// launch a kernel whose LAST template argument is the projection, with the context's projection.
+// TARGS = the leading template arguments in parentheses, with a trailing comma, e.g. (true, false,) or ()
+#define MS_UNPAREN(...) __VA_ARGS__
+#define MS_PROJ_LAUNCH(K, TARGS, CFG, ...)                                                                                   \
+    do {                                                                                                                    \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) K<MS_UNPAREN TARGS MS_PROJ_SPHERICAL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);         \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) K<MS_UNPAREN TARGS MS_PROJ_CYLINDRICAL><<<MS_UNPAREN CFG>>>(__VA_ARGS__); \
+        else K<MS_UNPAREN TARGS MS_PROJ_PLANE><<<MS_UNPAREN CFG>>>(__VA_ARGS__);                                                    \
+    } while (0)
+
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
                        int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{})
 {
@@ -2134,7 +2144,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
         if (c->cfg.reserved[0] == 0)
-            k_stage1_t<<<dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX)), 0, st>>>(
+            MS_PROJ_LAUNCH(k_stage1_t, (), (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX)), 0, st), 
                 (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
@@ -2142,8 +2152,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
-            k_warp_t<true, false><<<dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st>>>(
-                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
+            MS_PROJ_LAUNCH(k_warp_t, (true, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
@@ -2151,11 +2160,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         int lds_ok = c->cfg.reserved[1] != 0 && c->warp_lds_bytes > 0;   // opt-in: LDS staging of the source tiles (measured slower than direct gathers)
         for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
         if (lds_ok)
-            k_warp_t<false, true><<<dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st>>>(
-                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1);
+            MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1);
         else
-            k_warp_t<false, false><<<dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st>>>(
-                (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0);
+            MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

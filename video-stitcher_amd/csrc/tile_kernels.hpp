@@ -117,7 +117,7 @@ __device__ __forceinline__ void blend_taps2(const Taps ta, const Taps tb, const 
 // ---- Gaussian level 0 (remap + gain [or CPW stage 2] + reflect pad), 4 px per lane ---------------------
 // Source coordinates of the 4 pixels of a lane.  Non-CPW: rebuilt from the 1-D tables (same fp32 ops as the dense
 // x_map/y_map, which are therefore never read per frame); CPW stage 2: read from the dense mesh maps.
-template <bool CPW>
+template <bool CPW, int PROJ = -1>
 __device__ __forceinline__ void warp_coords4(const ViewDesc &V, const MeshTable &mesh, int v, int x, int y, float xc[4], float yc[4])
 {
     const int ay = reflect_fast(y - V.top, V.ah);
@@ -136,7 +136,7 @@ __device__ __forceinline__ void warp_coords4(const ViewDesc &V, const MeshTable 
             for (int k = 0; k < 4; ++k) ct[k] = V.coltab[reflect_fast(i0 + k, V.aw)];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) warp_combine(V.proj, ct[k], rt, V.wp, xc[k], yc[k]);
+        for (int k = 0; k < 4; ++k) warp_combine(PROJ < 0 ? V.proj : PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
     } else {
         const float *mxp = mesh.x[v], *myp = mesh.y[v];
         const int mpitch = mesh.pitch[v];
@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
 constexpr int WARP_NG = MS_WARP_NG;
 constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = WARP_BX x WARP_BY lanes
 
-template <bool CPW, bool STAGED>
+// PROJ = the context's projection (one per context): a compile-time constant keeps the coordinate code free of per-pixel branches
+template <bool CPW, bool STAGED, int PROJ>
 __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
@@ -269,10 +270,10 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
         if (active[g]) { for (int k = 0; k < 4; ++k) { xc[b][k] = 1.55f * (float)(x + k - V.left) + 20.3f; yc[b][k] = 1.6f * (float)(ys[g] - V.top) + 10.7f; } }
 #else
         if (active[g]) {
-            if (CPW) warp_coords4<CPW>(V, mesh, v, x, ys[g], xc[b], yc[b]);
+            if (CPW) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[b], yc[b]);
             else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) warp_combine(V.proj, ct[k], rt[g], V.wp, xc[b][k], yc[b][k]);
+                for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[b][k], yc[b][k]);
             }
         }
 #endif
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
     float xc[WARP_NG][4], yc[WARP_NG][4];
 #pragma unroll
     for (int g = 0; g < WARP_NG; ++g) {
-        if (active[g]) warp_coords4<CPW>(V, mesh, v, x, ys[g], xc[g], yc[g]);
+        if (active[g]) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[g], yc[g]);
         else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) xc[g][k] = yc[g][k] = -1.f;
@@ -442,6 +443,7 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
 
 // ---- CPW stage 1: images[i] = gain(remap(full_img, x_map, y_map)) (timed.cpp:90-94), 4 px per lane --------------
 // Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).
+template <int PROJ>
 __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                   SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp)
 {
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
     const float2 rt = V.rowtab[y];
     float xc[4], yc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) warp_combine(V.proj, V.coltab[min(x + k, V.aw - 1)], rt, V.wp, xc[k], yc[k]);
+    for (int k = 0; k < 4; ++k) warp_combine(PROJ, V.coltab[min(x + k, V.aw - 1)], rt, V.wp, xc[k], yc[k]);
     Taps t[4];
     Px2 r1[4], r2[4];
 #pragma unroll
