@@ -109,6 +109,69 @@ def test_user_masks_override(ms, cuda, oracle):
     b.close(); comp.close()
 
 
+def test_blocked_camera_and_uncovered_regions(ms, cuda, oracle):
+    """A view whose mask is entirely zero (a blocked camera) contributes nothing and owns no work; where no mask covers the panorama the
+    weight sum is 1e-5, the result mask is 0 and the output is 0 (blenders.cpp:803-810).  Also a view reduced to a one-pixel-wide strip."""
+    comp, cfg, gains = make_rig(ms, "mini6", mask_mode=0)
+    rois = [comp.view_geom(i).roi.tuple() for i in range(cfg["n"])]
+    masks = []
+    for i, r in enumerate(rois):
+        m = np.full((r[3], r[2]), 255, np.uint8)
+        if i == 1:
+            m[:] = 0                                   # blocked camera
+        if i == 3:
+            m[:] = 0; m[:, r[2] // 2] = 255             # a single column survives
+        if i == 4:
+            m[: r[3] // 2] = 0                          # upper half missing: leaves a hole in the panorama where nothing else covers
+        masks.append(m)
+        comp.set_mask(i, m)
+    comp.init_blender()
+    frames = [synth.frame(cfg["w"], cfg["h"], i, 5) for i in range(cfg["n"])]
+    pg = comp.pano_geom()
+    out16 = torch.full((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), 77, dtype=torch.int16, device=cuda)
+    out8 = torch.full((cfg["out_h"], cfg["out_w"], 3), 9, dtype=torch.uint8, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out8u=[out8], out16s=[out16])
+    torch.cuda.synchronize()
+    b = oracle.Blender([r[:2] for r in rois], [r[2:] for r in rois], cfg["num_bands"])
+    for i in range(cfg["n"]):
+        b.init_view(i, masks[i])
+    for i in range(cfg["n"]):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames[i], xm, ym, gains[i])
+    ref, refmask = b.blend()
+    assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    assert (refmask == 0).any() and (ref[refmask == 0] == 0).all()
+    b.close(); comp.close()
+
+
+def test_num_bands_is_capped_by_the_panorama_size(ms, cuda, oracle):
+    """MultiBandBlender::prepare caps num_bands at ceil(log2(max(dst width, height))) (blenders.cpp:241-245): 7 asked on a 64-wide pano
+    resolves to 6, and the tiny rig still stitches bit-exactly (all levels fall to the generic kernels)."""
+    n, w, h, out = 4, 40, 30, (64, 32)
+    comp = ms.Compositor(n, (w, h), ms.PROJ_SPHERICAL, synth.warp_scale(out[0]), num_bands=7, out_size=out)
+    gains = synth.gains(n)
+    for i in range(n):
+        comp.set_camera(i, *synth.camera(n, w, h, 110.0, i)); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    rois = [comp.view_geom(i).roi.tuple() for i in range(n)]
+    g = oracle.blender_prepare(oracle.result_roi([r[:2] for r in rois], [r[2:] for r in rois]), 7)
+    pg = comp.pano_geom()
+    assert pg.num_bands == g.num_bands == 6 and pg.dst_roi.tuple() == g.dst_roi.tuple()
+    frames = [synth.frame(w, h, i, 1) for i in range(n)]
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    b = oracle.Blender([r[:2] for r in rois], [r[2:] for r in rois], 7)
+    for i in range(n):
+        b.init_view(i, host(comp.mask(i)))
+    for i in range(n):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames[i], xm, ym, gains[i])
+    ref, refmask = b.blend()
+    assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    b.close(); comp.close()
+
+
 @pytest.mark.parametrize("nm", [(10, 10), (40, 40), (7, 13)])
 def test_mesh_to_map_vs_oracle(ms, cuda, oracle, nm):
     """convertMeshesToMap (APP/meshwarper.cpp:823-886): custom_resize up, scatter-average at half resolution
