@@ -204,33 +204,29 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
         const int lr = Li.h - 1, lc = Li.w - 1;
         const int own_a = min((strip * TAIL_STRIP) << (nb - l - 1), Lo.w);
         const int own_b = (strip * TAIL_STRIP + TAIL_STRIP >= w[nb]) ? Lo.w : min(((strip + 1) * TAIL_STRIP) << (nb - l - 1), Lo.w);
-        for (int y = ty; y < Lo.h; y += 4) {
-            int ry[5];
+        // flat index over the strip's outputs: every lane works (strips are only 16..40 columns wide); i -> (y, xo) with one fp32
+        // multiply: (i + 0.5) / wo is at least 0.5 / 64 away from an integer, far more than the fp32 error for i < 2^16
+        const float rwo = 1.0f / (float)wo;
+        for (int i = ty * 64 + tx; i < wo * Lo.h; i += 256) {
+            const int y = (int)(((float)i + 0.5f) * rwo), xo = i - y * wo;
+            const int x = a[l + 1] + xo;
+            int ry[5], cx[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const int r = 2 * y - 2 + k;
-                ry[k] = big ? (abs(r) > lr ? 2 * lr - abs(r) : abs(r)) : r101(r, Li.h);
+                const int r = 2 * y - 2 + k, q = 2 * x - 2 + k;
+                ry[k] = (big ? (abs(r) > lr ? 2 * lr - abs(r) : abs(r)) : r101(r, Li.h)) * wi;
+                cx[k] = (big ? (abs(q) > lc ? 2 * lc - abs(q) : abs(q)) : r101(q, Li.w)) - a[l];
             }
-            for (int xo = tx; xo < wo; xo += 64) {
-                const int x = a[l + 1] + xo;
-                int cx[5];
+            // separable: 5 horizontal sums (1 4 6 4 1), then the vertical one -- same integers as the 25-term sum
+            int hs[5];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int q = 2 * x - 2 + k;
-                    cx[k] = (big ? (abs(q) > lc ? 2 * lc - abs(q) : abs(q)) : r101(q, Li.w)) - a[l];
-                }
-                const int wv[5] = {1, 4, 6, 4, 1};
-                int acc = 0;
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const uint8_t *r = cur + ry[j] * wi;
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) acc += wv[j] * wv[k] * (int)r[cx[k]];
-                }
-                const int o = rne_shift(acc, 8);
-                nxt[y * wo + xo] = (uint8_t)o;
-                if (x >= own_a && x < own_b) out[(size_t)y * Lo.pitch + x] = (int16_t)o;
+            for (int j = 0; j < 5; ++j) {
+                const uint8_t *r = cur + ry[j];
+                hs[j] = (int)r[cx[0]] + (int)r[cx[4]] + 4 * ((int)r[cx[1]] + (int)r[cx[3]]) + 6 * (int)r[cx[2]];
             }
+            const int o = rne_shift(hs[0] + hs[4] + 4 * (hs[1] + hs[3]) + 6 * hs[2], 8);
+            nxt[i] = (uint8_t)o;
+            if (x >= own_a && x < own_b) out[(size_t)y * Lo.pitch + x] = (int16_t)o;
         }
         __syncthreads();
         cur = nxt;
