@@ -107,9 +107,20 @@ __device__ __forceinline__ void warp_combine(int proj, const float2 c, const flo
     ox = __builtin_fmaf(P.k[2], z_, __builtin_fmaf(P.k[1], y_, P.k[0] * x_));
     oy = __builtin_fmaf(P.k[5], z_, __builtin_fmaf(P.k[4], y_, P.k[3] * x_));
     const float oz = __builtin_fmaf(P.k[8], z_, __builtin_fmaf(P.k[7], y_, P.k[6] * x_));
-    // divide unconditionally and select (no trap on the GPU; same results): straight-line code instead of a divergent block per pixel
+    // Divide unconditionally and select (no trap on the GPU): straight-line code instead of a divergent block per pixel.  x/z and y/z
+    // share the denominator: one refined reciprocal (rcp + 2 Newton steps) and, per numerator, quotient + 2 residual corrections -- the
+    // compiler's own correctly rounded sequence without the div_scale / div_fixup wrappers, i.e. the same bits whenever z and the
+    // quotients are in the normal range (always, for a pixel that can land in an image).  The dense-map kernels (ms_build_maps,
+    // ms_build_warp_maps) and the per-frame kernels all go through this function, so they agree bit for bit by construction.
     const bool ok = proj == MS_PROJ_PLANE || oz > 0;
-    const float qx = ox / oz, qy = oy / oz;
+    const float r0 = __builtin_amdgcn_rcpf(oz);
+    const float e0 = __builtin_fmaf(-oz, r0, 1.f);
+    const float rz = __builtin_fmaf(e0, r0, r0);
+    float qx = ox * rz, qy = oy * rz;
+    qx = __builtin_fmaf(__builtin_fmaf(-oz, qx, ox), rz, qx);
+    qy = __builtin_fmaf(__builtin_fmaf(-oz, qy, oy), rz, qy);
+    qx = __builtin_fmaf(__builtin_fmaf(-oz, qx, ox), rz, qx);
+    qy = __builtin_fmaf(__builtin_fmaf(-oz, qy, oy), rz, qy);
     ox = ok ? qx : -1.f;
     oy = ok ? qy : -1.f;
 }
