@@ -1301,6 +1301,11 @@ static int build_plan(ms_ctx *c)
                     if (any_in(Nd[v][0], V.pw, V.ph, x0, y0, WARP_TW, WARP_TH)) {
                         WarpTile t{};
                         t.view = (short)v; t.x0 = (short)x0; t.y0 = (short)y0;
+                        if (x0 >= V.left && x0 + WARP_TW <= V.left + V.aw && y0 >= V.top && y0 + WARP_TH <= V.top + V.ah) {
+                            t.flags |= 4;         // interior tile: its table entries are known without the view descriptor
+                            t.ctab = (int)(c->tab_off[v] + (size_t)(x0 - V.left));
+                            t.rtab = (int)(c->tab_off[v] + (size_t)round_up(V.aw, 4) + (size_t)(y0 - V.top));
+                        }
                         tiles.push_back(t);
                         need0 += (double)std::min(WARP_TW, V.pw - x0) * std::min(WARP_TH, V.ph - y0);
                     }
@@ -2148,7 +2153,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
-            MS_PROJ_LAUNCH(k_warp_t, (true, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0);
+            MS_PROJ_LAUNCH(k_warp_t, (true, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0, (const float2 *)c->tabs.p);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
@@ -2156,9 +2161,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         int lds_ok = c->cfg.reserved[1] != 0 && c->warp_lds_bytes > 0;   // opt-in: LDS staging of the source tiles (measured slower than direct gathers)
         for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
         if (lds_ok)
-            MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1);
+            MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1, (const float2 *)c->tabs.p);
         else
-            MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0);
+            MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0, (const float2 *)c->tabs.p);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

@@ -72,7 +72,10 @@ struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *
 // Every per-frame kernel is driven by a list of tiles that are actually needed: tiles of a view whose
 // weights are zero at every band (most of the +-pi-straddling view, the seam-cut outer parts of the others)
 // are never produced or read.  Skipping them is exact: a zero weight contributes trunc(L * 0) == 0.
-struct WarpTile { short view, flags; short x0, y0; short sx0, sy0, sw, sh; };   // out tile origin + source bbox
+// out tile origin + source bbox (LDS-staged variant) + where the tile's projection tables start.  flags: bit 0 = bbox fits the LDS budget,
+// bit 1 = (CPW stage 1) reachable tile, bit 2 = every pixel of the tile lies inside the warped view in x and y (no reflect padding),
+// in which case ctab / rtab index the column / row terms of the tile's first column / row in the context's table buffer
+struct WarpTile { short view, flags; short x0, y0; short sx0, sy0, sw, sh; int ctab, rtab; };
 struct DownTile { short view, pad; short x0, y0; };                              // output (level l+1) tile origin
 struct BlendTile { short x0, y0; unsigned view_mask; };                          // pano tile origin + contributing views
 

@@ -231,7 +231,7 @@ template <bool CPW, bool STAGED, int PROJ>
 __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
-                                                         uint8_t *__restrict__ g0, long long g0_stride, int lds_ok)
+                                                         uint8_t *__restrict__ g0, long long g0_stride, int lds_ok, const float2 *__restrict__ tabs)
 {
     extern __shared__ uint4 s_tile4[];                       // optional staged source tile (packed BGR rows)
     const WarpTile T = tiles[blockIdx.x];
@@ -260,9 +260,20 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
     // building the coordinates of a group is then pure arithmetic, with no load between it and the tap reads
     float2 ct[4], rt[WARP_NG];
     if (!CPW) {
-        warp_coltab4(V, min(x, V.pw - 4), ct);
+        if (T.flags & 4) {            // interior tile: table addresses come from the tile entry alone, so these loads do not wait for
+                                      // the view descriptor (one round trip less on the wave's critical path)
+            float4 a, b;
+            const float2 *cp = tabs + T.ctab + 4 * (int)threadIdx.x;
+            __builtin_memcpy(&a, __builtin_assume_aligned(cp, 8), 16);
+            __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
+            ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
+            for (int g = 0; g < WARP_NG; ++g) rt[g] = tabs[T.rtab + (int)threadIdx.y + g * WARP_BY];
+        } else {
+            warp_coltab4(V, min(x, V.pw - 4), ct);
+#pragma unroll
+            for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
+        }
     }
     auto issue = [&](int g) {
         const int b = g & 1;
