@@ -1,0 +1,66 @@
+"""Randomised shapes for the per-op kernels (hypothesis): every size from 1x1 up, odd widths, pitches that are not the row size.
+Integer outputs must equal the oracle bit for bit.  Complements the fixed-size cases of test_prims_gpu.py."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from helpers import host, to_dev, to_dev_roi
+
+pytestmark = pytest.mark.gpu
+FAST = settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+dims = st.tuples(st.integers(1, 70), st.integers(1, 90))
+
+
+@FAST
+@given(size=dims, seed=st.integers(0, 2 ** 31 - 1), roi=st.booleans())
+def test_pyr_down_up_16s_any_size(ms, cuda, oracle, size, seed, roi):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-32768, 32768, size=(size[0], size[1], 3), dtype=np.int16)
+    up = (lambda x: to_dev_roi(x, rng)) if roi else to_dev
+    assert np.array_equal(host(ms.pyr_down(up(a))), oracle.pyr_down_16s(a))
+    assert np.array_equal(host(ms.pyr_up(up(a))), oracle.pyr_up_16s(a))
+
+
+@FAST
+@given(size=dims, src_size=dims, seed=st.integers(0, 2 ** 31 - 1))
+def test_remap_linear_any_size_and_wild_coordinates(ms, cuda, oracle, size, src_size, seed):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, 256, size=(src_size[0], src_size[1], 3), dtype=np.uint8)
+    mx = rng.uniform(-3, src_size[1] + 3, size=size).astype(np.float32)
+    my = rng.uniform(-3, src_size[0] + 3, size=size).astype(np.float32)
+    wild = rng.random(size) < 0.05                       # NaN / inf / huge / exactly-on-the-border coordinates
+    mx[wild] = rng.choice(np.array([np.nan, np.inf, -np.inf, 1e20, -1e20, -1.0, 0.0, src_size[1] - 1.0, float(src_size[1])], np.float32), size=int(wild.sum()))
+    got = ms.remap(to_dev(src), to_dev(mx), to_dev(my), ms.INTER_LINEAR)
+    assert np.array_equal(host(got), oracle.remap_linear_8uc3(src, mx, my))
+    got_r = ms.remap(to_dev(src), to_dev(mx), to_dev(my), ms.INTER_LINEAR, ms.BORDER_REFLECT)
+    assert np.array_equal(host(got_r), oracle.remap_linear_reflect_8uc3(src, mx, my))
+
+
+@FAST
+@given(size=dims, pad=st.tuples(st.integers(0, 9), st.integers(0, 9), st.integers(0, 9), st.integers(0, 9)), seed=st.integers(0, 2 ** 31 - 1))
+def test_copy_make_border_reflect_any_size(ms, cuda, oracle, size, pad, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(size[0], size[1], 3), dtype=np.uint8)
+    t, b, l, r = pad
+    got = ms.copy_make_border(to_dev(a), t, b, l, r, ms.BORDER_REFLECT)
+    assert np.array_equal(host(got), oracle.copy_make_border_reflect(a, t, b, l, r))
+
+
+@FAST
+@given(size=dims, seed=st.integers(0, 2 ** 31 - 1))
+def test_accumulate_normalise_any_size(ms, cuda, oracle, size, seed):
+    """addSrcWeightGpu32F + normalizeUsingWeightMapGpu32F (multiband_blend.cu:36-108) on random int16 / fp32 data, incl. weights of 0."""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(-2000, 2000, size=(size[0], size[1], 3), dtype=np.int16)
+    w = rng.random(size, dtype=np.float32)
+    w[rng.random(size) < 0.2] = 0.0
+    dst = rng.integers(-500, 500, size=src.shape, dtype=np.int16)
+    dw = rng.random(size, dtype=np.float32)
+    d_dev, dw_dev = to_dev(dst), to_dev(dw)
+    ms.add_src_weight_32f(to_dev(src), to_dev(w), d_dev, dw_dev)
+    rd, rdw = dst.copy(), dw.copy()
+    oracle.add_src_weight_32f(src, w, rd, rdw)
+    assert np.array_equal(host(d_dev), rd) and np.array_equal(host(dw_dev), rdw)
+    ms.normalize_using_weight_32f(dw_dev, d_dev)
+    oracle.normalize_32f(rdw, rd)
+    assert np.array_equal(host(d_dev), rd)
