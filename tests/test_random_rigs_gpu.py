@@ -1,0 +1,48 @@
+"""Randomised rigs (hypothesis): number of views, source size, field of view, output width, bands, projection, mask mode, CPW on/off.
+Every draw is calibrated on the device and one frame is compared with the oracle bit for bit (16S panorama + result mask)."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import synth
+from helpers import host, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(n=st.integers(2, 6), w=st.integers(48, 150), h=st.integers(40, 110), spread=st.floats(1.25, 1.9), out_w=st.sampled_from([192, 256, 320, 448]),
+       bands=st.integers(1, 4), cyl=st.booleans(), seams=st.booleans(), cpw=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed):
+    hfov = min(130.0, 360.0 / n * spread)
+    proj = ms.PROJ_CYLINDRICAL if cyl else ms.PROJ_SPHERICAL
+    comp = ms.Compositor(n, (w, h), proj, synth.warp_scale(out_w), num_bands=bands, enable_cpw=cpw, out_size=(out_w, out_w // 2))
+    rng = np.random.default_rng(seed)
+    gains = [float(g) for g in rng.uniform(0.9, 1.1, n)]
+    for i in range(n):
+        comp.set_camera(i, *synth.camera(n, w, h, hfov, i)); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1 if seams else 0); comp.init_blender()
+    meshes = None
+    if cpw:
+        meshes = []
+        for i in range(n):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 6, 7, phase=0.4 * i, amp=float(rng.uniform(0.5, 5.0))))
+            meshes.append(tuple(host(m) for m in comp.mesh_maps(i)))
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    rois = [comp.view_geom(i).roi.tuple() for i in range(n)]
+    b = oracle.Blender([r[:2] for r in rois], [r[2:] for r in rois], bands)
+    for i in range(n):
+        b.init_view(i, host(comp.mask(i)))
+    for i in range(n):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames[i], xm, ym, gains[i], *(meshes[i] if meshes else (None, None)))
+    ref, refmask = b.blend()
+    assert b.num_bands == pg.num_bands
+    assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    b.close(); comp.close()
