@@ -1,5 +1,7 @@
 """Randomised shapes for the per-op kernels (hypothesis): every size from 1x1 up, odd widths, pitches that are not the row size.
 Integer outputs must equal the oracle bit for bit.  Complements the fixed-size cases of test_prims_gpu.py."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -7,7 +9,7 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 from helpers import host, to_dev, to_dev_roi
 
 pytestmark = pytest.mark.gpu
-FAST = settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+FAST = settings(max_examples=int(os.environ.get("MS_TEST_EXAMPLES", 40)), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 dims = st.tuples(st.integers(1, 70), st.integers(1, 90))
 
 

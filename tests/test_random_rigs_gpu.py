@@ -1,5 +1,7 @@
 """Randomised rigs (hypothesis): number of views, source size, field of view, output width, bands, projection, mask mode, CPW on/off.
 Every draw is calibrated on the device and one frame is compared with the oracle bit for bit (16S panorama + result mask)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,7 +13,7 @@ from helpers import host, to_dev
 pytestmark = pytest.mark.gpu
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("MS_TEST_EXAMPLES", 25)), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(n=st.integers(2, 6), w=st.integers(48, 150), h=st.integers(40, 110), spread=st.floats(1.25, 1.9), out_w=st.sampled_from([192, 256, 320, 448]),
        bands=st.integers(1, 4), cyl=st.booleans(), seams=st.booleans(), cpw=st.booleans(), seed=st.integers(0, 10 ** 6))
 def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed):
