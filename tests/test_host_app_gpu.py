@@ -38,6 +38,22 @@ def test_host_app_matches_python_binding(ms, cuda, tmp_path, rig):
     comp.close()
 
 
+def test_host_app_nv12_ingest(ms, cuda, tmp_path):
+    """--nv12: cameras deliver NV12, the host uploads half the bytes and cvtColor(YUV2BGR_NV12) (networking.cpp:45-47) runs on the device."""
+    cfg = synth.CONFIGS["mini6"]
+    info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
+                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 8, "--nv12")
+    assert info["nv12"] is True
+    got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
+    comp, _, _ = make_rig(ms, "mini6")
+    out8 = torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda)
+    frames = [ms.nv12_to_bgr(to_dev(synth.nv12_frame(cfg["w"], cfg["h"], i))) for i in range(cfg["n"])]
+    comp.stitch([frames], out8u=[out8])
+    torch.cuda.synchronize()
+    assert np.array_equal(got, host(out8))
+    comp.close()
+
+
 def test_host_app_cpw_with_concurrent_recalibration(ms, cuda, tmp_path):
     """CPW on, meshes swapped by the recalibration thread while frames flow: must run to completion and produce a covered panorama."""
     cfg = synth.CONFIGS["mini6"]

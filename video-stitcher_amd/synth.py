@@ -53,6 +53,20 @@ def frame(w, h, i, t, noise=True):
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
+def nv12_frame(w, h, i):
+    """Synthetic NV12 camera frame (h*3/2 x w uint8): Y = the green-channel pattern of frame(noise=False), U/V = integer ramps.
+    Same bytes as synth_nv12() of host/stitch_app.cpp."""
+    x = np.arange(w, dtype=np.float64)[None, :]
+    y = np.arange(h, dtype=np.float64)[:, None]
+    chk = 40.0 * (((np.arange(w)[None, :] // 32) + (np.arange(h)[:, None] // 32)) & 1)
+    Y = np.clip(np.rint(128.0 + 60.0 * np.sin(2.0 * math.pi * (x / 97.0 + y / 61.0 + i / 7.0 + 1.0 / 3.0)) + chk), 0, 255).astype(np.uint8)
+    uv = np.empty((h // 2, w), np.uint8)
+    xs = np.arange(w // 2)[None, :]; ys = np.arange(h // 2)[:, None]
+    uv[:, 0::2] = (64 + (3 * xs + 5 * i) % 128 + 0 * ys).astype(np.uint8)
+    uv[:, 1::2] = (64 + (2 * ys + 7 * i) % 128 + 0 * xs).astype(np.uint8)
+    return np.vstack([Y, uv])
+
+
 def mesh(aw, ah, n_rows, n_cols, phase=0.0, amp=8.0):
     """Forward vertex mesh (N x M) in view-ROI pixels: identity + amp*sin(2pi u + phase)*sin(pi v)."""
     v = np.linspace(0.0, 1.0, n_rows)[:, None]
