@@ -13,4 +13,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $B > $OUT/be
 python bench.py --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err || true
 python tools/summarize_traffic.py $OUT $TAG $CFG $F
 # gpurun only merges gpurun_out/ back: park the summaries there (copy them into profiles/ and commit)
+python tools/report.py $TAG > /dev/null 2>&1 || true
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/traffic_latest.json gpurun_out/profiles_out/

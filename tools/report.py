@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline report from the committed profiles: launch time (rocprofv3 kernel trace), HBM bytes (PMC, calibrated), VALU
+instructions and occupancy (SQ counters), algorithmic bytes (bench.py) -> profiles/<tag>_report.md
+
+  python tools/report.py r01"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(path):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for block in re.split(r"\n(?=\S)", open(path).read()):
+        lines = block.strip().split("\n")
+        d = {}
+        for x in lines[1:]:
+            m = re.match(r"\s+(\S+)\s+([\d.]+)\s+\(mean launch ([\d.]+)", x)
+            if m:
+                d[m.group(1)] = float(m.group(2)); d["_us"] = float(m.group(3))
+        if d:
+            out[lines[0].strip()] = d
+    return out
+
+
+def short(n):
+    return n.replace("void ", "").replace("ms::", "").split("(")[0]
+
+
+def main(tag):
+    prof = os.path.join(ROOT, "profiles")
+    bench = json.load(open(os.path.join(prof, "%s_bench.json" % tag)))
+    traffic = json.load(open(os.path.join(prof, "%s_traffic.json" % tag)))
+    ctr = counters(os.path.join(prof, "%s_counters.txt" % tag))
+    F = traffic["frames_per_launch"]
+    clk = 2.33e9
+    rows = []
+    for k, v in traffic["kernels"].items():
+        if k in ("k_warp", "k_blend_l0", "k_down_l0") or v["launches"] < 20 or "calib" in k:      # (aliases, calibration-time one-offs)
+            continue
+        c = next((d for n, d in ctr.items() if short(n) == k), {})
+        waves = c.get("SQ_WAVES", 0)
+        valu = c.get("SQ_INSTS_VALU", 0)
+        us = v["mean_ns"] / 1e3
+        busy = valu * 4 / 1024 / (us * 1e-6 * clk) if valu else None
+        occ = c.get("SQ_WAVE_CYCLES", 0) * 4 / (c.get("_us", us) * 1e-6 * clk) / 1024 if c.get("SQ_WAVE_CYCLES") else None
+        rows.append((us * v["launches"], k, v["launches"], us, v["hbm_bytes_per_launch"], waves, valu / waves if waves else None, busy, occ))
+    rows.sort(reverse=True)
+    lines = ["# Per-kernel report (%s): config 2, %d frames per launch, one context / one stream" % (tag, F), "",
+             "Sources: `%s_kernel_trace.txt`/`%s_traffic.json` (rocprofv3 kernel trace; FETCH_SIZE x2.0 + WRITE_SIZE x1.0, calibrated on a 1 GiB copy),"
+             " `%s_counters.txt` (SQ counters), `%s_bench.json` (bench.py line).  VALU busy = VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.33 GHz)." % (tag, tag, tag, tag), "",
+             "| kernel | mean launch µs | µs / frame | HBM MB / launch | HBM TB/s | waves | VALU / wave | VALU busy | waves / SIMD |", "|---|---|---|---|---|---|---|---|---|"]
+    for _, k, n, us, hb, waves, vpw, busy, occ in rows:
+        lines.append("| `%s` | %.1f | %.2f | %.0f | %.2f | %s | %s | %s | %s |" % (
+            k, us, us / F, hb / 1e6, hb / (us * 1e-6) / 1e12, "%d" % waves if waves else "-", "%.0f" % vpw if vpw else "-",
+            "%.2f" % busy if busy is not None else "-", "%.1f" % occ if occ is not None else "-"))
+    r = bench["roofline"]
+    lines += ["", "bench.py: **%.0f frames/s** (%s); dominant kernel `%s`: %.0f MB algorithmic / %.1f µs = %.0f GB/s = **%.3f of 8 TB/s**; PMC traffic of that "
+              "launch %.0f MB." % (bench["value"], bench["config"]["workload"], r["kernel"], r["alg_bytes_per_launch"] / 1e6, r["mean_launch_ms"] * 1e3,
+                                   r["achieved"], r["frac"], (r["traffic"] or 0) / 1e6),
+              "cpu_baseline: %.1f frames/s on %d threads of %s (%s)." % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["cores"],
+                                                                          bench["cpu_baseline"].get("cpu", "?"), bench["cpu_baseline"]["kind"]) if "cpu_baseline" in bench else ""]
+    out = os.path.join(prof, "%s_report.md" % tag)
+    open(out, "w").write("\n".join(lines) + "\n")
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
