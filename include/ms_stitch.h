@@ -251,6 +251,13 @@ MS_API int ms_set_mesh_maps(ms_ctx *ctx, int view, const ms_image *x_mesh, const
  * No allocation, no host sync. */
 MS_API int ms_stitch(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
                      ms_stream stream);
+/* The reference's own call shape (timed.cpp:127-137): stitch_online(view) for every view, then MultiBandBlender::blend.  ms_feed records the
+ * view's device image (8UC3, source size; borrowed until ms_blend), ms_blend composites the frame exactly like ms_stitch(ctx, 1, views, ...)
+ * and fails with MS_ERR_STATE if a view was not fed since the previous blend.  (feed_online's per-view work is batched across views here, so
+ * it runs inside ms_blend; the stream argument of ms_feed is accepted for signature parity and ignored.) */
+MS_API int ms_feed(ms_ctx *ctx, int view, const ms_image *img, ms_stream stream);
+MS_API int ms_blend(ms_ctx *ctx, ms_image *out8u, ms_image *out16s, ms_stream stream);
+
 /* View sharding (BASELINE configs[4]): create every rank's context with the SAME cameras/masks and
  * ms_config.reserved[3] = number of shards S (<= 4), reserved[4] = this rank's shard index; shard k owns the contiguous block
  * of views [k*N/S, (k+1)*N/S).  The weighted accumulation into the dst Laplacian pyramid is a sum of int16 terms

@@ -314,6 +314,26 @@ def test_feather_needs_single_band_context(ms, cuda):
     comp.close()
 
 
+def test_feed_then_blend_equals_stitch(ms, cuda):
+    """The reference's call shape -- stitch_online per view, then blend (timed.cpp:127-137) -- gives the ms_stitch frame; blend without all
+    views fed is a state error."""
+    comp, cfg, _ = make_rig(ms, "mini6")
+    frames = [to_dev(synth.frame(cfg["w"], cfg["h"], i, 4)) for i in range(cfg["n"])]
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    want = torch.zeros(shape, dtype=torch.int16, device=cuda); got = torch.zeros(shape, dtype=torch.int16, device=cuda)
+    comp.stitch([frames], out16s=[want])
+    for i in reversed(range(cfg["n"])):            # any order
+        comp.feed(i, frames[i])
+    comp.blend(out16s=got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    comp.feed(0, frames[0])
+    with pytest.raises(ms.MsError, match="were fed"):
+        comp.blend(out16s=got)
+    comp.close()
+
+
 def test_state_errors(ms, cuda):
     comp = ms.Compositor(2, (64, 48), ms.PROJ_SPHERICAL, 50.0, num_bands=2, out_size=(0, 0))
     with pytest.raises(ms.MsError, match="camera 0 not set"):

@@ -1126,6 +1126,8 @@ struct ms_ctx {
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0;
+    ms_image fed[MAX_VIEWS] = {};      // ms_feed: the views of the frame being assembled (borrowed until ms_blend)
+    unsigned fed_mask = 0;
     DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
@@ -2255,6 +2257,29 @@ int ms_stitch_timed(ms_ctx *c, int n_frames, const ms_image *views, ms_image *ou
     int n = 0;
     const int e = stitch_impl(c, n_frames, views, out8u, out16s, as_stream(stream), cap, names, ms_out, &n);
     return e ? e : n;
+}
+
+// ---- the reference's call shape: stitch_online(view) x N, then blend (timed.cpp:56-152) ------------------------------------
+// feed_online's per-view work (remap, gain, pyramids, accumulate) is not run per view here: the compositor batches all views of a
+// frame into the same launches, so ms_feed only records the view and ms_blend runs the frame.  The images must stay valid (and
+// unmodified) until ms_blend returns -- they do in the reference's stitch_one, whose full_imgs outlive the blend call.
+int ms_feed(ms_ctx *c, int view, const ms_image *img, ms_stream)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    MS_CHECK(img && img->data && img->type == MS_8UC3 && img->rows == c->cfg.src_height && img->cols == c->cfg.src_width,
+             "ms_feed: view %d must be 8UC3 %dx%d", view, c->cfg.src_width, c->cfg.src_height);
+    c->fed[view] = *img;
+    c->fed_mask |= 1u << view;
+    return MS_OK;
+}
+
+int ms_blend(ms_ctx *c, ms_image *out8u, ms_image *out16s, ms_stream stream)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    const unsigned all = (c->N >= 32) ? 0xffffffffu : ((1u << c->N) - 1u);
+    if ((c->fed_mask & all) != all) return fail(MS_ERR_STATE, "ms_blend: only views 0x%x of 0x%x were fed since the last blend", c->fed_mask, all);
+    c->fed_mask = 0;
+    return stitch_impl(c, 1, c->fed, out8u, out16s, as_stream(stream), 0, nullptr, nullptr, nullptr);
 }
 
 // ---- view sharding: partial sums on every rank, finish on the sink (BASELINE configs[4]) -------------

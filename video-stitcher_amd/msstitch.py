@@ -60,7 +60,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp",
+    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend",
 ]
 
 _lib = None
@@ -382,6 +382,14 @@ class Compositor:
         fp = C.POINTER(C.c_float)
         _chk(load().ms_set_mesh_interp(self._ctx, view, a[0].ctypes.data_as(fp), a[1].ctypes.data_as(fp), a[2].ctypes.data_as(fp),
                                        a[3].ctypes.data_as(fp), n, m, C.c_float(progress), _stream()))
+
+    def feed(self, view, image):
+        _chk(load().ms_feed(self._ctx, view, C.byref(img(image)), _stream()))
+
+    def blend(self, out8u=None, out16s=None):
+        o8 = C.byref(img(out8u)) if out8u is not None else None
+        o16 = C.byref(img(out16s)) if out16s is not None else None
+        _chk(load().ms_blend(self._ctx, o8, o16, _stream()))
 
     def mesh_displacement(self, view):
         d = C.c_float(0)

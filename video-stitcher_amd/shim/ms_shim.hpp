@@ -91,6 +91,15 @@ public:
         if (out16s) o16 = wrap(*out16s);
         check(ms_stitch(ctx_, (int)(v.size() / n_), v.data(), out8u ? &o8 : nullptr, out16s ? &o16 : nullptr, s));
     }
+    // MultiBandBlender::feed_online(img, idx, stream) / blend(dst, dst_mask, gpuOut, true) call shape (timed.cpp:110,137)
+    template <class Mat> void feed_online(const Mat &img, int idx, ms_stream s = nullptr) { ms_image v = wrap(img); check(ms_feed(ctx_, idx, &v, s)); }
+    template <class Mat> void blend(Mat *out8u, Mat *out16s, ms_stream s = nullptr)
+    {
+        ms_image o8{}, o16{};
+        if (out8u) o8 = wrap(*out8u);
+        if (out16s) o16 = wrap(*out16s);
+        check(ms_blend(ctx_, out8u ? &o8 : nullptr, out16s ? &o16 : nullptr, s));
+    }
     ms_pano_geom panoGeom() const { ms_pano_geom g; check(ms_get_pano_geom(ctx_, &g)); return g; }
     ms_view_geom viewGeom(int i) const { ms_view_geom g; check(ms_get_view_geom(ctx_, i, &g)); return g; }
     ms_ctx *raw() { return ctx_; }

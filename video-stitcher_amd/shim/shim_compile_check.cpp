@@ -17,6 +17,8 @@ int shim_compile_check()
         msshim::Compositor comp(6, 1920, 1080, MS_PROJ_CYLINDRICAL, 611.f, 5, false, 3840, 1920);
         std::vector<FakeGpuMat> frames(6);
         comp.stitch_one(frames, &a, (FakeGpuMat *)nullptr);
+        for (int i = 0; i < 6; ++i) comp.feed_online(frames[i], i);
+        comp.blend(&a, (FakeGpuMat *)nullptr);
     } catch (const msshim::Error &e) {
         return e.code;
     }
