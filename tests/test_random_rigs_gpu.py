@@ -48,3 +48,44 @@ def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, ban
     assert b.num_bands == pg.num_bands
     assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
     b.close(); comp.close()
+
+
+@settings(max_examples=int(os.environ.get("MS_TEST_EXAMPLES", 15)), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(n=st.integers(2, 5), w=st.integers(48, 120), h=st.integers(40, 90), spread=st.floats(1.3, 1.8), out_w=st.sampled_from([192, 256, 320]),
+       nf=st.integers(1, 3), sharp=st.sampled_from([0.02, 0.05, 0.2]), holes=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_random_feather_rig_batches_and_canvas(ms, cuda, oracle, n, w, h, spread, out_w, nf, sharp, holes, seed):
+    """FeatherBlender mode on random rigs, batches of 1-3 frames, random holes in the masks, 16S result + mask + 8U canvas."""
+    from test_compositor_gpu import canvas_from
+    hfov = min(130.0, 360.0 / n * spread)
+    out = (out_w, out_w // 2)
+    comp = ms.Compositor(n, (w, h), ms.PROJ_SPHERICAL, synth.warp_scale(out_w), num_bands=0, out_size=out, max_frames=nf)
+    rng = np.random.default_rng(seed)
+    gains = [float(g) for g in rng.uniform(0.9, 1.1, n)]
+    for i in range(n):
+        comp.set_camera(i, *synth.camera(n, w, h, hfov, i)); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(0)
+    masks = []
+    for i in range(n):
+        m = host(comp.mask(i)).copy()
+        if holes:
+            y0, x0 = rng.integers(0, max(1, m.shape[0] - 8)), rng.integers(0, max(1, m.shape[1] - 8))
+            m[y0:y0 + 8, x0:x0 + 8] = 0
+            comp.set_mask(i, m)
+        masks.append(m)
+    comp.init_feather(sharp)
+    frames = [[rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)] for _ in range(nf)]
+    pg = comp.pano_geom()
+    out16 = [torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda) for _ in range(nf)]
+    out8 = [torch.zeros((out[1], out[0], 3), dtype=torch.uint8, device=cuda) for _ in range(nf)]
+    comp.stitch([[to_dev(f) for f in fr] for fr in frames], out8u=out8, out16s=out16)
+    torch.cuda.synchronize()
+    corners = [comp.view_geom(i).roi.tuple()[:2] for i in range(n)]
+    for t in range(nf):
+        warped = []
+        for i in range(n):
+            xm, ym = [host(m) for m in comp.maps(i)]
+            warped.append(oracle.convert_scale_8u(oracle.remap_linear_8uc3(frames[t][i], xm, ym), gains[i]))
+        ref16, refmask, roi = oracle.feather_blend(corners, warped, masks, sharp)
+        assert np.array_equal(host(out16[t]), ref16) and np.array_equal(host(comp.result_mask()), refmask)
+        assert np.array_equal(host(out8[t]), canvas_from(ref16, pg, out[0], out[1]))
+    comp.close()
