@@ -2147,7 +2147,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
         if (c->cfg.reserved[0] == 0)
-            MS_PROJ_LAUNCH(k_stage1_t, (), (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX)), 0, st), 
+            MS_PROJ_LAUNCH(k_stage1_t, (), (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH / 2, 256 / WARP_BX)), 0, st), 
                 (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(

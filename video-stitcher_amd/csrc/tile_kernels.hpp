@@ -275,14 +275,20 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
             for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
         }
     }
+    if (CPW && WARP_NG <= 2) {        // the dense mesh maps of both row groups are read up front too (one round trip, not one per group)
+#pragma unroll
+        for (int g = 0; g < WARP_NG; ++g)
+            if (active[g]) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[g & 1], yc[g & 1]);
+    }
     auto issue = [&](int g) {
         const int b = g & 1;
 #if defined(MS_PROBE) && MS_PROBE == 3       // roofline probe: affine coordinates instead of the projection (same gather density)
         if (active[g]) { for (int k = 0; k < 4; ++k) { xc[b][k] = 1.55f * (float)(x + k - V.left) + 20.3f; yc[b][k] = 1.6f * (float)(ys[g] - V.top) + 10.7f; } }
 #else
         if (active[g]) {
-            if (CPW) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[b], yc[b]);
-            else {
+            if (CPW) {
+                if (WARP_NG > 2) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[b], yc[b]);      // (<= 2 groups: already read up front)
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[b][k], yc[b][k]);
             }
@@ -464,45 +470,67 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
     if (!(T.flags & 2) && *disp.p[v] <= disp.limit_bits) return;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * (int)threadIdx.x;
+    if (x >= V.aw) return;
     const uint8_t *sp = src.p[f * n_views + v];
     const unsigned sstep = src.step[f * n_views + v];
-    for (int y = T.y0 + (int)threadIdx.y; y < T.y0 + WARP_TH; y += (int)blockDim.y) {
-    if (x >= V.aw || y >= V.ah) continue;
-    const float2 rt = V.rowtab[y];
-    float xc[4], yc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) warp_combine(PROJ, V.coltab[min(x + k, V.aw - 1)], rt, V.wp, xc[k], yc[k]);
-    Taps t[4];
-    Px2 r1[4], r2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        t[k] = make_taps(xc[k], yc[k], srows, scols);
-        const unsigned off = tap_offset(t[k].x1, t[k].y1, srows, scols, sstep);
-        r1[k] = load_px2(sp, off);
-        r2[k] = load_px2(sp + sstep, off);
-    }
-    uint8_t o8[12];
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        float o[2][3];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (!t[k + j].fast) fix_border_taps(r1[k + j], r2[k + j], t[k + j].x1, t[k + j].y1, srows, scols);
-        blend_taps2(t[k], t[k + 1], r1[k], r2[k], r1[k + 1], r2[k + 1], o[0], o[1]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o8[3 * (k + j) + c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f));
-    }
-    uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
+    // column terms once per lane (as in k_warp_t); the rows of the tile are walked as a software pipeline: the tap reads of the next
+    // row are in flight while the current one is blended
+    float2 ct[4];
     if (x + 3 < V.aw) {
-        unsigned w[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) w[i] = (unsigned)o8[4 * i] | ((unsigned)o8[4 * i + 1] << 8) | ((unsigned)o8[4 * i + 2] << 16) | ((unsigned)o8[4 * i + 3] << 24);
-        __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
+        float4 a, b;
+        __builtin_memcpy(&a, __builtin_assume_aligned(V.coltab + x, 8), 16);
+        __builtin_memcpy(&b, __builtin_assume_aligned(V.coltab + x + 2, 8), 16);
+        ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
     } else {
-        for (int k = 0; k < 4 && x + k < V.aw; ++k) { d[3 * k] = o8[3 * k]; d[3 * k + 1] = o8[3 * k + 1]; d[3 * k + 2] = o8[3 * k + 2]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ct[k] = V.coltab[min(x + k, V.aw - 1)];
     }
+    constexpr int S1_BY = (WARP_TH / 2 < 256 / WARP_BX) ? WARP_TH / 2 : 256 / WARP_BX;      // lane rows of the block (launch uses the same)
+    constexpr int S1_NG = WARP_TH / S1_BY;                                                 // row groups per lane
+    float xc[2][4], yc[2][4];
+    Px2 r1[2][4], r2[2][4];
+    auto issue = [&](int y, int b) {
+        if (y >= V.ah) return;
+        const float2 rt = V.rowtab[y];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            warp_combine(PROJ, ct[k], rt, V.wp, xc[b][k], yc[b][k]);
+            const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
+            r1[b][k] = load_px2(sp, off);
+            r2[b][k] = load_px2(sp + sstep, off);
+        }
+    };
+    issue(T.y0 + (int)threadIdx.y, 0);
+#pragma unroll
+    for (int g = 0; g < S1_NG; ++g) {
+        const int b = g & 1, y = T.y0 + (int)threadIdx.y + g * S1_BY;
+        if (g + 1 < S1_NG) issue(y + S1_BY, b ^ 1);
+        if (y >= V.ah) continue;
+        unsigned w[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+            float o[2][3];
+            Taps t[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
+                if (!t[j].fast) fix_border_taps(r1[b][k + j], r2[b][k + j], t[j].x1, t[j].y1, srows, scols);
+            }
+            blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int i = 3 * (k + j) + c;          // byte i of the 12 interleaved output bytes
+                    w[i >> 2] = sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), i & 3, w[i >> 2]);
+                }
+        }
+        uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
+        if (x + 3 < V.aw) __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
+        else {
+            for (int k = 0; k < 4 && x + k < V.aw; ++k)
+                for (int c = 0; c < 3; ++c) { const int i = 3 * k + c; d[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3))); }
+        }
     }
 }
 
