@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=48, help="frames per step, split evenly over --streams contexts (1 = live mode)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per step, split evenly over --streams contexts (default 48 = 3 x 16; cfg3: 16 on one context; cfg5: 24; 1 = live mode)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -242,10 +242,18 @@ def main():
     ap.add_argument("--recalib-every", type=int, default=60,
                     help="cfg3 only: re-expand new CPW meshes (ms_set_mesh x views) every this many frames, inside the timed region "
                          "(BASELINE configs[2]: recalibrate every 60 f); 0 = never")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=None,
                     help="contexts / HIP streams a step's frames are split over (default 3 x 16 frames: the small coarse-level kernels of one "
                          "batch overlap the large kernels of another: +13 % over one stream)")
     args = ap.parse_args()
+    if args.view_shards > 1:          # one context per shard, no stream splitting
+        args.streams = 1
+        if args.frames is None:
+            args.frames = 4 if args.config == "cfg5" else 16
+    if args.streams is None:        # cfg3 re-expands the CPW meshes on every context: one context there, three elsewhere
+        args.streams = 1 if args.config == "cfg3" else 3
+    if args.frames is None:
+        args.frames = {"cfg5": 8}.get(args.config, 16) * args.streams
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
