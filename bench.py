@@ -55,6 +55,9 @@ def kernel_bytes(comp, cfg, n_frames, cpw):
         if l == 0:
             b += 3.0 * cfg["out_w"] * cfg["out_h"]
         kb["k_blend_l%d" % l] = b
+    # fused coarse-level launches cover several of the per-level entries above
+    kb["k_down_tail"] = sum(v for k, v in kb.items() if k.startswith("k_down_l") and int(k[8:]) >= 3)
+    kb["k_blend_tail"] = sum(v for k, v in kb.items() if k.startswith("k_blend_l") and int(k[9:]) >= 3)
     return {k: v * n_frames for k, v in kb.items()}, sumP, Q, A
 
 
@@ -420,7 +423,7 @@ def main():
            "calls": int(per_call.size), "frames_per_call": Fs}
     kb, sumP, Q, A = kernel_bytes(comp, cfg, Fs, cpw)
     dom = max(kmean, key=kmean.get)
-    achieved = kb[dom] / (kmean[dom] * 1e-3) / 1e9          # GB/s
+    achieved = kb.get(dom, 0.0) / (kmean[dom] * 1e-3) / 1e9          # GB/s
     b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), [0], 0, (cfg["out_w"], cfg["out_h"]))  # placeholder, replaced below
     P_list = []
     for i in range(cfg["n"]):
@@ -454,7 +457,7 @@ def main():
                                                                   " [DEBUG: ranks share one GPU, gloo]" if share else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": int(kb[dom]), "mean_launch_ms": round(kmean[dom], 5)},
+                         "alg_bytes_per_launch": int(kb.get(dom, 0)), "mean_launch_ms": round(kmean[dom], 5)},
             "frame_roofline": {"alg_bytes_per_frame": int(b_alg_frame), "gpu_ms_per_frame": round(gpu_ms_step / Fs, 5),
                                "achieved_GBps": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 1e9, 1),
                                "frac": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),

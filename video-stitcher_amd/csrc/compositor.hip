@@ -518,6 +518,96 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
     }
 }
 
+// ---- fused tail of the band chain: the coarse bands nb .. t of one (frame, column strip) in one workgroup -------------------
+// The coarsest bands are tiny (config 2: 120x20, 240x40, 480x80): a launch per band is pure latency (3 x 10-17 us), and at one frame per
+// call these launches are a third of the frame time.  Each band is computed from its views exactly as k_blend_top / k_blend do; the
+// collapsed bands above t stay in LDS (three int16 planes of the strip plus the columns pyrUp needs), only band t is stored -- it is all
+// the next (vectorised) band kernel reads.  Column ranges of a strip: band t owns [a_t, b_t); band l+1 needs [a_l/2 - 1, (b_l-1)/2 + 1].
+constexpr int BTAIL_W = 32;             // columns of band t per strip
+__host__ __device__ inline void btail_range(const int *qw, int t, int nb, int strip, int *a, int *b)
+{
+    a[t] = strip * BTAIL_W; b[t] = min(a[t] + BTAIL_W, qw[t]);
+    for (int l = t; l < nb; ++l) {
+        a[l + 1] = max(a[l] / 2 - 1, 0) & ~1;
+        b[l + 1] = min(((b[l] - 1) / 2 + 2 + 1) & ~1, qw[l + 1]);
+    }
+}
+__global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__ views, PanoDesc P, int t,
+                                                    const int16_t *__restrict__ gl, long long gl_stride,
+                                                    int16_t *__restrict__ cl, long long cl_stride)
+{
+    extern __shared__ int16_t s_c[];
+    const int nb = P.nb, f = blockIdx.z, strip = blockIdx.x, c = blockIdx.y;      // one colour plane per workgroup
+    int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
+    btail_range(P.qw, t, nb, strip, a, b);
+    const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+    int16_t *cur = s_c, *prev = nullptr;       // cur: band l being written ((b-a) x qh), prev: band l+1
+    int prev_w = 0;
+    const int16_t *glf = gl + (size_t)f * gl_stride;
+    for (int l = nb; l >= t; --l) {
+        const int lw = b[l] - a[l], lh = P.qh[l];
+        if (l == nb) {
+            // coarsest band: C = trunc( sum_v trunc(G * w) / den ), per pixel (view rects need not be even-aligned here)
+            for (int i = tid; i < lw * lh; i += 256) {
+                const int y = i / lw, x = a[l] + (i - y * lw);
+                int16_t acc = 0;
+                for (int v = 0; v < P.n_views; ++v) {
+                    const LevelDesc &L = views[v].lv[l];
+                    const int lx = x - L.x_tl, ly = y - L.y_tl;
+                    if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
+                    const float w = L.wgt[(size_t)ly * L.wpitch + lx];
+                    acc = (int16_t)(acc + trunc_s16((float)(int)glf[L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx] * w));
+                }
+                const DivBy div(P.den[l][(size_t)y * P.dpitch[l] + x]);
+                cur[i] = trunc_s16(div((float)acc));
+            }
+        } else {
+            // band l < nb: Laplacian of every view formed on the fly, accumulate, normalise, add pyrUp of the collapsed band l+1 (in LDS); 2x2 quads
+            const int qwl = lw >> 1, qhl = lh >> 1;
+            for (int i = tid; i < qwl * qhl; i += 256) {
+                const int qy = i / qwl, qxl = i - qy * qwl;
+                const int x0 = a[l] + 2 * qxl, y0 = 2 * qy;
+                int16_t acc[4] = {0, 0, 0, 0};
+                for (int v = 0; v < P.n_views; ++v) {
+                    const LevelDesc &L = views[v].lv[l];
+                    const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
+                    if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;   // rects are even-aligned below level nb
+                    const LevelDesc &C = views[v].lv[l + 1];
+                    const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
+                    const float w[4] = {wp[0], wp[1], wp[L.wpitch], wp[L.wpitch + 1]};
+                    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;     // (short)(L * 0) == 0
+                    int up[4];
+                    up_quad(glf + C.off + (size_t)c * C.h * C.pitch, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up);
+                    const int16_t *p = glf + L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx;
+                    const int g[4] = {p[0], p[1], p[L.pitch], p[L.pitch + 1]};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int lap = sat_s16(g[k] - (int)sat_s16(up[k]));
+                        acc[k] = (int16_t)(acc[k] + trunc_s16((float)lap * w[k]));
+                    }
+                }
+                const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
+                const DivBy div[4] = {DivBy(dp[0]), DivBy(dp[1]), DivBy(dp[P.dpitch[l]]), DivBy(dp[P.dpitch[l] + 1])};
+                int up[4], res[4];
+                // prev holds columns [a[l+1], b[l+1]) of band l+1: index with the global column (clamped to the band by pu_idx) minus a[l+1]
+                up_quad(prev - a[l + 1], prev_w, P.qh[l + 1], P.qw[l + 1], qy, x0 >> 1, up);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) res[k] = sat_s16((int)sat_s16(up[k]) + (int)trunc_s16(div[k]((float)acc[k])));
+                if (l == t) {
+                    int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)c * P.qh[l] * P.qpitch[l] + (size_t)y0 * P.qpitch[l] + x0;
+                    d[0] = (int16_t)res[0]; d[1] = (int16_t)res[1]; d[P.qpitch[l]] = (int16_t)res[2]; d[P.qpitch[l] + 1] = (int16_t)res[3];
+                } else {
+                    int16_t *d = cur + (size_t)y0 * lw + 2 * qxl;
+                    d[0] = (int16_t)res[0]; d[1] = (int16_t)res[1]; d[lw] = (int16_t)res[2]; d[lw + 1] = (int16_t)res[3];
+                }
+            }
+        }
+        __syncthreads();
+        prev = cur; prev_w = lw;
+        cur = cur + (((size_t)lw * lh + 7) & ~(size_t)7);
+    }
+}
+
 // ---- vectorised band kernel: 2 rows x 8 columns per thread ------------------------------------------
 // Valid where every view rect and the pano level are 8-aligned in x and 2-aligned in y (levels l <= nb-3).
 // Same arithmetic as k_blend; views whose 16 weights are all zero are skipped (trunc(L*0) == 0 exactly),
@@ -1122,7 +1212,8 @@ struct ms_ctx {
     bool blend_vec[MAX_LEVELS] = {};   // band l may use the 2x8 kernel
     // work lists (tiles that are actually needed)
     bool warp_tiled = false;
-    int tail_l0 = -1, tail_lds = 0, tail_strips = 1;    // fused coarse-level reduce (k_down_tail): first level it reads, LDS bytes; -1 = off
+    int tail_l0 = -1, tail_lds = 0, tail_strips = 1;
+    int btail_t = -1, btail_lds = 0, btail_strips = 0;      // fused coarse band chain (k_blend_tail): finest band it produces, LDS bytes, strips    // fused coarse-level reduce (k_down_tail): first level it reads, LDS bytes; -1 = off
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0;
@@ -1826,6 +1917,31 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     MS_HIP(hipMemsetAsync(c->den.p, 0, den_total * sizeof(float), st));
     for (int l = 0; l <= nb; ++l) P.den[l] = (const float *)c->den.p + c->den_off[l];
     P.mask = (const uint8_t *)c->result_mask.p;
+    {   // fused coarse band chain: from the first band the vectorised kernel cannot take up to the coarsest one
+        int t = 0;
+        while (t < nb && c->blend_vec[t]) ++t;
+        c->btail_t = -1; c->btail_lds = 0; c->btail_strips = 0;
+        bool ok = t >= 1 && t < nb && c->cfg.reserved[0] == 0;
+        for (int l = t; ok && l < nb; ++l) {          // quads: even band sizes and even-aligned view rects below the coarsest band
+            ok = P.qw[l] % 2 == 0 && P.qh[l] % 2 == 0;
+            for (int v = 0; ok && v < N; ++v) {
+                const LevelDesc &L = c->h_views[v].lv[l];
+                ok = L.w % 2 == 0 && L.h % 2 == 0 && L.x_tl % 2 == 0 && L.y_tl % 2 == 0;
+            }
+        }
+        if (ok) {
+            const int strips = div_up(P.qw[t], BTAIL_W);
+            size_t need = 0;
+            for (int sidx = 0; sidx < strips; ++sidx) {
+                int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
+                btail_range(P.qw, t, nb, sidx, a, b);
+                size_t bytes = 0;
+                for (int l = t + 1; l <= nb; ++l) bytes += ((size_t)(b[l] - a[l]) * P.qh[l] + 7) / 8 * 8 * sizeof(int16_t);
+                need = std::max(need, bytes);
+            }
+            if (need <= 60 * 1024) { c->btail_t = t; c->btail_lds = (int)need + 64; c->btail_strips = strips; }
+        }
+    }
 
     // ---- init_gpu per view, in view order: weight = mask/255 -> constant border -> nb x pyrDown,
     //      and the weight sums (the `dst_w += w` of addSrcWeightKernel32F, blenders.cpp:729-746)
@@ -2212,10 +2328,18 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else if (S.mode == 1) K<L0, 1><<<G, B, 0, st>>>(__VA_ARGS__);   \
         else K<L0, 2><<<G, B, 0, st>>>(__VA_ARGS__);                    \
     } while (0)
-    MS_MODE_LAUNCH(k_blend_top, dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, S);
-    MS_LAUNCH_CHECK();
-    if (int e = mark(blend_names[nb])) return e;
-    for (int l = nb - 1; l >= 0; --l) {
+    int l_first = nb - 1;
+    if (S.mode == 0 && c->btail_t >= 0) {      // bands nb .. btail_t in one launch
+        k_blend_tail<<<dim3(c->btail_strips, 3, F), blk, c->btail_lds, st>>>(vt, P, c->btail_t, gl, c->gl_stride, cl, c->cl_stride);
+        MS_LAUNCH_CHECK();
+        if (int e = mark("k_blend_tail")) return e;
+        l_first = c->btail_t - 1;
+    } else {
+        MS_MODE_LAUNCH(k_blend_top, dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, S);
+        MS_LAUNCH_CHECK();
+        if (int e = mark(blend_names[nb])) return e;
+    }
+    for (int l = l_first; l >= 0; --l) {
         if (c->blend_vec[l] && c->cfg.reserved[0] == 0) {
             const dim3 g(c->n_blend_tiles[l], 1, F), b(32, 8);
             if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
