@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
 // call these launches are a third of the frame time.  Each band is computed from its views exactly as k_blend_top / k_blend do; the
 // collapsed bands above t stay in LDS (three int16 planes of the strip plus the columns pyrUp needs), only band t is stored -- it is all
 // the next (vectorised) band kernel reads.  Column ranges of a strip: band t owns [a_t, b_t); band l+1 needs [a_l/2 - 1, (b_l-1)/2 + 1].
-constexpr int BTAIL_W = 32;             // columns of band t per strip
+constexpr int BTAIL_W = 16;             // columns of band t per strip
 __host__ __device__ inline void btail_range(const int *qw, int t, int nb, int strip, int *a, int *b)
 {
     a[t] = strip * BTAIL_W; b[t] = min(a[t] + BTAIL_W, qw[t]);
