@@ -314,6 +314,34 @@ def test_feather_needs_single_band_context(ms, cuda):
     comp.close()
 
 
+def test_concurrent_contexts_on_separate_streams(ms, cuda):
+    """bench.py's default: several contexts, each on its own HIP stream, in flight at once.  Three contexts x 4 frames issued back to back
+    on three streams for several rounds must give exactly what one context gives frame by frame."""
+    comps = [make_rig(ms, "mini6", max_frames=4)[0] for _ in range(3)]
+    cfg = synth.CONFIGS["mini6"]
+    pg = comps[0].pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(12)]
+    want = []
+    for t in range(12):
+        o = torch.zeros(shape, dtype=torch.int16, device=cuda)
+        comps[0].stitch([frames[t]], out16s=[o])
+        want.append(o)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=cuda) for _ in range(3)]
+    for rnd in range(5):
+        got = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(12)]
+        torch.cuda.synchronize()
+        for k in range(3):
+            with torch.cuda.stream(streams[k]):
+                comps[k].stitch(frames[4 * k:4 * k + 4], out16s=got[4 * k:4 * k + 4])
+        torch.cuda.synchronize()
+        for t in range(12):
+            assert torch.equal(got[t], want[t]), (rnd, t)
+    for c in comps:
+        c.close()
+
+
 def test_feed_then_blend_equals_stitch(ms, cuda):
     """The reference's call shape -- stitch_online per view, then blend (timed.cpp:127-137) -- gives the ms_stitch frame; blend without all
     views fed is a state error."""
