@@ -1213,6 +1213,9 @@ struct ms_ctx {
     // work lists (tiles that are actually needed)
     bool warp_tiled = false;
     int tail_l0 = -1, tail_lds = 0, tail_strips = 1;
+    // the fused band kernel started one band finer: used for batches of 1-2 frames (live mode), where a launch costs more than the
+    // vectorised kernel saves
+    int btail2_t = -1, btail2_lds = 0, btail2_strips = 0;
     int btail_t = -1, btail_lds = 0, btail_strips = 0;      // fused coarse band chain (k_blend_tail): finest band it produces, LDS bytes, strips    // fused coarse-level reduce (k_down_tail): first level it reads, LDS bytes; -1 = off
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
@@ -1841,23 +1844,25 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     {   // coarse levels that the tile kernel cannot take (width not a multiple of 8) go to one fused launch if a plane chain fits in LDS
         int t0 = 0;
         while (t0 < nb && c->down_vec[t0]) ++t0;
-        c->tail_l0 = -1; c->tail_lds = 0;
-        if (t0 >= 1 && t0 < nb) {          // level t0 is int16 (t0 >= 1); the u8 level 0 never starts a tail
+        auto plan_tail = [&](int l0, int *out_l0, int *out_lds, int *out_strips) {
+            *out_l0 = -1; *out_lds = 0; *out_strips = 1;
+            if (l0 < 1 || l0 >= nb) return;          // level l0 is int16 (l0 >= 1); the u8 level 0 never starts a tail
             int need = 0, strips = 1;
             for (int v = 0; v < N; ++v) {
                 int w[MAX_LEVELS + 1], a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
-                for (int l = t0; l <= nb; ++l) w[l] = c->h_views[v].lv[l].w;
+                for (int l = l0; l <= nb; ++l) w[l] = c->h_views[v].lv[l].w;
                 const int ns = div_up(w[nb], TAIL_STRIP);
                 strips = std::max(strips, ns);
                 for (int sidx = 0; sidx < ns; ++sidx) {
-                    tail_range(w, t0, nb, sidx, a, b);
+                    tail_range(w, l0, nb, sidx, a, b);
                     int bytes = 0;
-                    for (int l = t0; l <= nb; ++l) bytes += ((b[l] - a[l]) * c->h_views[v].lv[l].h + 15) & ~15;
+                    for (int l = l0; l <= nb; ++l) bytes += ((b[l] - a[l]) * c->h_views[v].lv[l].h + 15) & ~15;
                     need = std::max(need, bytes);
                 }
             }
-            if (need <= 64 * 1024) { c->tail_l0 = t0; c->tail_lds = need; c->tail_strips = strips; }
-        }
+            if (need <= 64 * 1024) { *out_l0 = l0; *out_lds = need; *out_strips = strips; }
+        };
+        plan_tail(t0, &c->tail_l0, &c->tail_lds, &c->tail_strips);
     }
     for (int l = 0; l < nb; ++l) {
         int qw = c->bg.dst_roi.width >> l, qh = c->bg.dst_roi.height >> l;
@@ -1920,27 +1925,30 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     {   // fused coarse band chain: from the first band the vectorised kernel cannot take up to the coarsest one
         int t = 0;
         while (t < nb && c->blend_vec[t]) ++t;
-        c->btail_t = -1; c->btail_lds = 0; c->btail_strips = 0;
-        bool ok = t >= 1 && t < nb && c->cfg.reserved[0] == 0;
-        for (int l = t; ok && l < nb; ++l) {          // quads: even band sizes and even-aligned view rects below the coarsest band
-            ok = P.qw[l] % 2 == 0 && P.qh[l] % 2 == 0;
-            for (int v = 0; ok && v < N; ++v) {
-                const LevelDesc &L = c->h_views[v].lv[l];
-                ok = L.w % 2 == 0 && L.h % 2 == 0 && L.x_tl % 2 == 0 && L.y_tl % 2 == 0;
+        auto plan_btail = [&](int tt, int *out_t, int *out_lds, int *out_strips) {
+            *out_t = -1; *out_lds = 0; *out_strips = 0;
+            bool ok = tt >= 1 && tt < nb && c->cfg.reserved[0] == 0;
+            for (int l = tt; ok && l < nb; ++l) {          // quads: even band sizes and even-aligned view rects below the coarsest band
+                ok = P.qw[l] % 2 == 0 && P.qh[l] % 2 == 0;
+                for (int v = 0; ok && v < N; ++v) {
+                    const LevelDesc &L = c->h_views[v].lv[l];
+                    ok = L.w % 2 == 0 && L.h % 2 == 0 && L.x_tl % 2 == 0 && L.y_tl % 2 == 0;
+                }
             }
-        }
-        if (ok) {
-            const int strips = div_up(P.qw[t], BTAIL_W);
+            if (!ok) return;
+            const int strips = div_up(P.qw[tt], BTAIL_W);
             size_t need = 0;
             for (int sidx = 0; sidx < strips; ++sidx) {
                 int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
-                btail_range(P.qw, t, nb, sidx, a, b);
+                btail_range(P.qw, tt, nb, sidx, a, b);
                 size_t bytes = 0;
-                for (int l = t + 1; l <= nb; ++l) bytes += ((size_t)(b[l] - a[l]) * P.qh[l] + 7) / 8 * 8 * sizeof(int16_t);
+                for (int l = tt + 1; l <= nb; ++l) bytes += ((size_t)(b[l] - a[l]) * P.qh[l] + 7) / 8 * 8 * sizeof(int16_t);
                 need = std::max(need, bytes);
             }
-            if (need <= 60 * 1024) { c->btail_t = t; c->btail_lds = (int)need + 64; c->btail_strips = strips; }
-        }
+            if (need <= 60 * 1024) { *out_t = tt; *out_lds = (int)need + 64; *out_strips = strips; }
+        };
+        plan_btail(t, &c->btail_t, &c->btail_lds, &c->btail_strips);
+        plan_btail(t - 1, &c->btail2_t, &c->btail2_lds, &c->btail2_strips);
     }
 
     // ---- init_gpu per view, in view order: weight = mask/255 -> constant border -> nb x pyrDown,
@@ -2289,9 +2297,10 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     MS_LAUNCH_CHECK();
     if (int e = mark("k_warp")) return e;
 
+    const int dt_l0 = c->tail_l0, dt_lds = c->tail_lds, dt_strips = c->tail_strips;     // (starting the reduce tail a level finer was measured slower even for one frame)
     for (int l = 0; l < nb; ++l) {
-        if (l == c->tail_l0 && c->cfg.reserved[0] == 0) {
-            k_down_tail<<<dim3(F * N * 3 * c->tail_strips), blk, c->tail_lds, st>>>(vt, N, l, nb, c->tail_strips, gl, c->gl_stride, c->own_mask);
+        if (l == dt_l0 && c->cfg.reserved[0] == 0) {
+            k_down_tail<<<dim3(F * N * 3 * dt_strips), blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask);
             MS_LAUNCH_CHECK();
             if (int e = mark("k_down_tail")) return e;
             break;
@@ -2329,11 +2338,13 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else K<L0, 2><<<G, B, 0, st>>>(__VA_ARGS__);                    \
     } while (0)
     int l_first = nb - 1;
-    if (S.mode == 0 && c->btail_t >= 0) {      // bands nb .. btail_t in one launch
-        k_blend_tail<<<dim3(c->btail_strips, 3, F), blk, c->btail_lds, st>>>(vt, P, c->btail_t, gl, c->gl_stride, cl, c->cl_stride);
+    const bool bt2 = F <= 2 && c->btail2_t >= 0;      // live mode (1-2 frames per call): launches dominate, the band tail starts one band finer
+    const int bt_t = bt2 ? c->btail2_t : c->btail_t, bt_lds = bt2 ? c->btail2_lds : c->btail_lds, bt_strips = bt2 ? c->btail2_strips : c->btail_strips;
+    if (S.mode == 0 && bt_t >= 0) {      // bands nb .. bt_t in one launch
+        k_blend_tail<<<dim3(bt_strips, 3, F), blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_blend_tail")) return e;
-        l_first = c->btail_t - 1;
+        l_first = bt_t - 1;
     } else {
         MS_MODE_LAUNCH(k_blend_top, dim3(div_up(P.qw[nb], 64), div_up(P.qh[nb], 4), F), blk, vt, P, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, S);
         MS_LAUNCH_CHECK();
