@@ -89,3 +89,32 @@ def test_random_feather_rig_batches_and_canvas(ms, cuda, oracle, n, w, h, spread
         assert np.array_equal(host(out16[t]), ref16) and np.array_equal(host(comp.result_mask()), refmask)
         assert np.array_equal(host(out8[t]), canvas_from(ref16, pg, out[0], out[1]))
     comp.close()
+
+
+@settings(max_examples=int(os.environ.get("MS_TEST_EXAMPLES", 12)), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(n=st.integers(2, 3), w=st.integers(64, 160), h=st.integers(48, 120), step=st.floats(8.0, 24.0), hfov=st.floats(45.0, 75.0),
+       scale=st.floats(60.0, 220.0), bands=st.integers(1, 4), seams=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_random_plane_rig_matches_oracle(ms, cuda, oracle, n, w, h, step, hfov, scale, bands, seams, seed):
+    """PlaneWarperGpu rigs: 2-3 views fanned out by 8-24 degrees (a plane cannot hold a wide panorama), random scale; no equirect canvas."""
+    import math
+    comp = ms.Compositor(n, (w, h), ms.PROJ_PLANE, float(np.float32(scale)), num_bands=bands, out_size=(0, 0))
+    rng = np.random.default_rng(seed)
+    gains = [float(g) for g in rng.uniform(0.9, 1.1, n)]
+    for i in range(n):
+        comp.set_camera(i, *synth.camera(1, w, h, hfov, 0, yaw=math.radians((i - (n - 1) / 2.0) * step))); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1 if seams else 0); comp.init_blender()
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    rois = [comp.view_geom(i).roi.tuple() for i in range(n)]
+    b = oracle.Blender([r[:2] for r in rois], [r[2:] for r in rois], bands)
+    for i in range(n):
+        b.init_view(i, host(comp.mask(i)))
+    for i in range(n):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames[i], xm, ym, gains[i])
+    ref, refmask = b.blend()
+    assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    b.close(); comp.close()
