@@ -234,6 +234,12 @@ MS_API int ms_set_mesh_interp(ms_ctx *ctx, int view, const float *start_x, const
 /* Largest |x_mesh - x| / |y_mesh - y| (pixels) of the active CPW mesh of `view`, measured on the device by ms_set_mesh / ms_set_mesh_maps.
  * While it stays <= 32 the first CPW remap (timed.cpp:90-94) skips the tiles the mesh remap cannot reach; larger meshes warp whole views. */
 MS_API int ms_get_mesh_displacement(ms_ctx *ctx, int view, float *out_px);
+/* MultiBandBlender::update_mask (blenders.cpp:297-315; its call is commented out in the reference's main loop, timed.cpp:598-605):
+ * the mask init_gpu received for `view`, remapped through the view's active CPW mesh (INTER_LINEAR, BORDER_CONSTANT 0), replaces the view's
+ * blend-weight pyramid.  Needs enable_cpw, ms_init_blender and a mesh for the view.  The reference re-accumulates the weight sums each frame;
+ * here they are frame-invariant tables, so the call rebuilds them (and the work lists) as ms_init_blender does, keeping meshes and gains.
+ * ms_get_mask keeps returning the original mask; ms_set_mask / ms_build_masks / ms_calibrate_seam drop the re-warped one. */
+MS_API int ms_update_mask(ms_ctx *ctx, int view, ms_stream stream);
 
 /* MeshWarper::convertMeshesToMap for one view (APP/meshwarper.cpp:823-886): N x M vertex mesh (HOST fp32,
  * forward positions in view-ROI pixels) -> dense backward maps x_mesh/y_mesh, double-buffered; takes

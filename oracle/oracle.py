@@ -394,7 +394,15 @@ class Blender:
     def init_view(self, v, mask):
         mask = np.ascontiguousarray(mask, np.uint8)
         assert mask.shape == (self.sizes[v][1], self.sizes[v][0])
+        self.__dict__.setdefault("_masks", {})[v] = mask
         lib().orc_blender_init_view(self._h, v, _p(mask), _st(mask))
+
+    def update_mask(self, v, xmesh, ymesh):
+        """MultiBandBlender::update_mask (blenders.cpp:297-315): remap(gpu_masks_[v], x_mesh, y_mesh, INTER_LINEAR, BORDER_CONSTANT 0)
+        -> convertTo 32F /255 -> copyMakeBorder -> pyrDown chain, i.e. init_gpu's weight steps on the re-warped mask."""
+        warped = remap_linear_8uc1(self._masks[v], xmesh, ymesh)
+        lib().orc_blender_init_view(self._h, v, _p(warped), _st(warped))
+        return warped
 
     def view_geom(self, v):
         vg = ViewGeom()

@@ -75,6 +75,50 @@ def test_stitch_cpw_matches_oracle(ms, cuda, oracle):
     comp.close()
 
 
+def test_update_mask_matches_oracle(ms, cuda, oracle):
+    """MultiBandBlender::update_mask (blenders.cpp:297-315): masks re-warped through the CPW meshes replace the blend weights."""
+    comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
+    frames_np = [synth.frame(cfg["w"], cfg["h"], i, 5) for i in range(cfg["n"])]
+    frames = [[to_dev(f) for f in frames_np]]
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    meshes = []
+    for i in range(cfg["n"]):
+        r = comp.view_geom(i).roi
+        mx, my = synth.mesh(r.width, r.height, 9, 11, phase=0.4 * i, amp=6.0)
+        comp.set_mesh(i, mx, my)
+        dmx, dmy = comp.mesh_maps(i)
+        meshes.append((host(dmx), host(dmy)))
+    comp.stitch(frames, out16s=[out16]); torch.cuda.synchronize()
+    before = host(out16).copy()
+    updated = (0, 2, 3)
+    for i in updated:
+        comp.update_mask(i)
+    comp.stitch(frames, out16s=[out16]); torch.cuda.synchronize()
+
+    b, _ = oracle_blender_from(oracle, comp, cfg)       # comp.mask(i) stays the mask init_gpu received
+    changed = 0
+    for i in updated:
+        warped = b.update_mask(i, *meshes[i])
+        changed += int((warped != host(comp.mask(i))).sum())
+    assert changed > 0, "the meshes must actually move the masks"
+    for i in range(cfg["n"]):
+        xm, ym = [host(t) for t in comp.maps(i)]
+        b.stitch_online(i, frames_np[i], xm, ym, gains[i], *meshes[i])
+    ref16, refmask = b.blend()
+    b.close()
+    assert np.array_equal(host(comp.result_mask()), refmask)
+    assert np.array_equal(host(out16), ref16)
+    assert not np.array_equal(before, ref16)
+    # fresh masks drop the re-warped ones: back to the first result
+    for i in range(cfg["n"]):
+        comp.set_mask(i, host(comp.mask(i)))
+    comp.init_blender()
+    comp.stitch(frames, out16s=[out16]); torch.cuda.synchronize()
+    assert np.array_equal(host(out16), before)
+    comp.close()
+
+
 def test_batched_frames_equal_single_frames(ms, cuda):
     comp, cfg, gains = make_rig(ms, "mini6", max_frames=3)
     pg = comp.pano_geom()

@@ -1222,6 +1222,8 @@ struct ms_ctx {
     int n_stage1_tiles = 0;
     ms_image fed[MAX_VIEWS] = {};      // ms_feed: the views of the frame being assembled (borrowed until ms_blend)
     unsigned fed_mask = 0;
+    DevBuf masks_eff;                  // ms_update_mask: masks re-warped through the CPW mesh (same layout as `masks`)
+    bool use_eff[MAX_VIEWS] = {};
     DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
@@ -1650,6 +1652,7 @@ static int alloc_masks(ms_ctx *c)
 {
     size_t total = 0;
     for (int i = 0; i < c->N; ++i) { c->mask_off[i] = total; total += (size_t)c->roi[i].width * c->roi[i].height; }
+    for (int i = 0; i < MAX_VIEWS; ++i) c->use_eff[i] = false;     // fresh masks supersede any ms_update_mask result
     return c->masks.bytes >= total && c->masks.p ? MS_OK : c->masks.alloc(total);
 }
 
@@ -1782,11 +1785,18 @@ int ms_set_mask(ms_ctx *c, int view, const uint8_t *mask_host, size_t step)
     if (!c->maps_built) return fail(MS_ERR_STATE, "ms_set_mask: call ms_build_maps first");
     MS_CHECK(mask_host && step >= (size_t)c->roi[view].width, "ms_set_mask: bad mask/step");
     if (int e = alloc_masks(c)) return e;
+    c->use_eff[view] = false;
     MS_HIP(hipMemcpy2D((uint8_t *)c->masks.p + c->mask_off[view], c->roi[view].width, mask_host, step,
                        c->roi[view].width, c->roi[view].height, hipMemcpyHostToDevice));
     c->masks_built = true;   // caller is responsible for setting every view
     c->blender_ready = false;
     return MS_OK;
+}
+
+// the mask init_gpu sees for a view: the caller's / seam finder's, or its re-warp through the CPW mesh (update_mask)
+static const uint8_t *blend_mask_ptr(const ms_ctx *c, int v)
+{
+    return (c->use_eff[v] ? (const uint8_t *)c->masks_eff.p : (const uint8_t *)c->masks.p) + c->mask_off[v];
 }
 
 int ms_init_blender(ms_ctx *c, ms_stream stream)
@@ -1889,7 +1899,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             ViewDesc &V = c->h_views[v];
             V.wm0 = (const uint8_t *)c->wm0.p + c->wm0_off[v];
             MS_HIP(hipMemcpy2DAsync((uint8_t *)c->wm0.p + c->wm0_off[v] + (size_t)V.top * V.wm0_pitch + V.left, V.wm0_pitch,
-                                    (const uint8_t *)c->masks.p + c->mask_off[v], V.aw, V.aw, V.ah, hipMemcpyDeviceToDevice, st));
+                                    blend_mask_ptr(c, v), V.aw, V.aw, V.ah, hipMemcpyDeviceToDevice, st));
         }
     }
     for (int v = 0; v < N; ++v)
@@ -1957,7 +1967,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     if (int e = wm.alloc((size_t)c->max_aw * c->max_ah * sizeof(float))) return e;
     for (int v = 0; v < N; ++v) {
         ViewDesc &V = c->h_views[v];
-        ms_image mask{(uint8_t *)c->masks.p + c->mask_off[v], (size_t)V.aw, V.ah, V.aw, MS_8UC1};
+        ms_image mask{(void *)blend_mask_ptr(c, v), (size_t)V.aw, V.ah, V.aw, MS_8UC1};
         ms_image wmap{wm.p, (size_t)V.aw * sizeof(float), V.ah, V.aw, MS_32FC1};
         if (c->feather_sharpness >= 0.f) {            // FeatherBlender::feed -> createWeightMap (blenders.cpp:156, 944-951), host side like the reference
             std::vector<uint8_t> hm((size_t)V.aw * V.ah);
@@ -2011,8 +2021,10 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         if (int e = c->stage.alloc((size_t)c->stage_stride * F)) return e;
         size_t mtotal = 0;
         for (int v = 0; v < N; ++v) { c->mesh_off[v] = mtotal; mtotal += (size_t)2 * c->h_views[v].ah * c->map_pitch[v]; }
-        for (int b = 0; b < 2; ++b) if (int e = c->mesh[b].alloc(mtotal * sizeof(float))) return e;
-        for (int v = 0; v < N; ++v) { c->mesh_active[v] = 0; c->mesh_set[v] = false; }
+        if (c->mesh[0].bytes != mtotal * sizeof(float) || !c->mesh[0].p) {      // (a re-initialisation with the same geometry -- ms_update_mask -- keeps the meshes)
+            for (int b = 0; b < 2; ++b) if (int e = c->mesh[b].alloc(mtotal * sizeof(float))) return e;
+            for (int v = 0; v < N; ++v) { c->mesh_active[v] = 0; c->mesh_set[v] = false; }
+        }
     }
     if (int e = c->view_tab.alloc(sizeof(ViewDesc) * N)) return e;
     MS_HIP(hipMemcpy(c->view_tab.p, c->h_views.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice));
@@ -2168,6 +2180,31 @@ int ms_set_mesh_interp(ms_ctx *c, int view, const float *x0, const float *y0, co
         my[i] = y0[i] + (y1[i] - y0[i]) * progress;
     }
     return ms_set_mesh(c, view, mx.data(), my.data(), N, M, stream);
+}
+
+// MultiBandBlender::update_mask (blenders.cpp:297-315): the view's mask re-warped through its CPW mesh (remap LINEAR, BORDER_CONSTANT 0),
+// then weight map, border, pyrDown chain as in init_gpu.  The reference re-accumulates the weight sums every frame, here they are static
+// tables: the sums, the result mask and the work lists are rebuilt too (calibration-time cost; synchronises).  Disabled in the reference's
+// main loop ("causes black seams", timed.cpp:598-605) but part of the blender's interface.
+int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
+{
+    if (int e = ctx_check_view(c, view)) return e;
+    if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view]) return fail(MS_ERR_STATE, "ms_update_mask: needs enable_cpw, ms_init_blender and a mesh for view %d", view);
+    hipStream_t st = as_stream(stream);
+    if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
+    if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
+        if (int e = c->masks_eff.alloc(c->masks.bytes)) return e;
+        MS_HIP(hipMemcpy(c->masks_eff.p, c->masks.p, c->masks.bytes, hipMemcpyDeviceToDevice));
+    }
+    const int aw = c->roi[view].width, ah = c->roi[view].height;
+    ms_image src{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)aw, ah, aw, MS_8UC1};
+    ms_image dst{(uint8_t *)c->masks_eff.p + c->mask_off[view], (size_t)aw, ah, aw, MS_8UC1};
+    ms_image mx = mesh_image(c, c->mesh_active[view], view, 0), my = mesh_image(c, c->mesh_active[view], view, 1);
+    if (int e = launch_remap(src, mx, my, dst, MS_INTER_LINEAR, MS_BORDER_CONSTANT, st)) return e;
+    MS_HIP(hipStreamSynchronize(st));
+    c->use_eff[view] = true;
+    return ms_init_blender(c, stream);
 }
 
 int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)

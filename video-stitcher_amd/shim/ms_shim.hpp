@@ -77,6 +77,7 @@ public:
     void buildMasks(bool voronoi_seams = true, ms_stream s = nullptr) { check(ms_build_masks(ctx_, voronoi_seams ? 1 : 0, s)); }
     void setMask(int i, const uint8_t *host_mask, size_t step) { check(ms_set_mask(ctx_, i, host_mask, step)); }
     void init_gpu(ms_stream s = nullptr) { check(ms_init_blender(ctx_, s)); }         // mb->init_gpu for every view
+    void update_mask(int img_num, ms_stream s = nullptr) { check(ms_update_mask(ctx_, img_num, s)); }   // mb->update_mask(idx, x_mesh, y_mesh): uses the view's active mesh
     // MeshWarper::convertMeshesToMap (meshwarper.cpp:823): callable from the recalibration thread
     void convertMeshToMap(int i, const float *mesh_x, const float *mesh_y, int N, int M, ms_stream s = nullptr)
     { check(ms_set_mesh(ctx_, i, mesh_x, mesh_y, N, M, s)); }
