@@ -292,6 +292,48 @@ typedef struct ms_pano_geom {
 } ms_pano_geom;
 MS_API int ms_get_view_geom(const ms_ctx *ctx, int view, ms_view_geom *g);
 MS_API int ms_get_pano_geom(const ms_ctx *ctx, ms_pano_geom *g);
+/* ---- CPW mesh optimiser: MeshWarper::createMesh after feature matching (360_stitcher/meshwarper.cpp:279-301) ------------------------
+ * The feature front-end (ORB, matching, RANSAC: featurefinder.cpp) stays with the caller; what crosses the boundary is what
+ * createMesh hands to calcLocalTerm / calcGlobalTerm: per view, the selected matches (filterMatches, meshwarper.cpp:888-946, capped at
+ * MAX_FEATURES_PER_IMAGE) as keypoint positions in WARPED-VIEW pixels. */
+typedef struct ms_mesh_match {
+    float x1, y1;       /* features[src].keypoints[queryIdx].pt, src = the view the list belongs to */
+    float x2, y2;       /* features[dst].keypoints[trainIdx].pt (temporal lists: the same view in the previous calibration) */
+    int dst;            /* matchWithDst_t::dst (ignored in temporal lists) */
+} ms_mesh_match;
+
+typedef struct ms_mesh_params {
+    int mesh_cols, mesh_rows;       /* M, N: MESH_WIDTH, MESH_HEIGHT (defs.h:65-66) */
+    float alphas[4];                /* ALPHAS (defs.h:69): local, global, smoothness, temporal term weights; temporal is used iff != 0 (defs.h:70) */
+    int global_dist;                /* GLOBAL_DIST (defs.h:71) */
+    float focal_length;             /* MeshWarper::focal_length */
+    double compose_scale, work_scale;
+    int wrap_around;                /* wrapAround (defs.h:25) */
+    int theta_rule;                 /* 0: the reference's hard-coded 6-camera angles (meshwarper.cpp:617-629); 1: (dst - src) * 2 pi / n_views, wrapped */
+    int max_iterations;             /* 0 = Eigen's default, 2 * columns */
+    double tolerance;               /* 0 = Eigen's default, DBL_EPSILON */
+} ms_mesh_params;
+
+typedef struct ms_mesh_info {
+    int rows, cols, nnz;            /* the system actually assembled (the reference allocates more, all-zero, rows) */
+    int iterations;                 /* solver.iterations() */
+    double error;                   /* solver.error() = ||A^T r|| / ||A^T b|| */
+} ms_mesh_info;
+
+MS_API int ms_mesh_default_params(ms_mesh_params *prm);      /* defs.h values, 10 x 10 mesh */
+/* calcSmoothnessTerm's salience (meshwarper.cpp:497-563) of every (vertex, triangle) of one warped view (device 8UC3):
+ * sal_host[(i * mesh_cols + j) * 8 + t], NaN where triangle t of vertex (j, i) leaves the mesh.  The pixel pass (masked sum / sum of squares
+ * per cell crop, cv::meanStdDev under a cv::fillConvexPoly mask) runs on the device. */
+MS_API int ms_mesh_saliency(const ms_image *warped_view, int mesh_cols, int mesh_rows, float *sal_host, ms_stream stream);
+/* createMesh's loop + solve (meshwarper.cpp:279-301): for every view calcLocalTerm, calcGlobalTerm, calcSmoothnessTerm[, calcTemporalLocalTerm],
+ * then x = LeastSquaresConjugateGradient(A).solve(b) in fp64 on the device and convertVectorToMesh.
+ * warped_views[n_views]: the remapped frames `images[idx]` (device 8UC3; mesh_size = their sizes).  matches: the per-view lists back to back,
+ * match_count[v] entries each (host); temporal / temporal_count likewise or NULL.  mesh_x / mesh_y: host, n_views * mesh_rows * mesh_cols
+ * vertex positions in view pixels, ready for ms_set_mesh / ms_set_mesh_interp.  Synchronises `stream`. */
+MS_API int ms_create_mesh(int n_views, const ms_image *warped_views, const ms_mesh_match *matches, const int *match_count,
+                          const ms_mesh_match *temporal, const int *temporal_count, const ms_mesh_params *prm,
+                          float *mesh_x, float *mesh_y, ms_mesh_info *info, ms_stream stream);
+
 /* device-resident static tables, for parity tests: x_maps[i]/y_maps[i] (32FC1), masks (8UC1),
  * weight pyramid level (32FC1). Borrowed pointers owned by ctx. */
 MS_API int ms_get_maps(const ms_ctx *ctx, int view, ms_image *xmap, ms_image *ymap);

@@ -1,0 +1,685 @@
+// mesh_solver.hip -- the CPW mesh optimiser on the device (gfx950): MeshWarper::createMesh after feature matching
+// (360_stitcher/meshwarper.cpp:279-301): local / global / smoothness / temporal terms of |A x - b|^2, then the solve the reference hands
+// to Eigen::LeastSquaresConjugateGradient<SparseMatrix<double>> (third party; algorithm of Eigen 3.3 LeastSquareConjugateGradient.h:
+// CG on the normal equations, Jacobi preconditioner, x0 = 0, tolerance DBL_EPSILON, at most 2*cols iterations).
+//
+// Split of the work:
+//   device  k_tri_stats     masked sum / sum of squares of every (vertex, triangle) cell crop -- the only pass over pixels
+//           k_lscg_rows     tmp = A p           (ELL, one thread per row; deferred residual update folded in)
+//           k_lscg_cols     A^T residual, z     (CSC, 16 lanes per column)
+//           k_lscg_update   x += alpha p ; p = z + beta p
+//           all fp64; every reduction is a fixed-order tree over per-block partials (<= LSCG_PARTS blocks), re-summed by each consumer
+//           block, so the solve is run-to-run reproducible and needs no in-launch hand-off between workgroups.
+//   host    triangle masks (cv::fillConvexPoly restated), coefficient arithmetic in the reference's float expressions, CSR/CSC layout.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <vector>
+#include "common.hpp"
+
+namespace ms {
+namespace {
+
+struct Buf {                                    // device buffer, freed on scope exit
+    void *p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { if (p) (void)hipFree(p); p = nullptr; MS_HIP(hipMalloc(&p, n ? n : 16)); return MS_OK; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// ------------------------------------------------------------------------------------------------ cv::fillConvexPoly, 3 points
+// drawing.cpp:1109-1271 (line_type 8, shift 0): the polygon outline with Line() (8-connected Bresenham of LineIterator :165-252 with
+// left_to_right, clipped by clipLine :97-148), then the scan conversion with 16.16 fixed-point edges.
+struct Pt { long long x, y; };
+constexpr int XY_SHIFT = 16;
+constexpr long long XY_ONE = 1ll << XY_SHIFT;
+
+bool clip_line(long long w, long long h, Pt &a, Pt &b)
+{
+    const long long right = w - 1, bottom = h - 1;
+    if (w <= 0 || h <= 0) return false;
+    long long &x1 = a.x, &y1 = a.y, &x2 = b.x, &y2 = b.y;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long e;
+        if (c1 & 12) { e = c1 < 8 ? 0 : bottom; x1 += (long long)((double)(e - y1) * (x2 - x1) / (y2 - y1)); y1 = e; c1 = (x1 < 0) + (x1 > right) * 2; }
+        if (c2 & 12) { e = c2 < 8 ? 0 : bottom; x2 += (long long)((double)(e - y2) * (x2 - x1) / (y2 - y1)); y2 = e; c2 = (x2 < 0) + (x2 > right) * 2; }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) { e = c1 == 1 ? 0 : right; y1 += (long long)((double)(e - x1) * (y2 - y1) / (x2 - x1)); x1 = e; c1 = 0; }
+            if (c2) { e = c2 == 1 ? 0 : right; y2 += (long long)((double)(e - x2) * (y2 - y1) / (x2 - x1)); x2 = e; c2 = 0; }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+void draw_line8(std::vector<uint8_t> &img, int w, int h, Pt a, Pt b)
+{
+    if (a.x < 0 || a.x >= w || b.x < 0 || b.x >= w || a.y < 0 || a.y >= h || b.y < 0 || b.y >= h)
+        if (!clip_line(w, h, a, b)) return;
+    long long dx = b.x - a.x, dy = b.y - a.y;
+    if (dx < 0) { dx = -dx; dy = -dy; a = b; }                  // walk from the left end point
+    const int ystep = dy < 0 ? -1 : 1;
+    if (dy < 0) dy = -dy;
+    int mx = 1, my = 0, px = 0, py = ystep;                     // "minus" step (every pixel), "plus" step (when err < 0)
+    if (dy > dx) { std::swap(dx, dy); std::swap(mx, px); std::swap(my, py); }
+    long long err = dx - 2 * dy;
+    long long x = a.x, y = a.y;
+    for (long long i = 0; i <= dx; ++i) {
+        img[(size_t)y * w + x] = 255;
+        const bool neg = err < 0;
+        err += -2 * dy + (neg ? 2 * dx : 0);
+        x += mx + (neg ? px : 0);
+        y += my + (neg ? py : 0);
+    }
+}
+
+void fill_convex3(std::vector<uint8_t> &img, int w, int h, const Pt v[3])
+{
+    const int n = 3;
+    long long xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y;
+    int imin = 0;
+    Pt p0 = v[n - 1];
+    for (int i = 0; i < n; ++i) {
+        if (v[i].y < ymin) { ymin = v[i].y; imin = i; }
+        ymax = std::max(ymax, v[i].y); xmax = std::max(xmax, v[i].x); xmin = std::min(xmin, v[i].x);
+        draw_line8(img, w, h, p0, v[i]);
+        p0 = v[i];
+    }
+    if (xmax < 0 || ymax < 0 || xmin >= w || ymin >= h) return;
+    ymax = std::min<long long>(ymax, h - 1);
+    struct { int idx, di; long long x, dx; long long ye; } e[2] = {{imin, 1, -XY_ONE, 0, ymin}, {imin, n - 1, -XY_ONE, 0, ymin}};
+    int edges = n;
+    long long y = ymin;
+    do {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= e[i].ye) {
+                int idx0 = e[i].idx, idx = idx0 + e[i].di;
+                if (idx >= n) idx -= n;
+                for (; edges-- > 0;) {
+                    const long long ty = v[idx].y;
+                    if (ty > y) {
+                        const long long xs = v[idx0].x << XY_SHIFT, xe = v[idx].x << XY_SHIFT;
+                        e[i].ye = ty;
+                        e[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        e[i].x = xs;
+                        e[i].idx = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += e[i].di;
+                    if (idx >= n) idx -= n;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            const int l = e[0].x > e[1].x ? 1 : 0, r = 1 - l;
+            long long xx1 = (e[l].x + (XY_ONE >> 1)) >> XY_SHIFT, xx2 = (e[r].x + (XY_ONE >> 1)) >> XY_SHIFT;
+            if (xx2 >= 0 && xx1 < w) {
+                xx1 = std::max<long long>(xx1, 0);
+                xx2 = std::min<long long>(xx2, w - 1);
+                for (long long x = xx1; x <= xx2; ++x) img[(size_t)y * w + x] = 255;
+            }
+        }
+        e[0].x += e[0].dx;
+        e[1].x += e[1].dx;
+    } while (++y <= ymax);
+}
+
+// meshwarper.cpp:441-486: offsets (x, y) of V1, V2 (the vertex itself), V3 of the 8 triangles around a vertex
+const int TRI[8][3][2] = {
+    {{-1, 0}, {0, 0}, {-1, -1}}, {{0, -1}, {0, 0}, {-1, -1}}, {{0, -1}, {0, 0}, {1, -1}}, {{1, 0}, {0, 0}, {1, -1}},
+    {{-1, 0}, {0, 0}, {-1, 1}},  {{0, 1}, {0, 0}, {-1, 1}},   {{0, 1}, {0, 0}, {1, 1}},   {{1, 0}, {0, 0}, {1, 1}},
+};
+
+// meshwarper.cpp:527-551: Mat mask(cell_height, cell_width) = 0; fillConvexPoly(mask, {Vi_rel * cell}, 255)
+void triangle_mask(int t, float cell_w, float cell_h, std::vector<uint8_t> &mask, int &mw, int &mh)
+{
+    mw = (int)cell_w; mh = (int)cell_h;
+    mask.assign((size_t)mw * mh, 0);
+    int rel[3][2], minx = 0, miny = 0;
+    for (int k = 0; k < 3; ++k) { rel[k][0] = TRI[t][k][0]; rel[k][1] = TRI[t][k][1]; minx = std::min(minx, rel[k][0]); miny = std::min(miny, rel[k][1]); }
+    Pt v[3];
+    for (int k = 0; k < 3; ++k) {
+        if (minx < 0) rel[k][0]++;
+        if (miny < 0) rel[k][1]++;
+        v[k].x = (int)(rel[k][0] * cell_w);
+        v[k].y = (int)(rel[k][1] * cell_h);
+    }
+    fill_convex3(mask, mw, mh, v);
+}
+
+// ------------------------------------------------------------------------------------------------ device: triangle statistics
+struct TriJob { int x, y, t; };
+
+// one wave per (vertex, triangle): sum and sum of squares of the three channels over the masked cell crop (exact integers)
+__global__ void __launch_bounds__(64) k_tri_stats(const uint8_t *__restrict__ img, size_t step, const uint8_t *__restrict__ masks, int mw, int mh,
+                                                 const TriJob *__restrict__ jobs, unsigned long long *__restrict__ out)
+{
+    const TriJob jb = jobs[blockIdx.x];
+    const uint8_t *m = masks + (size_t)jb.t * mw * mh;
+    unsigned long long s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < mw * mh; i += 64) {
+        if (!m[i]) continue;
+        const int yy = i / mw, xx = i - yy * mw;
+        const uint8_t *px = img + (size_t)(jb.y + yy) * step + (size_t)(jb.x + xx) * 3;
+        for (int c = 0; c < 3; ++c) { const unsigned v = px[c]; s[c] += v; q[c] += v * v; }
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int off = 32; off; off >>= 1) {
+            s[c] += __shfl_xor(s[c], off);
+            q[c] += __shfl_xor(q[c], off);
+        }
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) { out[(size_t)blockIdx.x * 6 + c] = s[c]; out[(size_t)blockIdx.x * 6 + 3 + c] = q[c]; }
+}
+
+// saliency of every in-mesh (vertex, triangle) of one view (meshwarper.cpp:497-563); NaN marks triangles that leave the mesh
+int view_saliency(const ms_image &im, int M, int N, std::vector<float> &sal, hipStream_t st)
+{
+    const float width = (float)im.cols, height = (float)im.rows;
+    const float cw = width / (M - 1), ch = height / (N - 1);
+    std::vector<uint8_t> masks, one;
+    int mw = 0, mh = 0, nz[8];
+    for (int t = 0; t < 8; ++t) {
+        triangle_mask(t, cw, ch, one, mw, mh);
+        nz[t] = 0;
+        for (uint8_t b : one) nz[t] += b != 0;
+        masks.insert(masks.end(), one.begin(), one.end());
+    }
+    MS_CHECK(mw >= 1 && mh >= 1, "ms_create_mesh: a %dx%d mesh on a %dx%d view has empty cells", M, N, im.cols, im.rows);
+    std::vector<TriJob> jobs;
+    std::vector<int> slot((size_t)N * M * 8, -1);
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < M; ++j)
+            for (int t = 0; t < 8; ++t) {
+                bool in = true;
+                float vx[3], vy[3];
+                for (int k = 0; k < 3; ++k) {
+                    const int x = j + TRI[t][k][0], y = i + TRI[t][k][1];
+                    in &= x >= 0 && y >= 0 && x < M && y < N;
+                    vx[k] = x * cw; vy[k] = y * ch;
+                }
+                if (!in) continue;
+                TriJob jb{(int)std::min(std::min(vx[0], vx[1]), vx[2]), (int)std::min(std::min(vy[0], vy[1]), vy[2]), t};
+                MS_CHECK(jb.x >= 0 && jb.y >= 0 && jb.x + mw <= im.cols && jb.y + mh <= im.rows, "ms_create_mesh: cell crop leaves the view (cv::Mat::operator() asserts)");
+                slot[((size_t)i * M + j) * 8 + t] = (int)jobs.size();
+                jobs.push_back(jb);
+            }
+    Buf dmask, djobs, dout;
+    if (int e = dmask.alloc(masks.size())) return e;
+    if (int e = djobs.alloc(jobs.size() * sizeof(TriJob))) return e;
+    if (int e = dout.alloc(jobs.size() * 6 * sizeof(unsigned long long))) return e;
+    MS_HIP(hipMemcpyAsync(dmask.p, masks.data(), masks.size(), hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(TriJob), hipMemcpyHostToDevice, st));
+    k_tri_stats<<<(unsigned)jobs.size(), 64, 0, st>>>((const uint8_t *)im.data, im.step, dmask.as<uint8_t>(), mw, mh, djobs.as<TriJob>(), dout.as<unsigned long long>());
+    MS_LAUNCH_CHECK();
+    std::vector<unsigned long long> sums(jobs.size() * 6);
+    MS_HIP(hipMemcpyAsync(sums.data(), dout.p, sums.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
+    sal.assign((size_t)N * M * 8, NAN);
+    for (size_t k = 0; k < slot.size(); ++k) {
+        if (slot[k] < 0) continue;
+        const unsigned long long *o = &sums[(size_t)slot[k] * 6];
+        const int cnt = nz[jobs[slot[k]].t];
+        const double scale = cnt ? 1. / cnt : 0.;                                      // cv::meanStdDev, stat.cpp:1939-1943
+        double nrm = 0;
+        for (int c = 0; c < 3; ++c) {
+            const double mean = (double)o[c] * scale;
+            const double dev = std::sqrt(std::max((double)o[3 + c] * scale - mean * mean, 0.));
+            const double var = dev * dev;                                             // cv::pow(deviation, 2)
+            nrm += var * var;
+        }
+        sal[k] = (float)std::sqrt(std::sqrt(nrm) + 0.5f);                               // sqrt(norm(variance, NORM_L2) + 0.5f)
+    }
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host: the linear system
+struct Entry { int row, col; double val; };
+struct LinSys {
+    int M, N, cols, rows = 0;
+    std::vector<Entry> e;
+    std::vector<double> b;
+    void put(int row_off, int col, float v) { e.push_back({rows + row_off, col, (double)v}); }
+    void end_rows(float b0, float b1) { b.push_back(b0); b.push_back(b1); rows += 2; }
+};
+
+float theta_of(int rule, int src, int dst, int n, bool wrap)
+{
+    float theta;
+    if (rule == 0) {                            // the reference's 6-camera rig, meshwarper.cpp:617-629
+        theta = (float)(dst - src);
+        if (src == 0 && dst == n - 1 && wrap) theta = -1;
+        if (src == 3) theta = 4.25f;
+        if (src == 4) theta = -0.25f;
+        theta *= 2 * 3.1415926535897932384626 / 6;
+    } else {                                    // evenly spaced ring of n cameras
+        int d = dst - src;
+        if (d > n / 2.0) d -= n;
+        if (d < -n / 2.0) d += n;
+        theta = (float)d;
+        theta *= 2 * 3.1415926535897932384626 / n;
+    }
+    return theta;
+}
+
+struct Cell { int t, l; float u, v; };
+Cell locate(float x, float y, float w, float h, int M, int N)       // meshwarper.cpp:646-668
+{
+    Cell c;
+    c.t = (int)std::floor(y * (N - 1) / h);
+    c.l = (int)std::floor(x * (M - 1) / w);
+    const float top = c.t * h / (N - 1), bot = top + h / (N - 1);
+    const float left = c.l * w / (M - 1), right = left + w / (M - 1);
+    c.u = (x - left) / (right - left);
+    c.v = (y - top) / (bot - top);
+    return c;
+}
+
+void put_bilinear(LinSys &S, int k, int base, const Cell &c, float a, bool negate)
+{
+    const int M = S.M;
+    const float u = c.u, v = c.v;
+    if (!negate) {
+        S.put(k, 2 * (c.l + M * c.t + base) + k, (1 - u) * (1 - v) * a);
+        S.put(k, 2 * (c.l + 1 + M * c.t + base) + k, u * (1 - v) * a);
+        S.put(k, 2 * (c.l + M * (c.t + 1) + base) + k, v * (1 - u) * a);
+        S.put(k, 2 * (c.l + 1 + M * (c.t + 1) + base) + k, u * v * a);
+    } else {
+        S.put(k, 2 * (c.l + M * c.t + base) + k, -(1 - u) * (1 - v) * a);
+        S.put(k, 2 * (c.l + 1 + M * c.t + base) + k, -u * (1 - v) * a);
+        S.put(k, 2 * (c.l + M * (c.t + 1) + base) + k, -v * (1 - u) * a);
+        S.put(k, 2 * (c.l + 1 + M * (c.t + 1) + base) + k, -u * v * a);
+    }
+}
+
+// calcLocalTerm, meshwarper.cpp:596-709
+void local_term(LinSys &S, const ms_mesh_match *m, int count, const ms_image *views, int n, int idx, const ms_mesh_params &P)
+{
+    const int M = S.M, N = S.N;
+    const float f = P.focal_length, a = std::sqrt(P.alphas[0]);
+    const float scale = (float)(P.compose_scale / P.work_scale);
+    for (int k = 0; k < count; ++k) {
+        const int dst = m[k].dst;
+        if (dst < 0 || dst >= n) continue;
+        const float w1 = (float)views[idx].cols, h1 = (float)views[idx].rows, w2 = (float)views[dst].cols, h2 = (float)views[dst].rows;
+        const float x1 = m[k].x1, y1 = m[k].y1, x2 = m[k].x2, y2 = m[k].y2;
+        if (x1 < 0 || x2 < 0 || y1 < 0 || y2 < 0 || x1 >= w1 || x2 >= w2 || y1 >= h1 || y2 >= h2) continue;
+        const Cell c1 = locate(x1, y1, w1, h1, M, N), c2 = locate(x2, y2, w2, h2, M, N);
+        // float rounding can put a point on the last mesh line; the reference would index past the mesh row there (undefined) -- skipped
+        if (c1.l + 1 >= M || c2.l + 1 >= M || c1.t + 1 >= N || c2.t + 1 >= N) continue;
+        const float theta = theta_of(P.theta_rule, idx, dst, n, P.wrap_around != 0);
+        for (int r = 0; r < 2; ++r) {
+            put_bilinear(S, r, M * N * idx, c1, a, false);
+            put_bilinear(S, r, M * N * dst, c2, a, true);
+        }
+        S.end_rows(theta * f * scale * a, 0.f);
+    }
+}
+
+// calcTemporalLocalTerm, meshwarper.cpp:711-786 ((x2, y2) = the same feature in the previous calibration)
+void temporal_term(LinSys &S, const ms_mesh_match *m, int count, const ms_image &view, int idx, const ms_mesh_params &P)
+{
+    const int M = S.M, N = S.N;
+    const float a = std::sqrt(P.alphas[3]);
+    const float w = (float)view.cols, h = (float)view.rows;
+    for (int k = 0; k < count; ++k) {
+        const float x1 = m[k].x1, y1 = m[k].y1, x2 = m[k].x2, y2 = m[k].y2;
+        if (x1 < 0 || x2 < 0 || y1 < 0 || y2 < 0 || x1 >= w || x2 >= w || y1 >= h || y2 >= h) continue;
+        const Cell c = locate(x1, y1, w, h, M, N);
+        if (c.l + 1 >= M || c.t + 1 >= N) continue;
+        for (int r = 0; r < 2; ++r) put_bilinear(S, r, M * N * idx, c, a, false);
+        S.end_rows(x2 * a, y2 * a);
+    }
+}
+
+// calcGlobalTerm, meshwarper.cpp:389-418; feature points are Point(keypoint.pt) = cvRound of the match positions (meshwarper.cpp:190-196)
+void global_term(LinSys &S, const ms_mesh_match *m, int count, const ms_image &view, int idx, const ms_mesh_params &P)
+{
+    const int M = S.M, N = S.N;
+    const float a = std::sqrt(P.alphas[1]);
+    std::vector<int> px(count), py(count);
+    for (int k = 0; k < count; ++k) { px[k] = (int)std::nearbyint((double)m[k].x1); py[k] = (int)std::nearbyint((double)m[k].y1); }
+    int col = N * M * 2 * idx;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < M; ++j) {
+            const float x1 = (float)(j * view.cols / (M - 1)), y1 = (float)(i * view.rows / (N - 1));
+            float tau = 1;
+            for (int k = 0; k < count; ++k) {
+                const double dx = px[k] - x1, dy = py[k] - y1;
+                if (std::sqrt(dx * dx + dy * dy) < P.global_dist) { tau = 0; break; }
+            }
+            S.put(0, col, a * tau);
+            S.put(1, col + 1, a * tau);
+            S.end_rows(a * tau * x1, a * tau * y1);
+            col += 2;
+        }
+}
+
+// calcSmoothnessTerm, meshwarper.cpp:421-593 (the x row and the y row of a triangle carry the same six coefficients, as in the reference)
+void smoothness_term(LinSys &S, const std::vector<float> &sal, const ms_image &view, int idx, const ms_mesh_params &P)
+{
+    const int M = S.M, N = S.N;
+    const float a = std::sqrt(P.alphas[2]);
+    const float width = (float)view.cols, height = (float)view.rows;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < M; ++j)
+            for (int t = 0; t < 8; ++t) {
+                const float s = sal[((size_t)i * M + j) * 8 + t];
+                if (s != s) continue;                                    // triangle leaves the mesh
+                int X[3], Y[3];
+                for (int k = 0; k < 3; ++k) { X[k] = j + TRI[t][k][0]; Y[k] = i + TRI[t][k][1]; }
+                const float V1x = X[0] * (width / (M - 1)), V2x = X[1] * (width / (M - 1)), V3x = X[2] * (width / (M - 1));
+                const float V1y = Y[0] * (height / (N - 1)), V2y = Y[1] * (height / (N - 1)), V3y = Y[2] * (height / (N - 1));
+                const float u = (-V1x * V2y + V1x * V3y - V2x * V1y + 2 * V2x * V2y - V2x * V3y + V3x * V1y - V3x * V2y) / (2 * (V2x - V3x) * (V2y - V3y));
+                const float v = (V1x * V2y - V1x * V3y - V2x * V1y + V2x * V3y + V3x * V1y - V3x * V2y) / (2 * (V2x - V3x) * (V2y - V3y));
+                const int c0 = 2 * (X[0] + M * Y[0] + M * N * idx), c1 = 2 * (X[1] + M * Y[1] + M * N * idx), c2 = 2 * (X[2] + M * Y[2] + M * N * idx);
+                for (int r = 0; r < 2; ++r) {
+                    S.put(r, c0, a * s);
+                    S.put(r, c0 + 1, a * s);
+                    S.put(r, c1, a * (u - v - 1) * s);
+                    S.put(r, c1 + 1, a * (u + v - 1) * s);
+                    S.put(r, c2, a * (-u + v) * s);
+                    S.put(r, c2 + 1, a * (-u - v) * s);
+                }
+                S.end_rows(0.f, 0.f);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------ device: least-squares CG, fp64
+constexpr int LSCG_PARTS = 128;                 // at most this many workgroups produce partial sums
+constexpr int ELL_W = 8;                        // no row of the system has more than 8 coefficients
+
+struct LscgState {                              // written only by workgroup 0 of the kernel named, read by later kernels
+    double alpha;                               // k_lscg_cols
+    double abs_new[2];                          // k_lscg_update, by iteration parity (the other slot is abs_old)
+    double rhs_norm2, res_norm2, threshold;     // k_lscg_update
+    int pending;                                // k_lscg_update: -1 running, >= 0 converged in that iteration, -2 zero right-hand side
+    int done;                                   // k_lscg_rows copies `pending` here: the flag k_lscg_update itself may read while it writes `pending`
+};
+
+// fixed-order sum of <= LSCG_PARTS partials; every thread of every workgroup gets the same value
+__device__ double sum_parts(const double *__restrict__ part, int stride, int n, double *lds)
+{
+    const int t = threadIdx.x;
+    if (t < LSCG_PARTS) lds[t] = t < n ? part[(size_t)t * stride] : 0.0;
+    __syncthreads();
+    for (int w = LSCG_PARTS / 2; w; w >>= 1) {
+        if (t < w) lds[t] += lds[t + w];
+        __syncthreads();
+    }
+    const double r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ double block_sum(double v, double *lds)          // fixed-order tree over the 256 threads
+{
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int w = 128; w; w >>= 1) {
+        if (t < w) lds[t] += lds[t + w];
+        __syncthreads();
+    }
+    const double r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+// residual -= alpha_prev * tmp_prev (deferred from the previous iteration); tmp = A p; part1[block] = sum tmp^2
+__global__ void __launch_bounds__(256) k_lscg_rows(int R, const int *__restrict__ ecol, const double *__restrict__ eval, const double *__restrict__ p,
+                                                   double *__restrict__ residual, double *__restrict__ tmp, LscgState *__restrict__ S, double *__restrict__ part1)
+{
+    __shared__ double lds[256];
+    const int pend = S->pending;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->done = pend;
+    if (pend != -1) return;
+    const double alpha_prev = S->alpha;
+    double acc = 0;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        residual[r] = residual[r] - alpha_prev * tmp[r];
+        double t = 0;
+        for (int k = 0; k < ELL_W; ++k) t += eval[(size_t)k * R + r] * p[ecol[(size_t)k * R + r]];
+        tmp[r] = t;
+        acc += t * t;
+    }
+    const double s = block_sum(acc, lds);
+    if (threadIdx.x == 0) part1[blockIdx.x] = s;
+}
+
+// alpha = abs_new / sum(part1); normal residual nr = A^T (residual - alpha tmp); z = invdiag nr; partials of nr.nr and nr.z
+// init = 1: the prologue (alpha = 0, tmp = 0): nr = A^T b
+__global__ void __launch_bounds__(256) k_lscg_cols(int n, int iter, int init, int nparts1, const int *__restrict__ cptr, const int *__restrict__ crow,
+                                                   const double *__restrict__ cval, const double *__restrict__ invdiag, const double *__restrict__ residual,
+                                                   const double *__restrict__ tmp, double *__restrict__ z, LscgState *__restrict__ S,
+                                                   const double *__restrict__ part1, double *__restrict__ part3)
+{
+    __shared__ double lds[256];
+    if (S->pending != -1) return;
+    double alpha = 0;
+    if (!init) alpha = S->abs_new[(iter + 1) & 1] / sum_parts(part1, 1, nparts1, lds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->alpha = alpha;
+    const int lane = threadIdx.x & 15;
+    double a_nn = 0, a_nz = 0;
+    for (int j = (blockIdx.x * 256 + threadIdx.x) >> 4; j < n; j += gridDim.x * 16) {      // the 16 lanes of a group share j
+        double acc = 0;
+        for (int k = cptr[j] + lane; k < cptr[j + 1]; k += 16) {
+            const int r = crow[k];
+            acc += cval[k] * (residual[r] - alpha * tmp[r]);
+        }
+        for (int off = 8; off; off >>= 1) acc += __shfl_xor(acc, off, 16);
+        if (lane == 0) {
+            const double zj = invdiag[j] * acc;
+            z[j] = zj;
+            a_nn += acc * acc;
+            a_nz += acc * zj;
+        }
+    }
+    const double snn = block_sum(a_nn, lds), snz = block_sum(a_nz, lds);
+    if (threadIdx.x == 0) { part3[blockIdx.x * 2] = snn; part3[blockIdx.x * 2 + 1] = snz; }
+}
+
+// residualNorm2 = sum nr.nr -> converged?  beta = abs_new / abs_old;  x += alpha p;  p = z + beta p
+__global__ void __launch_bounds__(256) k_lscg_update(int n, int iter, int init, int nparts3, double tol, const double *__restrict__ z, double *__restrict__ x,
+                                                     double *__restrict__ p, LscgState *__restrict__ S, const double *__restrict__ part3)
+{
+    __shared__ double lds[256];
+    if (S->done != -1) return;
+    const double res_norm2 = sum_parts(part3, 2, nparts3, lds), abs_new = sum_parts(part3 + 1, 2, nparts3, lds);
+    const double alpha = S->alpha;
+    double threshold, beta;
+    bool converged;
+    if (init) {
+        threshold = tol * tol * res_norm2;                  // rhsNorm2 == residualNorm2: x0 = 0
+        converged = res_norm2 == 0 || res_norm2 < threshold;
+        beta = 0;
+    } else {
+        threshold = S->threshold;
+        converged = res_norm2 < threshold;
+        beta = abs_new / S->abs_new[(iter + 1) & 1];
+    }
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) {
+        const double pj = p[j];
+        x[j] = x[j] + alpha * pj;
+        if (!converged) p[j] = z[j] + beta * pj;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->abs_new[iter & 1] = abs_new;
+        S->res_norm2 = res_norm2;
+        if (init) { S->rhs_norm2 = res_norm2; S->threshold = threshold; }
+        if (converged) S->pending = init ? (res_norm2 == 0 ? -2 : 0) : iter;
+    }
+}
+
+int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vector<double> &x, ms_mesh_info *info, hipStream_t st)
+{
+    const int R = S.rows, n = S.cols;
+    const size_t nnz = S.e.size();
+    // rows: ELL (column-major slabs, padded with 0 * p[0]); entries of a row ordered by column as a column-major SpMV visits them
+    std::vector<int> ecol((size_t)ELL_W * R, 0), fill(R, 0);
+    std::vector<double> eval((size_t)ELL_W * R, 0.0);
+    std::vector<Entry> byrow(S.e);
+    std::stable_sort(byrow.begin(), byrow.end(), [](const Entry &a, const Entry &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
+    for (const Entry &e : byrow) {
+        MS_CHECK(e.col >= 0 && e.col < n && fill[e.row] < ELL_W, "ms_create_mesh: malformed system row %d", e.row);
+        ecol[(size_t)fill[e.row] * R + e.row] = e.col;
+        eval[(size_t)fill[e.row] * R + e.row] = e.val;
+        fill[e.row]++;
+    }
+    // columns: CSC with rows ascending; Jacobi preconditioner 1 / ||A_col||^2 (1 for an empty column)
+    std::vector<int> cptr(n + 1, 0), crow(nnz);
+    std::vector<double> cval(nnz), invdiag(n, 1.0);
+    for (const Entry &e : byrow) cptr[e.col + 1]++;
+    for (int j = 0; j < n; ++j) cptr[j + 1] += cptr[j];
+    {
+        std::vector<int> pos(cptr.begin(), cptr.end() - 1);
+        for (const Entry &e : byrow) { crow[pos[e.col]] = e.row; cval[pos[e.col]] = e.val; pos[e.col]++; }
+    }
+    for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int k = cptr[j]; k < cptr[j + 1]; ++k) s += cval[k] * cval[k];
+        if (s > 0) invdiag[j] = 1.0 / s;
+    }
+    Buf d_ecol, d_eval, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, d_x, d_p, d_state, d_p1, d_p3;
+    if (int e = d_ecol.alloc(ecol.size() * 4)) return e;
+    if (int e = d_eval.alloc(eval.size() * 8)) return e;
+    if (int e = d_cptr.alloc(cptr.size() * 4)) return e;
+    if (int e = d_crow.alloc(nnz * 4)) return e;
+    if (int e = d_cval.alloc(nnz * 8)) return e;
+    if (int e = d_inv.alloc((size_t)n * 8)) return e;
+    if (int e = d_res.alloc((size_t)R * 8)) return e;
+    if (int e = d_tmp.alloc((size_t)R * 8)) return e;
+    if (int e = d_z.alloc((size_t)n * 8)) return e;
+    if (int e = d_x.alloc((size_t)n * 8)) return e;
+    if (int e = d_p.alloc((size_t)n * 8)) return e;
+    if (int e = d_state.alloc(sizeof(LscgState))) return e;
+    if (int e = d_p1.alloc(LSCG_PARTS * 8)) return e;
+    if (int e = d_p3.alloc(LSCG_PARTS * 16)) return e;
+    MS_HIP(hipMemcpyAsync(d_ecol.p, ecol.data(), ecol.size() * 4, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(d_eval.p, eval.data(), eval.size() * 8, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(d_cptr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(d_crow.p, crow.data(), nnz * 4, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(d_cval.p, cval.data(), nnz * 8, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(d_inv.p, invdiag.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    MS_HIP(hipMemcpyAsync(d_res.p, S.b.data(), (size_t)R * 8, hipMemcpyHostToDevice, st));     // residual = b - A 0
+    MS_HIP(hipMemsetAsync(d_tmp.p, 0, (size_t)R * 8, st));
+    MS_HIP(hipMemsetAsync(d_x.p, 0, (size_t)n * 8, st));
+    MS_HIP(hipMemsetAsync(d_p.p, 0, (size_t)n * 8, st));
+    LscgState init_state{};
+    init_state.pending = init_state.done = -1;
+    MS_HIP(hipMemcpyAsync(d_state.p, &init_state, sizeof init_state, hipMemcpyHostToDevice, st));
+
+    const double tol = tolerance > 0 ? tolerance : DBL_EPSILON;
+    const int max_it = max_iterations > 0 ? max_iterations : 2 * n;
+    const int g_rows = std::min(LSCG_PARTS, div_up(R, 256)), g_cols = std::min(LSCG_PARTS, div_up(n * 16, 256)), g_upd = div_up(n, 256);
+    LscgState *ds = d_state.as<LscgState>();
+    // prologue: normal residual of x0 = 0, rhsNorm2, threshold, p = z
+    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, -1, 1, 0, d_cptr.as<int>(), d_crow.as<int>(), d_cval.as<double>(), d_inv.as<double>(), d_res.as<double>(),
+                                        d_tmp.as<double>(), d_z.as<double>(), ds, d_p1.as<double>(), d_p3.as<double>());
+    k_lscg_update<<<g_upd, 256, 0, st>>>(n, -1, 1, g_cols, tol, d_z.as<double>(), d_x.as<double>(), d_p.as<double>(), ds, d_p3.as<double>());
+    MS_LAUNCH_CHECK();
+    LscgState hs{};
+    int it = 0;
+    for (; it < max_it; ++it) {
+        k_lscg_rows<<<g_rows, 256, 0, st>>>(R, d_ecol.as<int>(), d_eval.as<double>(), d_p.as<double>(), d_res.as<double>(), d_tmp.as<double>(), ds, d_p1.as<double>());
+        k_lscg_cols<<<g_cols, 256, 0, st>>>(n, it, 0, g_rows, d_cptr.as<int>(), d_crow.as<int>(), d_cval.as<double>(), d_inv.as<double>(), d_res.as<double>(),
+                                            d_tmp.as<double>(), d_z.as<double>(), ds, d_p1.as<double>(), d_p3.as<double>());
+        k_lscg_update<<<g_upd, 256, 0, st>>>(n, it, 0, g_cols, tol, d_z.as<double>(), d_x.as<double>(), d_p.as<double>(), ds, d_p3.as<double>());
+        if ((it & 63) == 63) {                  // the kernels of a finished solve return at once; look at the flag now and then
+            MS_HIP(hipMemcpyAsync(&hs, ds, sizeof hs, hipMemcpyDeviceToHost, st));
+            MS_HIP(hipStreamSynchronize(st));
+            if (hs.pending != -1) break;
+        }
+    }
+    MS_LAUNCH_CHECK();
+    MS_HIP(hipMemcpyAsync(&hs, ds, sizeof hs, hipMemcpyDeviceToHost, st));
+    x.resize(n);
+    MS_HIP(hipMemcpyAsync(x.data(), d_x.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
+    if (info) {
+        info->rows = R; info->cols = n; info->nnz = (int)nnz;
+        info->iterations = hs.pending >= 0 ? hs.pending : hs.pending == -2 ? 0 : max_it;
+        info->error = hs.rhs_norm2 > 0 ? std::sqrt(hs.res_norm2 / hs.rhs_norm2) : 0.0;
+    }
+    return MS_OK;
+}
+
+int check_params(const ms_mesh_params *P)
+{
+    MS_CHECK(P != nullptr, "ms_create_mesh: null parameters");
+    MS_CHECK(P->mesh_cols >= 2 && P->mesh_rows >= 2 && P->mesh_cols <= 512 && P->mesh_rows <= 512, "ms_create_mesh: mesh %dx%d out of range", P->mesh_cols, P->mesh_rows);
+    for (int k = 0; k < 4; ++k) MS_CHECK(P->alphas[k] >= 0.f, "ms_create_mesh: negative term weight");
+    MS_CHECK(P->work_scale != 0.0, "ms_create_mesh: work_scale is zero");
+    MS_CHECK(P->theta_rule == 0 || P->theta_rule == 1, "ms_create_mesh: theta_rule must be 0 or 1");
+    return MS_OK;
+}
+
+}  // namespace
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" {
+
+int ms_mesh_default_params(ms_mesh_params *P)
+{
+    if (!P) return fail(MS_ERR_INVALID, "ms_mesh_default_params: null");
+    *P = ms_mesh_params{};
+    P->mesh_cols = 10; P->mesh_rows = 10;                                   // defs.h:65-66
+    P->alphas[0] = 1.0f; P->alphas[1] = 0.01f; P->alphas[2] = 0.00005f; P->alphas[3] = 0.0f;   // defs.h:69
+    P->global_dist = 30;                                                    // defs.h:71
+    P->focal_length = 1.f; P->compose_scale = 1.0; P->work_scale = 1.0;
+    P->wrap_around = 1;                                                     // defs.h:25
+    P->theta_rule = 0; P->max_iterations = 0; P->tolerance = 0.0;
+    return MS_OK;
+}
+
+int ms_mesh_saliency(const ms_image *view, int mesh_cols, int mesh_rows, float *sal_host, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(view && sal_host && view->data && view->type == MS_8UC3, "ms_mesh_saliency: needs an 8UC3 device image and a host output");
+    MS_CHECK(mesh_cols >= 2 && mesh_rows >= 2, "ms_mesh_saliency: mesh %dx%d out of range", mesh_cols, mesh_rows);
+    std::vector<float> sal;
+    if (int e = view_saliency(*view, mesh_cols, mesh_rows, sal, as_stream(stream))) return e;
+    memcpy(sal_host, sal.data(), sal.size() * sizeof(float));
+    return MS_OK;
+}
+
+int ms_create_mesh(int n_views, const ms_image *views, const ms_mesh_match *matches, const int *match_count, const ms_mesh_match *temporal,
+                   const int *temporal_count, const ms_mesh_params *P, float *mesh_x, float *mesh_y, ms_mesh_info *info, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    if (int e = check_params(P)) return e;
+    MS_CHECK(n_views >= 1 && views && match_count && mesh_x && mesh_y, "ms_create_mesh: null argument");
+    hipStream_t st = as_stream(stream);
+    const int M = P->mesh_cols, N = P->mesh_rows;
+    LinSys S;
+    S.M = M; S.N = N; S.cols = 2 * N * M * n_views;
+    const bool use_temporal = P->alphas[3] != 0.0f && temporal && temporal_count;     // defs.h:70
+    int moff = 0, toff = 0;
+    std::vector<float> sal;
+    for (int idx = 0; idx < n_views; ++idx) {
+        MS_CHECK(views[idx].data && views[idx].type == MS_8UC3 && views[idx].cols >= M && views[idx].rows >= N, "ms_create_mesh: view %d must be an 8UC3 device image", idx);
+        MS_CHECK(match_count[idx] >= 0 && (match_count[idx] == 0 || matches), "ms_create_mesh: bad match list of view %d", idx);
+        local_term(S, matches + moff, match_count[idx], views, n_views, idx, *P);
+        global_term(S, matches + moff, match_count[idx], views[idx], idx, *P);
+        if (int e = view_saliency(views[idx], M, N, sal, st)) return e;
+        smoothness_term(S, sal, views[idx], idx, *P);
+        if (use_temporal) { temporal_term(S, temporal + toff, temporal_count[idx], views[idx], idx, *P); toff += temporal_count[idx]; }
+        moff += match_count[idx];
+    }
+    std::vector<double> x;
+    if (int e = solve_lscg(S, P->max_iterations, P->tolerance, x, info, st)) return e;
+    for (int idx = 0; idx < n_views; ++idx)                                  // convertVectorToMesh, meshwarper.cpp:810-818
+        for (int k = 0; k < N * M; ++k) {
+            mesh_x[(size_t)idx * N * M + k] = (float)x[2 * ((size_t)k + (size_t)idx * M * N)];
+            mesh_y[(size_t)idx * N * M + k] = (float)x[2 * ((size_t)k + (size_t)idx * M * N) + 1];
+        }
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -52,6 +52,20 @@ class PanoGeom(C.Structure):
     _fields_ = [("num_bands", C.c_int), ("dst_roi_final", Rect), ("dst_roi", Rect), ("canvas_x", C.c_int), ("canvas_y", C.c_int)]
 
 
+class MeshMatch(C.Structure):
+    _fields_ = [("x1", C.c_float), ("y1", C.c_float), ("x2", C.c_float), ("y2", C.c_float), ("dst", C.c_int)]
+
+
+class MeshParams(C.Structure):
+    _fields_ = [("mesh_cols", C.c_int), ("mesh_rows", C.c_int), ("alphas", C.c_float * 4), ("global_dist", C.c_int),
+                ("focal_length", C.c_float), ("compose_scale", C.c_double), ("work_scale", C.c_double), ("wrap_around", C.c_int),
+                ("theta_rule", C.c_int), ("max_iterations", C.c_int), ("tolerance", C.c_double)]
+
+
+class MeshInfo(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("nnz", C.c_int), ("iterations", C.c_int), ("error", C.c_double)]
+
+
 EXPORTS = [
     "ms_last_error", "ms_version", "ms_device_count", "ms_remap", "ms_resize_linear", "ms_convert_scale_8u", "ms_convert",
     "ms_copy_make_border", "ms_pyr_down", "ms_pyr_up", "ms_subtract_16s", "ms_add_16s", "ms_add_src_weight_32f",
@@ -61,6 +75,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh",
 ]
 
 _lib = None
@@ -316,6 +331,53 @@ def result_roi(rois):
 
 
 # ------------------------------------------------------------------ compositor context
+
+def mesh_default_params(**kw):
+    """defs.h values (10 x 10 mesh, ALPHAS, GLOBAL_DIST, wrapAround); keyword arguments override fields."""
+    p = MeshParams()
+    _chk(load().ms_mesh_default_params(C.byref(p)))
+    for k, v in kw.items():
+        if k == "alphas":
+            p.alphas = (C.c_float * 4)(*v)
+        else:
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+    return p
+
+
+def mesh_saliency(view, mesh_cols, mesh_rows):
+    import numpy as np
+    out = np.empty((mesh_rows, mesh_cols, 8), np.float32)
+    _chk(load().ms_mesh_saliency(C.byref(img(view)), mesh_cols, mesh_rows, out.ctypes.data_as(C.POINTER(C.c_float)), _stream()))
+    return out
+
+
+def _match_array(lists):
+    flat = [m for l in lists for m in l]
+    arr = (MeshMatch * max(1, len(flat)))()
+    for k, m in enumerate(flat):
+        arr[k] = MeshMatch(float(m[0]), float(m[1]), float(m[2]), float(m[3]), int(m[4]) if len(m) > 4 else 0)
+    return arr, (C.c_int * len(lists))(*[len(l) for l in lists])
+
+
+def create_mesh(views, matches, params, temporal=None):
+    """MeshWarper::createMesh after feature matching (ms_create_mesh).  views: warped 8UC3 device tensors; matches[v]: list of
+    (x1, y1, x2, y2, dst); temporal[v]: list of (x1, y1, x2, y2).  Returns mesh_x, mesh_y (n, N, M) float32 host arrays and the solver info."""
+    import numpy as np
+    n = len(views)
+    ims = (Image * n)(*[img(v) for v in views])
+    marr, mcnt = _match_array(matches)
+    tarr = tcnt = None
+    if temporal is not None:
+        tarr, tcnt = _match_array(temporal)
+    mx = np.empty((n, params.mesh_rows, params.mesh_cols), np.float32)
+    my = np.empty_like(mx)
+    info = MeshInfo()
+    fp = C.POINTER(C.c_float)
+    _chk(load().ms_create_mesh(n, ims, marr, mcnt, tarr, tcnt, C.byref(params), mx.ctypes.data_as(fp), my.ctypes.data_as(fp),
+                               C.byref(info), _stream()))
+    return mx, my, {k: getattr(info, k) for k, _ in MeshInfo._fields_}
+
 
 class Compositor:
     """stitch_calib tables once (build_maps / build_masks / init_blender), then stitch() per frame batch."""
