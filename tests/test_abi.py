@@ -60,3 +60,17 @@ def test_status_and_version(ms):
     r = ms.Rect()
     assert lib.ms_warp_roi(7, None, None, C.c_float(1.0), 10, 10, C.byref(r)) == -1
     assert b"ms_warp_roi" in lib.ms_last_error()
+
+
+def test_shim_meshwarper_selection_state_machine(tmp_path):
+    """msshim::MeshWarper (filterMatches + the use-old-features logic of createMesh) against hand-derived expectations; host only."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shim_mw")
+    pkg = os.path.join(ROOT, "video-stitcher_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim_meshwarper_check.cpp"),
+                           "-L" + pkg, "-lmsstitch", "-Wl,-rpath," + pkg, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -389,7 +389,7 @@ void smoothness_term(LinSys &S, const std::vector<float> &sal, const ms_image &v
 }
 
 // ------------------------------------------------------------------------------------------------ device: least-squares CG, fp64
-constexpr int LSCG_PARTS = 128;                 // at most this many workgroups produce partial sums
+constexpr int LSCG_PARTS = 512;                 // at most this many workgroups produce partial sums (2 x the CU count)
 constexpr int ELL_W = 8;                        // no row of the system has more than 8 coefficients
 
 struct LscgState {                              // written only by workgroup 0 of the kernel named, read by later kernels
@@ -400,22 +400,7 @@ struct LscgState {                              // written only by workgroup 0 o
     int done;                                   // k_lscg_rows copies `pending` here: the flag k_lscg_update itself may read while it writes `pending`
 };
 
-// fixed-order sum of <= LSCG_PARTS partials; every thread of every workgroup gets the same value
-__device__ double sum_parts(const double *__restrict__ part, int stride, int n, double *lds)
-{
-    const int t = threadIdx.x;
-    if (t < LSCG_PARTS) lds[t] = t < n ? part[(size_t)t * stride] : 0.0;
-    __syncthreads();
-    for (int w = LSCG_PARTS / 2; w; w >>= 1) {
-        if (t < w) lds[t] += lds[t + w];
-        __syncthreads();
-    }
-    const double r = lds[0];
-    __syncthreads();
-    return r;
-}
-
-__device__ double block_sum(double v, double *lds)          // fixed-order tree over the 256 threads
+__device__ double block_sum_impl(double v, double *lds)     // fixed-order tree over the 256 threads
 {
     const int t = threadIdx.x;
     lds[t] = v;
@@ -428,6 +413,17 @@ __device__ double block_sum(double v, double *lds)          // fixed-order tree 
     __syncthreads();
     return r;
 }
+
+// fixed-order sum of <= LSCG_PARTS partials; every thread of every workgroup gets the same value
+__device__ double sum_parts(const double *__restrict__ part, int stride, int n, double *lds)
+{
+    const int t = threadIdx.x;                  // 256 threads
+    double v = 0;
+    for (int k = t; k < LSCG_PARTS; k += 256) v += k < n ? part[(size_t)k * stride] : 0.0;
+    return block_sum_impl(v, lds);
+}
+
+__device__ double block_sum(double v, double *lds) { return block_sum_impl(v, lds); }
 
 // residual -= alpha_prev * tmp_prev (deferred from the previous iteration); tmp = A p; part1[block] = sum tmp^2
 __global__ void __launch_bounds__(256) k_lscg_rows(int R, const int *__restrict__ ecol, const double *__restrict__ eval, const double *__restrict__ p,

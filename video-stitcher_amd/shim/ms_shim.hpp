@@ -6,6 +6,8 @@
 // sources/modules/core/include/opencv2/core/cuda.hpp:283-303).  Header-only, no OpenCV dependency.
 // Errors become exceptions here (the reference throws cv::Exception), never across the C boundary.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -108,6 +110,129 @@ public:
 private:
     ms_ctx *ctx_ = nullptr;
     int n_ = 0;
+};
+
+
+// ---- MeshWarper: createMesh's host logic around ms_create_mesh (360_stitcher/meshwarper.cpp:158-335) --------------------------
+// Works on anything shaped like cv::detail::ImageFeatures (.img_size, .keypoints[i].pt) and cv::detail::MatchesInfo (.src_img_idx,
+// .dst_img_idx, .matches[i].queryIdx/.trainIdx, .inliers_mask, .num_inliers): the feature front-end (featurefinder.cpp) stays the caller's.
+// Differences from the reference, all stated: NUM_IMAGES is the run-time view count (the literal 5 of filterMatches is num_images - 1);
+// prev_avg starts at 0 (an uninitialised member in the reference); old matches are kept as resolved positions instead of indices into a
+// copy of the old ImageFeatures.
+class MeshWarper {
+public:
+    static const int RECALIB_THRESH = 15;            // defs.h:49
+    static const int MAX_FEATURES_PER_IMAGE = 100;   // defs.h:60
+
+    MeshWarper(int num_images, int mesh_width, int mesh_height, float focal_length, double compose_scale, double work_scale)
+        : n_(num_images), old_(num_images), prev_(num_images), prev_avg_(2 * num_images, 0.f), have_old_(num_images, 0)
+    {
+        check(ms_mesh_default_params(&prm_));
+        prm_.mesh_cols = mesh_width; prm_.mesh_rows = mesh_height; prm_.focal_length = focal_length;
+        prm_.compose_scale = compose_scale; prm_.work_scale = work_scale;
+    }
+    ms_mesh_params &params() { return prm_; }
+
+    // theta of a camera pair, meshwarper.cpp:617-629 / :914-925 (before the * 2 pi / 6)
+    float theta(int src, int dst) const
+    {
+        float t = (float)(dst - src);
+        if (src == 0 && dst == n_ - 1 && prm_.wrap_around) t = -1;
+        if (src == 3) t = 4.25f;
+        if (src == 4) t = -0.25f;
+        return t;
+    }
+
+    // filterMatches, meshwarper.cpp:888-946: inliers of the kept camera pairs whose offset is plausible for the rig
+    template <class Features, class Matches>
+    void filterMatches(const std::vector<Matches> &pairwise_matches, const std::vector<Features> &features, std::vector<std::vector<ms_mesh_match>> &filt) const
+    {
+        filt.assign(n_, {});
+        for (const Matches &pw : pairwise_matches) {
+            const int src = pw.src_img_idx, dst = pw.dst_img_idx;
+            if (!pw.matches.size() || !pw.num_inliers) continue;
+            if (dst != n_ - 1 || (src != 0 && dst == n_ - 1))
+                if (src - dst - 1 != 0) continue;
+            for (size_t i = 0; i < pw.inliers_mask.size(); ++i) {
+                if (!pw.inliers_mask[i]) continue;
+                const auto &p1 = features[src].keypoints[pw.matches[i].queryIdx].pt;
+                const auto &p2 = features[dst].keypoints[pw.matches[i].trainIdx].pt;
+                const float scale = (float)(prm_.compose_scale / prm_.work_scale);
+                const float max_x_dist = theta(src, dst) * prm_.focal_length * scale;
+                if (std::fabs(p1.y - p2.y) > 40) continue;
+                if (std::fabs(max_x_dist - (p1.x - p2.x)) > 300) continue;
+                filt[src].push_back(ms_mesh_match{p1.x, p1.y, p2.x, p2.y, dst});
+            }
+        }
+    }
+
+    // the match lists createMesh hands to calcLocalTerm / calcGlobalTerm (meshwarper.cpp:158-292), and the state update (:313-334)
+    template <class Features, class Matches>
+    std::vector<std::vector<ms_mesh_match>> select(const std::vector<Features> &features, const std::vector<Matches> &pairwise_matches)
+    {
+        std::vector<std::vector<ms_mesh_match>> all, sel(n_), use(n_);
+        filterMatches(pairwise_matches, features, all);
+        for (int v = 0; v < n_; ++v)
+            sel[v].assign(all[v].begin(), all[v].begin() + std::min<size_t>(MAX_FEATURES_PER_IMAGE, all[v].size()));
+        // average x of the matched points per image half: [2 idx] = as source (left partner), [2 idx + 1] = as destination
+        std::vector<float> sum(2 * n_, 0.f), cnt(2 * n_, 0.f), avg(2 * n_, 0.f);
+        for (int v = 0; v < n_; ++v)
+            for (const ms_mesh_match &m : sel[v]) { sum[v * 2] += m.x1; sum[m.dst * 2 + 1] += m.x2; cnt[v * 2]++; cnt[m.dst * 2 + 1]++; }
+        for (int k = 0; k < 2 * n_; ++k) if (cnt[k] != 0) avg[k] = sum[k] / cnt[k];
+        std::vector<char> use_old(n_, 0);
+        for (int v = 0; v < n_; ++v) {
+            const int v2 = v == 0 ? n_ - 1 : v - 1;
+            const float d = std::fabs(avg[v * 2] - avg[v2 * 2 + 1]), dp = std::fabs(prev_avg_[v * 2] - prev_avg_[v2 * 2 + 1]);
+            const bool found = avg[v * 2] != 0 && avg[v2 * 2 + 1] != 0, found_prev = prev_avg_[v * 2] != 0 && prev_avg_[v2 * 2 + 1] != 0;
+            use_old[v] = std::fabs(d - dp) < RECALIB_THRESH || (!found && found_prev);
+            use[v] = use_old[v] ? old_[v] : sel[v];
+        }
+        for (int v = 0; v < n_; ++v) {
+            prev_[v] = sel[v];
+            const int v2 = v == 0 ? n_ - 1 : v - 1;
+            if (use_old[v] && !prev_[v].empty() && have_old_[v]) continue;
+            old_[v] = sel[v];   have_old_[v] = 1;  prev_avg_[v * 2] = avg[v * 2];   prev_avg_[v * 2 + 1] = avg[v * 2 + 1];
+            old_[v2] = sel[v2]; have_old_[v2] = 1; prev_avg_[v2 * 2] = avg[v2 * 2]; prev_avg_[v2 * 2 + 1] = avg[v2 * 2 + 1];
+        }
+        return use;
+    }
+
+    // createMesh from the matching step on: warped = images[idx] (the remapped frames, device 8UC3); meshes come back as n x N x M host floats
+    template <class Mat, class Features, class Matches>
+    ms_mesh_info createMesh(const std::vector<Mat> &warped, const std::vector<Features> &features, const std::vector<Matches> &pairwise_matches,
+                            std::vector<float> &mesh_x, std::vector<float> &mesh_y, ms_stream s = nullptr)
+    {
+        const std::vector<std::vector<ms_mesh_match>> use = select(features, pairwise_matches);
+        std::vector<ms_image> views;
+        std::vector<ms_mesh_match> flat;
+        std::vector<int> count;
+        for (const Mat &m : warped) views.push_back(wrap(m));
+        for (const auto &l : use) { flat.insert(flat.end(), l.begin(), l.end()); count.push_back((int)l.size()); }
+        mesh_x.assign((size_t)n_ * prm_.mesh_rows * prm_.mesh_cols, 0.f);
+        mesh_y.assign(mesh_x.size(), 0.f);
+        ms_mesh_info info{};
+        check(ms_create_mesh(n_, views.data(), flat.data(), count.data(), nullptr, nullptr, &prm_, mesh_x.data(), mesh_y.data(), &info, s));
+        return info;
+    }
+
+    // calibrateMeshWarp (meshwarper.cpp:356-376): createMesh + convertMeshesToMap into the compositor
+    template <class Mat, class Features, class Matches>
+    ms_mesh_info calibrateMeshWarp(Compositor &comp, const std::vector<Mat> &warped, const std::vector<Features> &features,
+                                   const std::vector<Matches> &pairwise_matches, ms_stream s = nullptr)
+    {
+        std::vector<float> mx, my;
+        const ms_mesh_info info = createMesh(warped, features, pairwise_matches, mx, my, s);
+        const size_t per = (size_t)prm_.mesh_rows * prm_.mesh_cols;
+        for (int v = 0; v < n_; ++v) comp.convertMeshToMap(v, mx.data() + v * per, my.data() + v * per, prm_.mesh_rows, prm_.mesh_cols, s);
+        return info;
+    }
+
+private:
+    int n_;
+    ms_mesh_params prm_{};
+    std::vector<std::vector<ms_mesh_match>> old_, prev_;    // old_matches / prev_matches, resolved to positions
+    std::vector<float> prev_avg_;
+    std::vector<char> have_old_;                             // !old_features.at(idx).empty()
 };
 
 }  // namespace msshim

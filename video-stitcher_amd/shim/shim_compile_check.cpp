@@ -19,6 +19,15 @@ int shim_compile_check()
         comp.stitch_one(frames, &a, (FakeGpuMat *)nullptr);
         for (int i = 0; i < 6; ++i) comp.feed_online(frames[i], i);
         comp.blend(&a, (FakeGpuMat *)nullptr);
+        // MeshWarper over ImageFeatures / MatchesInfo shaped types
+        struct Pt { float x, y; }; struct KeyPoint { Pt pt; }; struct Size { int width, height; };
+        struct Features { Size img_size; std::vector<KeyPoint> keypoints; };
+        struct DMatch { int queryIdx, trainIdx; };
+        struct Matches { int src_img_idx, dst_img_idx; std::vector<DMatch> matches; std::vector<unsigned char> inliers_mask; int num_inliers; };
+        msshim::MeshWarper mw(6, 10, 10, 600.f, 1.0, 0.5);
+        std::vector<Features> feats(6);
+        std::vector<Matches> pairwise(6);
+        mw.calibrateMeshWarp(comp, frames, feats, pairwise);
     } catch (const msshim::Error &e) {
         return e.code;
     }
