@@ -20,10 +20,11 @@
 namespace ms {
 namespace {
 
-struct Buf {                                    // device buffer, freed on scope exit
+struct Buf {                                    // stream-ordered device buffer (no device-wide synchronisation: the stitcher keeps running)
     void *p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { if (p) (void)hipFree(p); p = nullptr; MS_HIP(hipMalloc(&p, n ? n : 16)); return MS_OK; }
+    hipStream_t st = nullptr;
+    ~Buf() { if (p) (void)hipFreeAsync(p, st); }
+    int alloc(size_t n, hipStream_t s) { st = s; MS_HIP(hipMallocAsync(&p, n ? n : 16, s)); return MS_OK; }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -208,9 +209,9 @@ int view_saliency(const ms_image &im, int M, int N, std::vector<float> &sal, hip
                 jobs.push_back(jb);
             }
     Buf dmask, djobs, dout;
-    if (int e = dmask.alloc(masks.size())) return e;
-    if (int e = djobs.alloc(jobs.size() * sizeof(TriJob))) return e;
-    if (int e = dout.alloc(jobs.size() * 6 * sizeof(unsigned long long))) return e;
+    if (int e = dmask.alloc(masks.size(), st)) return e;
+    if (int e = djobs.alloc(jobs.size() * sizeof(TriJob), st)) return e;
+    if (int e = dout.alloc(jobs.size() * 6 * sizeof(unsigned long long), st)) return e;
     MS_HIP(hipMemcpyAsync(dmask.p, masks.data(), masks.size(), hipMemcpyHostToDevice, st));
     MS_HIP(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(TriJob), hipMemcpyHostToDevice, st));
     k_tri_stats<<<(unsigned)jobs.size(), 64, 0, st>>>((const uint8_t *)im.data, im.step, dmask.as<uint8_t>(), mw, mh, djobs.as<TriJob>(), dout.as<unsigned long long>());
@@ -541,20 +542,20 @@ int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vecto
         if (s > 0) invdiag[j] = 1.0 / s;
     }
     Buf d_ecol, d_eval, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, d_x, d_p, d_state, d_p1, d_p3;
-    if (int e = d_ecol.alloc(ecol.size() * 4)) return e;
-    if (int e = d_eval.alloc(eval.size() * 8)) return e;
-    if (int e = d_cptr.alloc(cptr.size() * 4)) return e;
-    if (int e = d_crow.alloc(nnz * 4)) return e;
-    if (int e = d_cval.alloc(nnz * 8)) return e;
-    if (int e = d_inv.alloc((size_t)n * 8)) return e;
-    if (int e = d_res.alloc((size_t)R * 8)) return e;
-    if (int e = d_tmp.alloc((size_t)R * 8)) return e;
-    if (int e = d_z.alloc((size_t)n * 8)) return e;
-    if (int e = d_x.alloc((size_t)n * 8)) return e;
-    if (int e = d_p.alloc((size_t)n * 8)) return e;
-    if (int e = d_state.alloc(sizeof(LscgState))) return e;
-    if (int e = d_p1.alloc(LSCG_PARTS * 8)) return e;
-    if (int e = d_p3.alloc(LSCG_PARTS * 16)) return e;
+    if (int e = d_ecol.alloc(ecol.size() * 4, st)) return e;
+    if (int e = d_eval.alloc(eval.size() * 8, st)) return e;
+    if (int e = d_cptr.alloc(cptr.size() * 4, st)) return e;
+    if (int e = d_crow.alloc(nnz * 4, st)) return e;
+    if (int e = d_cval.alloc(nnz * 8, st)) return e;
+    if (int e = d_inv.alloc((size_t)n * 8, st)) return e;
+    if (int e = d_res.alloc((size_t)R * 8, st)) return e;
+    if (int e = d_tmp.alloc((size_t)R * 8, st)) return e;
+    if (int e = d_z.alloc((size_t)n * 8, st)) return e;
+    if (int e = d_x.alloc((size_t)n * 8, st)) return e;
+    if (int e = d_p.alloc((size_t)n * 8, st)) return e;
+    if (int e = d_state.alloc(sizeof(LscgState), st)) return e;
+    if (int e = d_p1.alloc(LSCG_PARTS * 8, st)) return e;
+    if (int e = d_p3.alloc(LSCG_PARTS * 16, st)) return e;
     MS_HIP(hipMemcpyAsync(d_ecol.p, ecol.data(), ecol.size() * 4, hipMemcpyHostToDevice, st));
     MS_HIP(hipMemcpyAsync(d_eval.p, eval.data(), eval.size() * 8, hipMemcpyHostToDevice, st));
     MS_HIP(hipMemcpyAsync(d_cptr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, st));

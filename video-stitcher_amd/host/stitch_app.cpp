@@ -16,7 +16,7 @@
 //   recalibrate thread (timed.cpp:414-463)       recalibrate(): ms_set_mesh per view from its own stream
 //
 // Usage: stitch_app [--views 6] [--size 1920x1080] [--out 3840x1920] [--hfov 90] [--bands 5] [--frames 300] [--cpw]
-//                   [--i420] [--nv12] [--dump pano.bin] [--no-upload]
+//                   [--i420] [--nv12] [--dump pano.bin] [--no-upload] [--solve-mesh]
 // Prints one JSON line: end-to-end frames/s INCLUDING the PCIe upload of every source frame (unlike bench.py).
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -70,7 +70,7 @@ struct HostFrame { unsigned char *p = nullptr; int w = 0, h = 0; long long seq =
 struct Options {
     int views = 6, w = 1920, h = 1080, out_w = 3840, out_h = 1920, bands = 5, frames = 300;
     double hfov = 90.0;
-    bool cpw = false, i420 = false, upload = true, nv12 = false;
+    bool cpw = false, i420 = false, upload = true, nv12 = false, solve_mesh = false;
     std::string dump;
 };
 
@@ -152,6 +152,7 @@ int main(int argc, char **argv)
         else if (k == "--bands") o.bands = atoi(next());
         else if (k == "--frames") o.frames = atoi(next());
         else if (k == "--cpw") o.cpw = true;
+        else if (k == "--solve-mesh") o.cpw = o.solve_mesh = true;
         else if (k == "--i420") o.i420 = true;
         else if (k == "--no-upload") o.upload = false;
         else if (k == "--nv12") o.nv12 = true;
@@ -240,7 +241,72 @@ int main(int argc, char **argv)
 
         std::thread recalibrater;
         std::atomic<int> recalibrations{0};
-        if (o.cpw)
+        std::atomic<int> solver_iterations{0};
+        std::string recal_failure;
+        if (o.solve_mesh)
+            // recalibrateMesh (meshwarper.cpp:378-386) with the mesh actually solved: upload the current frames on the recalibration stream,
+            // remap them (createMesh's images[idx]), optimise the mesh from matches and hand it to the compositor -- all while the stitcher
+            // runs.  The feature front-end is not part of this build: the matches are synthetic (a parallax that drifts from round to round).
+            recalibrater = std::thread([&] {
+                try {
+                    struct Pt { float x, y; }; struct KeyPoint { Pt pt; }; struct Size { int width, height; };
+                    struct Features { Size img_size; std::vector<KeyPoint> keypoints; };
+                    struct DMatch { int queryIdx, trainIdx; };
+                    struct Matches { int src_img_idx, dst_img_idx; std::vector<DMatch> matches; std::vector<unsigned char> inliers_mask; int num_inliers; };
+                    msshim::MeshWarper mw(o.views, 10, 10, warp_scale, 1.0, 1.0);
+                    mw.params().theta_rule = 1;
+                    std::vector<DevMat> recal_full(o.views), images(o.views);
+                    std::vector<ms_view_geom> g(o.views);
+                    for (int i = 0; i < o.views; ++i) {
+                        g[i] = comp.viewGeom(i);
+                        recal_full[i].create(o.h, o.w, MS_8UC3, 3);
+                        images[i].create(g[i].roi.height, g[i].roi.width, MS_8UC3, 3);
+                    }
+                    int round = 1;
+                    while (running.load()) {
+                        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                        {
+                            std::lock_guard<std::mutex> lk(imgs.mu);
+                            if (!o.nv12)
+                                for (int i = 0; i < o.views; ++i)
+                                    HIPCHECK(hipMemcpy2DAsync(recal_full[i].data, recal_full[i].step, imgs.v[i].p, (size_t)o.w * 3, (size_t)o.w * 3, o.h,
+                                                              hipMemcpyHostToDevice, recal_stream));
+                            HIPCHECK(hipStreamSynchronize(recal_stream));
+                        }
+                        std::vector<Features> feats(o.views);
+                        std::vector<Matches> pairwise;
+                        for (int i = 0; i < o.views; ++i) {
+                            ms_image xm, ym;
+                            msshim::check(ms_get_maps(comp.raw(), i, &xm, &ym));
+                            ms_image src = msshim::wrap(recal_full[i]), dst = msshim::wrap(images[i]);
+                            msshim::check(ms_remap(&src, &xm, &ym, &dst, MS_INTER_LINEAR, MS_BORDER_CONSTANT, (ms_stream)recal_stream));
+                            feats[i].img_size = {g[i].roi.width, g[i].roi.height};
+                        }
+                        for (int src = 0; src < o.views; ++src) {             // the kept pairs are (src, src - 1) and the wrap-around seam (0, n - 1)
+                            const int dst = src == 0 ? o.views - 1 : src - 1;
+                            if (g[src].roi.width > o.out_w / 2 || g[dst].roi.width > o.out_w / 2) continue;      // the view straddling +-pi
+                            const int off = ((g[src].roi.x - g[dst].roi.x) % o.out_w + o.out_w) % o.out_w;        // x1 - x2 of a true correspondence = -off
+                            Matches m{src, dst, {}, {}, 0};
+                            for (int k = 0; k < 60; ++k) {
+                                const float x1 = 4.f + (float)((k * 37) % std::max(1, g[dst].roi.width - off - 8));
+                                const float y1 = 8.f + (float)((k * 53) % std::max(1, g[src].roi.height - 16));
+                                const float x2 = x1 + off + 3.f * std::sin(0.7f * round + 0.01f * y1), y2 = y1 + 1.5f * std::cos(0.4f * round);
+                                if (x2 < 0 || x2 >= g[dst].roi.width) continue;
+                                feats[src].keypoints.push_back({{x1, y1}});
+                                feats[dst].keypoints.push_back({{x2, y2}});
+                                m.matches.push_back({(int)feats[src].keypoints.size() - 1, (int)feats[dst].keypoints.size() - 1});
+                                m.inliers_mask.push_back(1);
+                                ++m.num_inliers;
+                            }
+                            pairwise.push_back(m);
+                        }
+                        const ms_mesh_info info = mw.calibrateMeshWarp(comp, images, feats, pairwise, (ms_stream)recal_stream);
+                        solver_iterations += info.iterations;
+                        ++round; ++recalibrations;
+                    }
+                } catch (const std::exception &e) { recal_failure = e.what(); }
+            });
+        else if (o.cpw)
             recalibrater = std::thread([&] {            // timed.cpp:414-463: new meshes while the stitcher keeps running
                 int round = 1;
                 while (running.load()) {
@@ -292,6 +358,7 @@ int main(int argc, char **argv)
         if (recalibrater.joinable()) recalibrater.join();
         HIPCHECK(hipDeviceSynchronize());
         if (!failure.empty()) { fprintf(stderr, "stitch_app: %s\n", failure.c_str()); return 1; }
+        if (!recal_failure.empty()) { fprintf(stderr, "stitch_app (recalibration): %s\n", recal_failure.c_str()); return 1; }
 
         for (unsigned char b : last_pano) checksum = (checksum ^ b) * 1099511628211ull;   // FNV-1a over the last 8U panorama
         if (!o.dump.empty()) {
@@ -300,9 +367,9 @@ int main(int argc, char **argv)
             fclose(f);
         }
         printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"upload\": %s, "
-               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"checksum\": \"%016llx\"}\n",
+               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"checksum\": \"%016llx\"}\n",
                o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.upload ? "true" : "false",
-               consumed, secs, consumed / secs, recalibrations.load(), checksum);
+               consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), checksum);
     } catch (const msshim::Error &e) {
         fprintf(stderr, "stitch_app: msstitch error %d: %s\n", e.code, e.what());
         return 1;

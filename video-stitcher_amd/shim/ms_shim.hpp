@@ -133,9 +133,16 @@ public:
     }
     ms_mesh_params &params() { return prm_; }
 
-    // theta of a camera pair, meshwarper.cpp:617-629 / :914-925 (before the * 2 pi / 6)
+    // theta of a camera pair in camera steps, meshwarper.cpp:617-629 / :914-925 (before the * 2 pi / 6, which filterMatches never applies);
+    // params().theta_rule = 1 (evenly spaced ring): the wrapped index difference, in radians
     float theta(int src, int dst) const
     {
+        if (prm_.theta_rule == 1) {
+            int d = dst - src;
+            if (d > n_ / 2.0) d -= n_;
+            if (d < -n_ / 2.0) d += n_;
+            return (float)(d * 2 * 3.1415926535897932384626 / n_);
+        }
         float t = (float)(dst - src);
         if (src == 0 && dst == n_ - 1 && prm_.wrap_around) t = -1;
         if (src == 3) t = 4.25f;
