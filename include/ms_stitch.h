@@ -334,6 +334,14 @@ MS_API int ms_create_mesh(int n_views, const ms_image *warped_views, const ms_me
                           const ms_mesh_match *temporal, const int *temporal_count, const ms_mesh_params *prm,
                           float *mesh_x, float *mesh_y, ms_mesh_info *info, ms_stream stream);
 
+/* DescriptorMatcher::create("BruteForce-Hamming")->knnMatch(query, train, matches, 2) of featurefinder::matchFeatures / matchFeaturesTemporal
+ * (360_stitcher/featurefinder.cpp:50-61, :117-128; BFMatcher::knnMatchImpl, features2d/src/matchers.cpp:815-880; cv::batchDistance,
+ * core/src/stat.cpp:3946-4008).  query / train: DEVICE 8UC1 descriptor rows (ORB: 32 bytes; any multiple of 4 up to 64).  For query row q,
+ * train_idx_host[2q], [2q+1] and distance_host[2q], [2q+1] receive the two nearest train rows in (distance, index) order -- exactly the rows
+ * and tie-breaks of the reference's insertion loop; index -1 / distance INT_MAX where train has fewer than two rows.  The 0.7 ratio test and
+ * findHomography stay with the caller (msshim::knnRatioMatches does the former).  Synchronises `stream`. */
+MS_API int ms_knn_match_hamming2(const ms_image *query, const ms_image *train, int *train_idx_host, int *distance_host, ms_stream stream);
+
 /* device-resident static tables, for parity tests: x_maps[i]/y_maps[i] (32FC1), masks (8UC1),
  * weight pyramid level (32FC1). Borrowed pointers owned by ctx. */
 MS_API int ms_get_maps(const ms_ctx *ctx, int view, ms_image *xmap, ms_image *ymap);

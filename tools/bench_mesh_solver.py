@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Recalibration-path timing of the CPW mesh optimiser (ms_create_mesh) on the config-2/3 rig: 6 warped 1080p views, 100 matches per
+"""Recalibration-path timing of the descriptor matcher (ms_knn_match_hamming2) and the CPW mesh optimiser (ms_create_mesh) on the config-2/3 rig: 6 warped 1080p views, 100 matches per
 seam (MAX_FEATURES_PER_IMAGE), the reference's default 10 x 10 mesh and BASELINE config 3's 40 x 40 mesh.  Prints one JSON line per mesh
 size; the numpy oracle (oracle/mesh_oracle.py, CPU) is timed beside it on the 10 x 10 case when --cpu is given.
 
@@ -53,6 +53,23 @@ def main():
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
+    # descriptor matching of matchFeatures: cuda::ORB::create(2500, ...) -> 2500 x 2500 Hamming 2-NN per seam (featurefinder.cpp:15, :60)
+    rng = np.random.default_rng(1)
+    q = torch.from_numpy(rng.integers(0, 256, (2500, 32), dtype=np.uint8)).cuda()
+    t = torch.from_numpy(rng.integers(0, 256, (2500, 32), dtype=np.uint8)).cuda()
+    ms.knn_match_hamming2(q, t)
+    ts = []
+    for _ in range(max(3, a.reps)):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ms.knn_match_hamming2(q, t)
+        ts.append(time.perf_counter() - t0)
+    line = {"what": "ms_knn_match_hamming2", "query": 2500, "train": 2500, "bytes": 32, "ms": round(1e3 * min(ts), 3)}
+    if a.cpu:
+        import features_oracle as fo
+        t0 = time.perf_counter()
+        fo.knn2(q.cpu().numpy(), t.cpu().numpy())
+        line["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+    print(json.dumps(line), flush=True)
     comp, cfg, warped, matches = build()
     scale = synth.warp_scale(cfg["out_w"])
     for M in (10, 40):

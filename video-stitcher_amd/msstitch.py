@@ -75,7 +75,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2",
 ]
 
 _lib = None
@@ -331,6 +331,17 @@ def result_roi(rois):
 
 
 # ------------------------------------------------------------------ compositor context
+
+def knn_match_hamming2(query, train):
+    """BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2): (train_idx, distance) int32 arrays of shape (nq, 2)."""
+    import numpy as np
+    nq = query.shape[0]
+    idx = np.empty((nq, 2), np.int32)
+    dist = np.empty((nq, 2), np.int32)
+    ip = C.POINTER(C.c_int)
+    _chk(load().ms_knn_match_hamming2(C.byref(img(query)), C.byref(img(train)), idx.ctypes.data_as(ip), dist.ctypes.data_as(ip), _stream()))
+    return idx, dist
+
 
 def mesh_default_params(**kw):
     """defs.h values (10 x 10 mesh, ALPHAS, GLOBAL_DIST, wrapAround); keyword arguments override fields."""

@@ -113,6 +113,18 @@ private:
 };
 
 
+// ---- matchFeatures' descriptor matching (featurefinder.cpp:50-66): dm->knnMatch(f1.descriptors, f2.descriptors, matches, 2) on the device,
+// then the 0.7 ratio test.  query / train: GpuMat-like 8UC1 descriptor matrices (upload of ImageFeatures::descriptors).
+// Calls emit(queryIdx, trainIdx, distance) for every kept pair, in query order -- push_back(DMatch(...)) in the caller.
+template <class Mat, class Emit> void knnRatioMatches(const Mat &query, const Mat &train, Emit emit, ms_stream s = nullptr)
+{
+    ms_image q = wrap(query), t = wrap(train);
+    std::vector<int> idx((size_t)2 * q.rows), dist((size_t)2 * q.rows);
+    check(ms_knn_match_hamming2(&q, &t, idx.data(), dist.data(), s));
+    for (int i = 0; i < q.rows; ++i)
+        if (idx[2 * i + 1] >= 0 && (float)dist[2 * i] < 0.7 * (float)dist[2 * i + 1]) emit(i, idx[2 * i], (float)dist[2 * i]);
+}
+
 // ---- MeshWarper: createMesh's host logic around ms_create_mesh (360_stitcher/meshwarper.cpp:158-335) --------------------------
 // Works on anything shaped like cv::detail::ImageFeatures (.img_size, .keypoints[i].pt) and cv::detail::MatchesInfo (.src_img_idx,
 // .dst_img_idx, .matches[i].queryIdx/.trainIdx, .inliers_mask, .num_inliers): the feature front-end (featurefinder.cpp) stays the caller's.

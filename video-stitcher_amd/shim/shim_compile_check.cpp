@@ -24,9 +24,10 @@ int shim_compile_check()
         struct Features { Size img_size; std::vector<KeyPoint> keypoints; };
         struct DMatch { int queryIdx, trainIdx; };
         struct Matches { int src_img_idx, dst_img_idx; std::vector<DMatch> matches; std::vector<unsigned char> inliers_mask; int num_inliers; };
-        msshim::MeshWarper mw(6, 10, 10, 600.f, 1.0, 0.5);
         std::vector<Features> feats(6);
         std::vector<Matches> pairwise(6);
+        msshim::knnRatioMatches(a, b, [&](int q, int t, float d) { pairwise[0].matches.push_back({q, t}); (void)d; });
+        msshim::MeshWarper mw(6, 10, 10, 600.f, 1.0, 0.5);
         mw.calibrateMeshWarp(comp, frames, feats, pairwise);
     } catch (const msshim::Error &e) {
         return e.code;
