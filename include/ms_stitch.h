@@ -49,7 +49,8 @@ typedef enum ms_status {
 enum { MS_8UC1 = 0, MS_8UC3 = 16, MS_16SC1 = 3, MS_16SC3 = 19, MS_32FC1 = 5 };
 /* cv::BorderTypes / cv::InterpolationFlags values used on the path */
 enum { MS_BORDER_CONSTANT = 0, MS_BORDER_REFLECT = 2 };
-enum { MS_INTER_NEAREST = 0, MS_INTER_LINEAR = 1 };
+enum { MS_INTER_NEAREST = 0, MS_INTER_LINEAR = 1,
+       MS_INTER_LINEAR_FIXPT = 0x101 };   /* cv::remap's CPU arithmetic (1/32-px coordinates, 15-bit weight table; imgwarp.cpp:211-284, :643-850, :1203-1270) */
 /* warper kinds: detail::{Plane,Cylindrical,Spherical}WarperGpu (OCV/stitching/include/opencv2/stitching/detail/warpers.hpp:435-550) */
 enum { MS_PROJ_PLANE = 0, MS_PROJ_CYLINDRICAL = 1, MS_PROJ_SPHERICAL = 2 };
 
@@ -74,7 +75,9 @@ MS_API int ms_device_count(void);       /* cuda::getCudaEnabledDeviceCount (blen
 /* cuda::remap(src, dst, xmap, ymap, INTER_LINEAR|INTER_NEAREST, borderMode, Scalar(0), stream)
  * OCV/cudawarping/src/remap.cpp:61-102 -> device::imgproc::remap_gpu<uchar3|uchar> (cuda/remap.cu:56-86).
  * BORDER_CONSTANT(0): 8UC3 linear, 8UC1 linear/nearest (the per-frame warps, timed.cpp:84-101; mask warps);
- * BORDER_REFLECT: 8UC3 linear (the seam-scale image warp, calibration.cpp:118).  dst.size == xmap.size == ymap.size. */
+ * BORDER_REFLECT: 8UC3 linear (the seam-scale image warp, calibration.cpp:118).  dst.size == xmap.size == ymap.size.
+ * MS_INTER_LINEAR_FIXPT (8UC1 / 8UC3, BORDER_CONSTANT) is the CPU cv::remap(..., INTER_LINEAR) flavour instead: what MeshWarper::createMesh
+ * warps its images with (meshwarper.cpp:72) and what the reference's CPU pipeline (BASELINE configs[0]) produces, bit for bit. */
 MS_API int ms_remap(const ms_image *src, const ms_image *xmap, const ms_image *ymap, ms_image *dst,
                     int interpolation, int border_type, ms_stream stream);
 

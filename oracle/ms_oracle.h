@@ -51,6 +51,9 @@ void orc_remap_linear_8uc3(const uint8_t *src, size_t sstep, int srows, int scol
                            const float *mapx, size_t mxstep, const float *mapy, size_t mystep,
                            uint8_t *dst, size_t dstep, int drows, int dcols);
 /* K1' cuda::remap, INTER_NEAREST, BORDER_CONSTANT(0), 8UC1 (calibration masks). */
+void orc_cv_remap_linear_8u(const uint8_t *src, size_t sstep, int srows, int scols, int cn,
+                            const float *mapx, size_t mxstep, const float *mapy, size_t mystep,
+                            uint8_t *dst, size_t dstep, int drows, int dcols);     /* cv::remap, CPU fixed-point flavour (a19) */
 void orc_remap_nearest_8uc1(const uint8_t *src, size_t sstep, int srows, int scols,
                             const float *mapx, size_t mxstep, const float *mapy, size_t mystep,
                             uint8_t *dst, size_t dstep, int drows, int dcols);

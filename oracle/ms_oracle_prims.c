@@ -134,6 +134,88 @@ void orc_remap_linear_8uc1(const uint8_t *src, size_t sstep, int srows, int scol
     remap_linear_8u(src, sstep, srows, scols, 1, mapx, mxstep, mapy, mystep, dst, dstep, drows, dcols);
 }
 
+/* a19 -- cv::remap, the CPU flavour (what MeshWarper::createMesh and the config-1 CPU pipeline run): INTER_LINEAR on CV_32FC1 map pairs,
+ * BORDER_CONSTANT(0), 8-bit sources.
+ *   RemapInvoker (imgproc/src/imgwarp.cpp:1203-1270): sx = cvRound(x * 32) (nearest-even; INT_MIN when out of range / NaN, as cvtps2dq),
+ *     XY = saturate_cast<short>(sx >> 5), table index (sy & 31) * 32 + (sx & 31)
+ *   initInterTab2D (imgwarp.cpp:211-284): BilinearTab_i = saturate_cast<short>(w * 32768), then the sum fix-up -- restated literally,
+ *     including its reads past the 2x2 entry (k1, k2 run over ksize/2 .. ksize/2 + 1), which land in the NEXT, still zero, entry
+ *   remapBilinear<FixedPtCast<int, uchar, 15>> (imgwarp.cpp:643-850): sum of tap * weight over the taps inside the image, (v + 16384) >> 15 */
+static short cv_bilinear_tab[32 * 32 * 4 + 8];
+static int cv_bilinear_tab_ready;
+static void cv_init_bilinear_tab(void)
+{
+    if (cv_bilinear_tab_ready) return;
+    memset(cv_bilinear_tab, 0, sizeof cv_bilinear_tab);
+    float tab1[32][2];
+    const float scale = 1.f / 32;
+    for (int i = 0; i < 32; ++i) { tab1[i][0] = 1.f - i * scale; tab1[i][1] = i * scale; }      /* interpolateLinear */
+    short *itab = cv_bilinear_tab;
+    const int ksize = 2;
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j, itab += ksize * ksize) {
+            int isum = 0;
+            for (int k1 = 0; k1 < ksize; ++k1) {
+                const float vy = tab1[i][k1];
+                for (int k2 = 0; k2 < ksize; ++k2) {
+                    const float v = vy * tab1[j][k2];
+                    long r = lrintf(v * 32768);                                               /* saturate_cast<short>(float) */
+                    if (r > 32767) r = 32767;
+                    if (r < -32768) r = -32768;
+                    isum += itab[k1 * ksize + k2] = (short)r;
+                }
+            }
+            if (isum != 32768) {
+                const int diff = isum - 32768;
+                const int ksize2 = ksize / 2;
+                int Mk1 = ksize2, Mk2 = ksize2, mk1 = ksize2, mk2 = ksize2;
+                for (int k1 = ksize2; k1 < ksize2 + 2; ++k1)
+                    for (int k2 = ksize2; k2 < ksize2 + 2; ++k2) {
+                        if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
+                else itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
+            }
+        }
+    cv_bilinear_tab_ready = 1;
+}
+
+static inline int cv_round_f(float v)
+{
+    const float r = rintf(v);
+    return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : INT32_MIN;
+}
+
+void orc_cv_remap_linear_8u(const uint8_t *src, size_t sstep, int srows, int scols, int cn,
+                            const float *mapx, size_t mxstep, const float *mapy, size_t mystep,
+                            uint8_t *dst, size_t dstep, int drows, int dcols)
+{
+    cv_init_bilinear_tab();
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < drows; ++y) {
+        const float *mx = CROWP(float, mapx, mxstep, y);
+        const float *my = CROWP(float, mapy, mystep, y);
+        uint8_t *d = ROWP(uint8_t, dst, dstep, y);
+        for (int x = 0; x < dcols; ++x) {
+            const int qx = cv_round_f(mx[x] * 32), qy = cv_round_f(my[x] * 32);
+            const short *w = cv_bilinear_tab + ((qy & 31) * 32 + (qx & 31)) * 4;
+            int sx = qx >> 5, sy = qy >> 5;
+            sx = sx > 32767 ? 32767 : sx < -32768 ? -32768 : sx;
+            sy = sy > 32767 ? 32767 : sy < -32768 ? -32768 : sy;
+            for (int c = 0; c < cn; ++c) {
+                int v = 0;
+                for (int t = 0; t < 4; ++t) {
+                    const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                    if (xx >= 0 && xx < scols && yy >= 0 && yy < srows) v += CROWP(uint8_t, src, sstep, yy)[xx * cn + c] * w[t];
+                }
+                v = (v + (1 << 14)) >> 15;
+                d[x * cn + c] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        }
+    }
+}
+
 /* K1': PointFilter (filters.hpp:58-77: src(__float2int_rz(y), __float2int_rz(x))) + BrdConstant(0) */
 void orc_remap_nearest_8uc1(const uint8_t *src, size_t sstep, int srows, int scols,
                             const float *mapx, size_t mxstep, const float *mapy, size_t mystep,

@@ -99,6 +99,17 @@ def remap_linear_8uc1(src, mapx, mapy):
     return dst
 
 
+def cv_remap_linear(src, mapx, mapy):
+    """cv::remap(src, dst, mapx, mapy, INTER_LINEAR) on the CPU (fixed-point coordinates and weights), 8UC1 or 8UC3, BORDER_CONSTANT 0."""
+    src = np.ascontiguousarray(src, np.uint8)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
+    dst = np.empty(mapx.shape + ((cn,) if src.ndim == 3 else ()), np.uint8)
+    lib().orc_cv_remap_linear_8u(_p(src), _st(src), src.shape[0], src.shape[1], cn, _p(mapx), _st(mapx), _p(mapy), _st(mapy),
+                                 _p(dst), _st(dst), dst.shape[0], dst.shape[1])
+    return dst
+
+
 def remap_linear_reflect_8uc3(src, mapx, mapy):
     mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
     dst = np.empty(mapx.shape + (3,), np.uint8)

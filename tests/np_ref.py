@@ -104,3 +104,30 @@ def feather_blend_np(corners, imgs8u, masks, dt_l1, sharpness=0.02):
     mask = np.where(dw > np.float32(1e-5), 255, 0).astype(np.uint8)
     q[mask == 0] = 0
     return q, mask
+
+
+def cv_remap_linear_np(src, mapx, mapy):
+    """Independent numpy statement of cv::remap's CPU arithmetic (INTER_LINEAR, float map pair, BORDER_CONSTANT 0, 8-bit):
+    coordinates quantised to 1/32 px (round half to even), closed-form 15-bit weights (32-fy)(32-fx)*32 ..., except the all-integer entry,
+    which OpenCV's table holds as {32767, 0, 0, 1} (32768 saturates to short and the fix-up adds the missing 1 to the last tap)."""
+    src = np.asarray(src)
+    img = src[..., None] if src.ndim == 2 else src
+    h, w, cn = img.shape
+    q = []
+    for m in (mapx, mapy):
+        r = np.rint(np.asarray(m, np.float32) * np.float32(32)).astype(np.float64)
+        bad = ~np.isfinite(r) | (r >= 2.0 ** 31) | (r < -2.0 ** 31)
+        q.append(np.where(bad, -2.0 ** 31, r).astype(np.int64))
+    fx, fy = q[0] & 31, q[1] & 31
+    sx, sy = np.clip(q[0] >> 5, -32768, 32767), np.clip(q[1] >> 5, -32768, 32767)
+    wts = [(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32]
+    whole = (fx == 0) & (fy == 0)
+    wts[0] = np.where(whole, 32767, wts[0]); wts[3] = np.where(whole, 1, wts[3])
+    acc = np.zeros(sx.shape + (cn,), np.int64)
+    for t, (dx, dy) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+        xx, yy = sx + dx, sy + dy
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        px = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        acc += np.where(ok[..., None], px, 0) * wts[t][..., None]
+    out = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+    return out[..., 0] if src.ndim == 2 else out

@@ -320,6 +320,38 @@ def test_feather_blender_matches_oracle(ms, cuda, oracle, rig):
     comp.close()
 
 
+def test_config1_cpu_flavour_remap_and_feather(ms, cuda, oracle):
+    """BASELINE configs[0] as the reference's CPU pipeline computes it: spherical maps, cv::remap's fixed-point bilinear (imgwarp.cpp), gain,
+    FeatherBlender(0.02).  GPU: the reference kernels with the CPU-flavoured projection remap (ms_config.reserved[5]) + ms_init_feather."""
+    import math
+    sc = float(np.float32(2000.0 / (2 * math.pi)))
+    comp = ms.Compositor(2, (640, 480), ms.PROJ_SPHERICAL, sc, num_bands=0, out_size=(2000, 1000), simple_kernels=True, cv_remap=True)
+    cams = [synth.camera(1, 640, 480, 90.0, 0, yaw=math.radians(a)) for a in (-25.0, 25.0)]
+    gains = [0.97, 1.04]
+    for i, (K, R) in enumerate(cams):
+        comp.set_camera(i, K, R); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(0); comp.init_feather(0.02)
+    pg = comp.pano_geom()
+    frames = [synth.frame(640, 480, i, 1) for i in range(2)]
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    corners = [comp.view_geom(i).roi.tuple()[:2] for i in range(2)]
+    masks = [host(comp.mask(i)) for i in range(2)]
+    warped, warped_cuda = [], []
+    for i in range(2):
+        xm, ym = [host(m) for m in comp.maps(i)]
+        warped.append(oracle.convert_scale_8u(oracle.cv_remap_linear(frames[i], xm, ym), gains[i]))
+        warped_cuda.append(oracle.convert_scale_8u(oracle.remap_linear_8uc3(frames[i], xm, ym), gains[i]))
+    ref16, refmask, roi = oracle.feather_blend(corners, warped, masks, 0.02)
+    assert np.array_equal(host(out16), ref16) and np.array_equal(host(comp.result_mask()), refmask)
+    other16, _, _ = oracle.feather_blend(corners, warped_cuda, masks, 0.02)
+    assert not np.array_equal(other16, ref16)         # the flavour matters: the CUDA arithmetic gives a different panorama
+    comp.close()
+    with pytest.raises(ms.MsError):                     # only in the reference kernels
+        ms.Compositor(2, (640, 480), ms.PROJ_SPHERICAL, sc, num_bands=0, out_size=(2000, 1000), cv_remap=True)
+
+
 @pytest.mark.parametrize("proj", ["cylindrical", "plane"])
 def test_other_projections_match_oracle(ms, cuda, oracle, proj):
     """The three *WarperGpu projections share the per-frame path (warpers_cuda.cpp:149-277): cylindrical on the 4-view rig,

@@ -258,3 +258,24 @@ def test_nv12_to_bgr(ms, cuda, oracle, size):
     assert np.array_equal(host(ms.nv12_to_bgr(to_dev(src))), ref)
     assert np.array_equal(host(ms.nv12_to_bgr(to_dev_roi(src, rng))), ref)
     assert tuple(ref[0, 0]) == (0, 0, 0) and tuple(ref[0, 1]) == (255, 255, 255)
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_remap_cpu_flavour_fixed_point(ms, cuda, oracle, cn):
+    """ms_remap(MS_INTER_LINEAR_FIXPT) = cv::remap(INTER_LINEAR) on the CPU: 1/32-px coordinates, 15-bit weight table, (v + 2^14) >> 15
+    (imgwarp.cpp:211-284, :643-850, :1203-1270); bit-exact against the C oracle and the independent numpy statement."""
+    import np_ref
+    rng = np.random.default_rng(40 + cn)
+    src = rng.integers(0, 256, size=(97, 131) + ((3,) if cn == 3 else ()), dtype=np.uint8)
+    yy, xx = np.mgrid[0:120, 0:150].astype(np.float32)
+    mx = (0.93 * xx - 0.36 * yy + 20.3).astype(np.float32)
+    my = (0.36 * xx + 0.87 * yy - 31.7).astype(np.float32)
+    mx[3, 4] = np.nan; my[5, 6] = np.inf; mx[7, 8] = -1e20; my[8, 9] = 3e9
+    mx[9, 10] = 17.0; my[9, 10] = 23.0
+    mx[11, :20] = np.arange(20) - 1.5; my[11, :20] = -0.5
+    mx[12, :20] = 129.0 + np.arange(20) * 0.125; my[12, :20] = 95.0 + np.arange(20) * 0.125       # right / bottom border taps
+    got = host(ms.remap(to_dev(src), to_dev(mx), to_dev(my), interpolation=ms.INTER_LINEAR_FIXPT))
+    assert np.array_equal(got, oracle.cv_remap_linear(src, mx, my))
+    assert np.array_equal(got, np_ref.cv_remap_linear_np(src, mx, my))
+    d = np.abs(got.astype(int) - host(ms.remap(to_dev(src), to_dev(mx), to_dev(my))).astype(int))
+    assert 0 < d.max() <= 8          # the two flavours do differ on noise (SURVEY App. C: up to 6)

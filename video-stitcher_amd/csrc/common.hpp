@@ -43,6 +43,38 @@ __device__ __forceinline__ uint8_t sat_u8_ref(float v)     // the definition, op
 __device__ __forceinline__ unsigned sat_u8_into(float v, unsigned k, unsigned word) { return __builtin_amdgcn_cvt_pk_u8_f32(v, k, word); }
 __device__ __forceinline__ uint8_t sat_u8(float v) { return (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(v, 0u, 0u); }
 // saturate_cast<short>(float) == cvt.rni.sat.s16.f32
+// cv::remap on the CPU (INTER_LINEAR, float map pair, BORDER_CONSTANT 0, 8-bit): RemapInvoker quantises the coordinates to 1/32 px with
+// cvtps2dq (nearest-even, 0x80000000 when unrepresentable), remapBilinear sums tap * BilinearTab_i over the taps inside the image and
+// rounds with (v + 2^14) >> 15 (imgwarp.cpp:1203-1270, :643-850).  The table is (32-fy)(32-fx)*32, ... exactly, except entry (0, 0):
+// 32768 saturates to 32767 and initInterTab2D's fix-up (imgwarp.cpp:249-265) puts the missing 1 on the last tap.
+__device__ __forceinline__ int cv_round_sse(float v)
+{
+    const float r = __builtin_rintf(v);
+    return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : (int)0x80000000;
+}
+template <int CN>
+__device__ __forceinline__ void remap_fixpt(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols, float xc, float yc, uint8_t out[CN])
+{
+    const int qx = cv_round_sse(xc * 32.f), qy = cv_round_sse(yc * 32.f);
+    const int fx = qx & 31, fy = qy & 31;
+    const int sx = max(-32768, min(32767, qx >> 5)), sy = max(-32768, min(32767, qy >> 5));
+    int w[4] = {(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32};
+    if ((fx | fy) == 0) { w[0] = 32767; w[3] = 1; }
+    int acc[CN];
+#pragma unroll
+    for (int c = 0; c < CN; ++c) acc[c] = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int xx = sx + (t & 1), yy = sy + (t >> 1);
+        const bool inb = xx >= 0 && xx < scols && yy >= 0 && yy < srows;
+        const uint8_t *p = src + (size_t)(inb ? yy : 0) * sstep + (size_t)(inb ? xx : 0) * CN;
+#pragma unroll
+        for (int c = 0; c < CN; ++c) acc[c] += inb ? (int)p[c] * w[t] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < CN; ++c) out[c] = (uint8_t)min(255, (acc[c] + (1 << 14)) >> 15);
+}
+
 __device__ __forceinline__ int16_t sat_s16(float v)
 {
     float r = __builtin_rintf(v);

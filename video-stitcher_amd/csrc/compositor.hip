@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) k_remap_gain(const ViewDesc *__restrict__
 
 // Gaussian level 0 of every view: (remap -> gain) or (remap through the mesh of the stage-1 image),
 // BORDER_REFLECT pad folded into the source index, planar u8 output.
-template <bool CPW>
+// FIX: cv::remap's CPU arithmetic for the projection remap (ms_config.reserved[5], the reference's CPU pipeline of BASELINE configs[0])
+template <bool CPW, bool FIX = false>
 __global__ void __launch_bounds__(256) k_warp(const ViewDesc *__restrict__ views, int n_views, SrcTable src, int src_rows, int src_cols,
                                               MeshTable mesh, const uint8_t *__restrict__ stage, long long stage_stride,
                                               uint8_t *__restrict__ g0, long long g0_stride)
@@ -86,9 +87,16 @@ __global__ void __launch_bounds__(256) k_warp(const ViewDesc *__restrict__ views
         for (int c = 0; c < 3; ++c) r[c] = sat_u8(o[c]);
     } else {
         const float xc = V.xmap[(size_t)ay * V.map_pitch + ax], yc = V.ymap[(size_t)ay * V.map_pitch + ax];
-        sample3(src.p[blockIdx.z], src.step[blockIdx.z], src_rows, src_cols, xc, yc, o);
+        if (FIX) {
+            uint8_t q[3];
+            remap_fixpt<3>(src.p[blockIdx.z], src.step[blockIdx.z], src_rows, src_cols, xc, yc, q);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) r[c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+            for (int c = 0; c < 3; ++c) r[c] = sat_u8(__builtin_fmaf(V.gain, (float)q[c], 0.f));
+        } else {
+            sample3(src.p[blockIdx.z], src.step[blockIdx.z], src_rows, src_cols, xc, yc, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = sat_u8(__builtin_fmaf(V.gain, (float)sat_u8(o[c]), 0.f));
+        }
     }
     const LevelDesc &L = V.lv[0];
     uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)y * L.pitch + x;
@@ -1560,6 +1568,10 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
         c->own_mask = 0;
         for (int v = idx * c->N / S; v < (idx + 1) * c->N / S; ++v) c->own_mask |= 1u << v;
     }
+    if (cfg->reserved[5] != 0 && (cfg->reserved[0] == 0 || cfg->enable_cpw)) {
+        delete c;
+        return fail(MS_ERR_INVALID, "ms_create: the CPU-flavoured remap (reserved[5]) runs in the reference kernels only (reserved[0] = 1) and without CPW");
+    }
     if (hipEventCreateWithFlags(&c->last_stitch, hipEventDisableTiming) != hipSuccess) { delete c; return fail(MS_ERR_HIP, "hipEventCreate failed"); }
     *out = c;
     return MS_OK;
@@ -2327,6 +2339,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1, (const float2 *)c->tabs.p);
         else
             MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0, (const float2 *)c->tabs.p);
+    } else if (c->cfg.reserved[5] != 0) {
+        k_warp<false, true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
+            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

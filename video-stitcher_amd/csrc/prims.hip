@@ -58,6 +58,20 @@ __global__ void __launch_bounds__(256) k_remap_linear(const uint8_t *__restrict_
     for (int c = 0; c < CN; ++c) d[c] = sat_u8(out[c]);
 }
 
+// cv::remap's CPU arithmetic (MS_INTER_LINEAR_FIXPT): see remap_fixpt in common.hpp
+template <int CN>
+__global__ void __launch_bounds__(256) k_remap_fixpt(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
+                                                     const float *__restrict__ mx, size_t mxstep, const float *__restrict__ my, size_t mystep,
+                                                     uint8_t *__restrict__ dst, size_t dstep, int drows, int dcols)
+{
+    XY_GUARD(dcols, drows)
+    uint8_t o[CN];
+    remap_fixpt<CN>(src, sstep, srows, scols, row_ptr<float>(mx, mxstep, y)[x], row_ptr<float>(my, mystep, y)[x], o);
+    uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) d[c] = o[c];
+}
+
 // remap, INTER_NEAREST (PointFilter: __float2int_rz), BORDER_CONSTANT(0), 8UC1  [filters.hpp:58-77]
 __global__ void __launch_bounds__(256) k_remap_nearest_c1(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols,
                                                           const float *__restrict__ mx, size_t mxstep,
@@ -113,6 +127,10 @@ int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms
         k_remap_linear<3><<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
     else if (src.type == MS_8UC1 && interp == MS_INTER_LINEAR)
         k_remap_linear<1><<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_8UC3 && interp == MS_INTER_LINEAR_FIXPT)
+        k_remap_fixpt<3><<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
+    else if (src.type == MS_8UC1 && interp == MS_INTER_LINEAR_FIXPT)
+        k_remap_fixpt<1><<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
     else if (src.type == MS_8UC1 && interp == MS_INTER_NEAREST)
         k_remap_nearest_c1<<<g, b, 0, st>>>(S, src.step, src.rows, src.cols, MX, xm.step, MY, ym.step, D, dst.step, dst.rows, dst.cols);
     else

@@ -279,7 +279,7 @@ int main(int argc, char **argv)
                             ms_image xm, ym;
                             msshim::check(ms_get_maps(comp.raw(), i, &xm, &ym));
                             ms_image src = msshim::wrap(recal_full[i]), dst = msshim::wrap(images[i]);
-                            msshim::check(ms_remap(&src, &xm, &ym, &dst, MS_INTER_LINEAR, MS_BORDER_CONSTANT, (ms_stream)recal_stream));
+                            msshim::check(ms_remap(&src, &xm, &ym, &dst, MS_INTER_LINEAR_FIXPT, MS_BORDER_CONSTANT, (ms_stream)recal_stream));   // cv::remap, meshwarper.cpp:72
                             feats[i].img_size = {g[i].roi.width, g[i].roi.height};
                         }
                         for (int src = 0; src < o.views; ++src) {             // the kept pairs are (src, src - 1) and the wrap-around seam (0, n - 1)
