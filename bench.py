@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--emulate-gather", action="store_true", help="single GPU: run the per-frame egress conversion of the N>1 path without the collective (host/GPU cost of that leg)")
     ap.add_argument("--gather-format", default="i420", choices=["i420", "bgr"],
                     help="what the sink rank receives: planar I420 of the pano rows (the encoder input of consume(), timed.cpp:308-316; "
                          "half the bytes) or the 8UC3 rows themselves")
@@ -329,6 +330,12 @@ def main():
     subruns = [[comps[k].prepared(frames[k * Fs:(k + 1) * Fs], out8u=outs[b][k * Fs:(k + 1) * Fs]) for k in range(S)] for b in range(2)]
     handles = [ctypes.c_void_p(st.cuda_stream) for st in streams]
 
+    gather = world > 1 and not args.no_gather
+    egress = gather or args.emulate_gather
+    # egress of the N>1 path: the pano ROI rows of every canvas of the step -> one I420 slab each, one launch once the contexts have joined
+    # (one launch per context on its own stream measured 4 % slower)
+    to_i420 = [ms.bgr_to_i420_batch_prepared([outs[b][j][ya:yb] for j in range(F)], [slabs[b][j] for j in range(F)]) for b in range(2)] if (i420 and egress) else None
+
     def make_run(b):
         def run():
             if S > 1:
@@ -340,9 +347,10 @@ def main():
                     cur.wait_stream(streams[k])
             else:
                 subruns[b][0](handles[0])
+            if to_i420:
+                to_i420[b]()
         return run
     runs = [make_run(b) for b in range(2)]
-    gather = world > 1 and not args.no_gather
     gl = [[torch.empty_like(slabs[0]) for _ in range(world)] for _ in range(2)] if (gather and rank == 0) else [None, None]
     pending = [None, None]
     y0 = pg.canvas_y
@@ -367,13 +375,13 @@ def main():
                         cc.set_mesh(i, *mesh_pool[recal["count"] % 4][i])
                 recal["count"] += 1
         runs[b]()
-        if gather:
-            for j in range(F):   # the pano ROI rows of each canvas are one contiguous slab
-                if i420:
-                    ms.bgr_to_i420(outs[b][j][ya:yb], dst=slabs[b][j])
-                else:
+        if gather or args.emulate_gather:
+            if not i420:         # (the I420 slabs are written by runs[b] itself)
+                for j in range(F):
                     slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
-            if share:
+            if not gather:
+                pass
+            elif share:
                 df.gather_slabs(slabs[b].cpu(), rank, world, dst=0, async_op=False)
             else:
                 pending[b], _ = df.gather_slabs(slabs[b], rank, world, dst=0, async_op=True, out=gl[b])

@@ -154,6 +154,8 @@ MS_API int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream stream);
  * RGB888toYUV420pInvoker (OCV/imgproc/src/color.cpp:9082-9160).  src 8UC3 with even width/height; dst contiguous
  * 8UC1 of (rows*3/2) x cols = planar I420.  Also what bench.py gathers across GPUs (half the bytes of BGR). */
 MS_API int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream stream);
+/* The same conversion for n frames of one geometry (same size and step) in one launch: the egress of a batch of panoramas. */
+MS_API int ms_bgr_to_i420_batch(const ms_image *src, ms_image *dst, int n, ms_stream stream);
 
 /* custom_resize(GpuMat &in, GpuMat &out, Size t_size)  APP/resize.cu:30-45, APP/calibration.h:15.
  * out->rows/cols give t_size.  32FC1. */

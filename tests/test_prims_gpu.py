@@ -279,3 +279,19 @@ def test_remap_cpu_flavour_fixed_point(ms, cuda, oracle, cn):
     assert np.array_equal(got, np_ref.cv_remap_linear_np(src, mx, my))
     d = np.abs(got.astype(int) - host(ms.remap(to_dev(src), to_dev(mx), to_dev(my))).astype(int))
     assert 0 < d.max() <= 8          # the two flavours do differ on noise (up to 6)
+
+
+def test_bgr_to_i420_batch_equals_single_calls(ms, cuda):
+    rng = np.random.default_rng(77)
+    frames = [to_dev(rng.integers(0, 256, (46, 64, 3), dtype=np.uint8)) for _ in range(70)]      # > one launch's table of 64
+    canvases = [torch.zeros((80, 64, 3), dtype=torch.uint8, device=cuda) for _ in frames]
+    for c, f in zip(canvases, frames):
+        c[10:56] = f
+    srcs = [c[10:56] for c in canvases]                                                            # rows of a larger canvas, as bench.py passes them
+    dsts = [torch.zeros((69, 64), dtype=torch.uint8, device=cuda) for _ in frames]
+    ms.bgr_to_i420_batch_prepared(srcs, dsts)()
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert np.array_equal(host(d), host(ms.bgr_to_i420(s)))
+    with pytest.raises(ms.MsError):
+        ms.bgr_to_i420_batch_prepared([srcs[0], srcs[1][:44]], dsts[:2])()

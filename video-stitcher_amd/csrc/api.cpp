@@ -223,6 +223,21 @@ int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream s)
     return launch_bgr_to_i420(*src, *dst, as_stream(s));
 }
 
+int ms_bgr_to_i420_batch(const ms_image *src, ms_image *dst, int n, ms_stream s)
+{
+    PRE()
+    MS_CHECK(src && dst && n >= 0, "ms_bgr_to_i420_batch: null argument");
+    for (int i = 0; i < n; ++i) {
+        MS_CHECK(src[i].data && dst[i].data && src[i].type == MS_8UC3 && dst[i].type == MS_8UC1, "ms_bgr_to_i420_batch: frame %d: 8UC3 -> 8UC1 planes", i);
+        MS_CHECK(src[i].cols == src[0].cols && src[i].rows == src[0].rows && src[i].step == src[0].step, "ms_bgr_to_i420_batch: frame %d differs in geometry from frame 0", i);
+        MS_CHECK(src[i].cols % 2 == 0 && src[i].rows % 2 == 0, "ms_bgr_to_i420_batch: width and height must be even (color.cpp: CV_Assert)");
+        MS_CHECK(dst[i].cols == src[i].cols && dst[i].rows == src[i].rows * 3 / 2 && dst[i].step == (size_t)dst[i].cols,
+                 "ms_bgr_to_i420_batch: dst %d must be a contiguous 8UC1 image of %d x %d", i, src[i].cols, src[i].rows * 3 / 2);
+    }
+    if (n == 0) return MS_OK;
+    return launch_bgr_to_i420_batch(src, dst, n, as_stream(s));
+}
+
 int ms_custom_resize_32f(const ms_image *in, ms_image *out, ms_stream s)
 {
     PRE() IMG(in, "ms_custom_resize_32f in") IMG(out, "ms_custom_resize_32f out")

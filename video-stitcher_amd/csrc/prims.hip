@@ -2,6 +2,7 @@
 // (row-pitched, interleaved) images.  These are the drop-in replacements of the reference's
 // individual calls (include/ms_stitch.h section 1); the per-frame fast path is compositor.hip.
 // Written for gfx950 wave64: 64 lanes along x (coalesced rows), 4 rows per 256-thread workgroup.
+#include <algorithm>
 #include "common.hpp"
 #include "launchers.hpp"
 
@@ -572,10 +573,9 @@ int launch_nv12_to_bgr(const ms_image &src, ms_image &dst, hipStream_t st)
 // cvtColor(COLOR_BGR2YUV_I420)  [imgproc/src/color.cpp:8745-8756, 9082-9160]: BT.601 fixed point (shift 20), chroma from
 // the top-left pixel of each 2x2 block, planar I420 output.  One lane = 2 rows x 4 pixels (12-byte row loads).
 __device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
-__global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst)
+constexpr int I420_BATCH = 64;
+__device__ __forceinline__ void bgr_to_i420_cell(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, int x, int y)
 {
-    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
-    if (x >= w || y >= h) return;
     constexpr int SH = 20, HALF = 1 << (SH - 1);
     constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
     uint8_t *Y = dst, *U = dst + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
@@ -601,6 +601,31 @@ __global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__
         if (n == 4 && (w & 3) == 0) *reinterpret_cast<unsigned *>(yd) = yq[r];
         else for (int k = 0; k < n; ++k) yd[k] = (uint8_t)(yq[r] >> (8 * k));
     }
+}
+__global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= w || y >= h) return;
+    bgr_to_i420_cell(src, sstep, w, h, dst, x, y);
+}
+// the same for up to I420_BATCH frames of one geometry in one launch (the egress of a batch of panoramas: one launch instead of one per frame)
+struct I420Batch { const uint8_t *src[I420_BATCH]; uint8_t *dst[I420_BATCH]; };
+__global__ void __launch_bounds__(256) k_bgr_to_i420_batch(I420Batch T, size_t sstep, int w, int h)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= w || y >= h) return;
+    bgr_to_i420_cell(T.src[blockIdx.z], sstep, w, h, T.dst[blockIdx.z], x, y);
+}
+int launch_bgr_to_i420_batch(const ms_image *src, ms_image *dst, int n, hipStream_t st)
+{
+    for (int i0 = 0; i0 < n; i0 += I420_BATCH) {
+        const int m = std::min(I420_BATCH, n - i0);
+        I420Batch T{};
+        for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
+        k_bgr_to_i420_batch<<<dim3(div_up(div_up(src[0].cols, 4), BX), div_up(src[0].rows / 2, BY), m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].cols, src[0].rows);
+        MS_LAUNCH_CHECK();
+    }
+    return MS_OK;
 }
 int launch_bgr_to_i420(const ms_image &src, ms_image &dst, hipStream_t st)
 {
