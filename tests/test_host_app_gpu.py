@@ -70,8 +70,8 @@ def test_host_app_solves_meshes_while_stitching(ms, cuda, tmp_path):
     (ms_create_mesh: triangle statistics + least-squares CG on its own stream) and swaps the meshes in, while the stitcher thread runs."""
     cfg = synth.CONFIGS["mini6"]
     info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
-                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 1500, "--solve-mesh")
-    assert info["frames"] == 1500 and info["cpw"] is True
-    assert info["recalibrations"] >= 2 and info["mesh_solver_iterations"] > info["recalibrations"] * 20
+                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 6000, "--solve-mesh")
+    assert info["frames"] == 6000 and info["cpw"] is True
+    assert info["recalibrations"] >= 1 and info["mesh_solver_iterations"] > info["recalibrations"] * 20
     got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
     assert (got.max(axis=2) > 0).mean() > 0.25

@@ -1161,6 +1161,165 @@ __global__ void __launch_bounds__(256) k_mesh_mean(float *sx, float *sy, const f
     sy[i] = sy[i] / cnt[i];
 }
 
+// custom_resize (APP/resize.cu:9-27) of one output element, the taps fetched through `at(row, col)`: the same expression tree as
+// k_custom_resize (prims.hip), so a fused consumer sees the bits the materialised map would hold
+// one axis of custom_resize: cell index i = x * (n - 1) / t (integer division) and fraction ((float)x * (float)(n - 1) / (float)t) - (float)i.
+// While t * (n - 1) < 2^23 the float quotient q is the correctly rounded value of an exact ratio whose distance to the next integer is at
+// least 1/t > ulp(q)/2, so (int)q IS the integer quotient and the ~40-instruction integer division disappears (`exact` says which case).
+__device__ __forceinline__ void resize_axis(int x, int n, int t, bool exact, int &i, float &frac)
+{
+    const float q = ((float)x) * (float)(n - 1) / (float)t;
+    i = exact ? (int)q : x * (n - 1) / t;
+    frac = q - (float)i;
+}
+__device__ __forceinline__ bool resize_axis_exact(int n, int t) { return (long long)t * (n - 1) < (1ll << 23); }
+template <class At>
+__device__ __forceinline__ float custom_resize_at(int tx, int ty, int cols, int rows, int x, int y, At at)
+{
+    int left, top;
+    float uu, vv;
+    resize_axis(x, cols, tx, resize_axis_exact(cols, tx), left, uu);
+    resize_axis(y, rows, ty, resize_axis_exact(rows, ty), top, vv);
+    float r = ((1.f - uu) * (1.f - vv)) * at(top, left);
+    r = __builtin_fmaf(uu * (1.f - vv), at(top, left + 1), r);
+    r = __builtin_fmaf((1.f - uu) * vv, at(top + 1, left), r);
+    r = __builtin_fmaf(uu * vv, at(top + 1, left + 1), r);
+    return r;
+}
+// convertMeshesToMap, first half in one launch (meshwarper.cpp:838-869): vertex mesh -> per-pixel forward position (custom_resize, not
+// materialised) -> scatter into the half-resolution sums.  Also clears what the previous update dirtied in the other accumulator
+// (ping-pong: no memset call between updates) and the displacement word of this update.
+constexpr int MESH_SR = 4;                         // rows per lane: a workgroup scatters a 64 x 16 pixel block
+constexpr int MESH_WW = 48, MESH_WH = 20, MESH_WMX = 6, MESH_WMY = 4;   // LDS window (half-resolution cells) around where the block's first pixel lands
+__global__ void __launch_bounds__(256) k_mesh_expand_scatter(const float *__restrict__ smx, const float *__restrict__ smy, int N, int M, int aw, int ah,
+                                                             unsigned long long *ax, unsigned long long *ay, int hw, int hh,
+                                                             unsigned long long *__restrict__ clear, size_t n_clear, unsigned *disp_word)
+{
+    // The pixels of a block land in a compact patch of the half-resolution grid (the mesh is a smooth deformation), and four of them share a
+    // cell: accumulate the patch in LDS and send one pair of global atomics per touched cell instead of one per pixel (device-scope atomics
+    // were 60 % of the update's GPU time); pixels landing outside the window go to memory directly.
+    __shared__ unsigned long long wx[MESH_WH * MESH_WW], wy[MESH_WH * MESH_WW];
+    const int lt = threadIdx.y * 64 + threadIdx.x;
+    const size_t tid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + lt, nthreads = (size_t)gridDim.x * gridDim.y * 256;
+    for (size_t k = tid; k < n_clear; k += nthreads) clear[k] = 0ull;
+    if (tid == 0) *disp_word = 0u;
+    for (int k = lt; k < MESH_WH * MESH_WW; k += 256) { wx[k] = 0ull; wy[k] = 0ull; }
+    const bool ex = resize_axis_exact(M, aw), ey = resize_axis_exact(N, ah);
+    auto forward = [&](int x, int y, float &fx, float &fy) {          // custom_resize of both vertex maps at (x, y): the expression tree of custom_resize_at
+        int left, top;
+        float uu, vv;
+        resize_axis(x, M, aw, ex, left, uu);
+        resize_axis(y, N, ah, ey, top, vv);
+        const float w00 = (1.f - uu) * (1.f - vv), w01 = uu * (1.f - vv), w10 = (1.f - uu) * vv, w11 = uu * vv;
+        const int i0 = top * M + left, i1 = i0 + M;
+        fx = w00 * smx[i0]; fy = w00 * smy[i0];
+        fx = __builtin_fmaf(w01, smx[i0 + 1], fx); fy = __builtin_fmaf(w01, smy[i0 + 1], fy);
+        fx = __builtin_fmaf(w10, smx[i1], fx);     fy = __builtin_fmaf(w10, smy[i1], fy);
+        fx = __builtin_fmaf(w11, smx[i1 + 1], fx); fy = __builtin_fmaf(w11, smy[i1 + 1], fy);
+    };
+    auto finite_i32 = [](float v) { return v > -2147483648.f && v < 2147483648.f; };
+    float ox, oy;
+    forward(blockIdx.x * 64, blockIdx.y * (4 * MESH_SR), ox, oy);          // the same for every lane: the window's anchor
+    const int wx0 = (finite_i32(ox) ? (int)ox / 2 : 0) - MESH_WMX, wy0 = (finite_i32(oy) ? (int)oy / 2 : 0) - MESH_WMY;
+    __syncthreads();
+    const int x = blockIdx.x * 64 + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < MESH_SR; ++r) {
+        const int y = blockIdx.y * (4 * MESH_SR) + r * 4 + threadIdx.y;
+        if (x >= aw || y >= ah) continue;
+        float fx, fy;
+        forward(x, y, fx, fy);
+        if (!(finite_i32(fx) && finite_i32(fy))) continue;
+        const int x_ = (int)fx / 2, y_ = (int)fy / 2;
+        if (x_ >= 0 && y_ >= 0 && x_ < hw && y_ < hh) {
+            // sum_x += x, sum_y += y, set_values++ as two 64-bit integer adds: [count : 24 | sum : 40].  The reference's float sums are integers,
+            // exact (and therefore order-independent) below 2^24, where (float)sum is the very same value
+            const unsigned long long vx = (1ull << 40) | (unsigned long long)x, vy = (unsigned long long)y;
+            const int cx = x_ - wx0, cy = y_ - wy0;
+            if ((unsigned)cx < (unsigned)MESH_WW && (unsigned)cy < (unsigned)MESH_WH) {
+                atomicAdd(&wx[cy * MESH_WW + cx], vx);
+                atomicAdd(&wy[cy * MESH_WW + cx], vy);
+            } else {
+                atomicAdd(&ax[(size_t)y_ * hw + x_], vx);
+                atomicAdd(&ay[(size_t)y_ * hw + x_], vy);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = lt; k < MESH_WH * MESH_WW; k += 256) {
+        const unsigned long long vx = wx[k];
+        if (vx == 0ull) continue;
+        const int cy = k / MESH_WW, cx = k - cy * MESH_WW;
+        const size_t g = (size_t)(wy0 + cy) * hw + (wx0 + cx);
+        atomicAdd(&ax[g], vx);
+        atomicAdd(&ay[g], wy[k]);
+    }
+}
+// second half (meshwarper.cpp:870-883): mean (0/0 -> NaN hole) + custom_resize back to the view size for both maps, and the largest
+// displacement of the new maps (see k_mesh_disp)
+constexpr int MESH_FW = 72, MESH_FH = 8;       // LDS footprint (cells) of a 64 x 4 output block: <= 64 * (hw - 1) / aw + 2 columns, likewise rows
+__global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long long *__restrict__ ax, const unsigned long long *__restrict__ ay, int hw, int hh,
+                                                          float *__restrict__ dx, float *__restrict__ dy, int pitch, int aw, int ah, unsigned *disp_word)
+{
+    __shared__ float mxs[MESH_FH][MESH_FW], mys[MESH_FH][MESH_FW];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const bool ex = resize_axis_exact(hw, aw), ey = resize_axis_exact(hh, ah);
+    // footprint of the block in the half-resolution maps
+    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4, bx1 = min(bx0 + 63, aw - 1), by1 = min(by0 + 3, ah - 1);
+    int c0, c1, r0, r1;
+    float t;
+    resize_axis(bx0, hw, aw, ex, c0, t); resize_axis(bx1, hw, aw, ex, c1, t);
+    resize_axis(by0, hh, ah, ey, r0, t); resize_axis(by1, hh, ah, ey, r1, t);
+    const int fw = c1 - c0 + 2, fh = r1 - r0 + 2;
+    const bool staged = fw <= MESH_FW && fh <= MESH_FH;             // (always for hw = aw / 2; the direct path keeps odd geometries correct)
+    constexpr unsigned long long SUM = (1ull << 40) - 1;
+    if (staged) {
+        for (int k = threadIdx.y * 64 + threadIdx.x; k < fw * fh; k += 256) {
+            const int rr = k / fw, cc = k - rr * fw, r = r0 + rr, c = c0 + cc;
+            float vx = 0.f, vy = 0.f;
+            if (r < hh && c < hw) {            // mean = sum / count; 0 / 0 -> NaN hole, as the reference (remap then yields 0)
+                const unsigned long long a = ax[(size_t)r * hw + c];
+                const float n = (float)(a >> 40);
+                vx = (float)(a & SUM) / n;
+                vy = (float)(ay[(size_t)r * hw + c] & SUM) / n;
+            }
+            mxs[rr][cc] = vx; mys[rr][cc] = vy;
+        }
+        __syncthreads();
+    }
+    float d = 0.f;
+    if (x < aw && y < ah) {
+        int left, top;
+        float uu, vv;
+        resize_axis(x, hw, aw, ex, left, uu);
+        resize_axis(y, hh, ah, ey, top, vv);
+        const float w00 = (1.f - uu) * (1.f - vv), w01 = uu * (1.f - vv), w10 = (1.f - uu) * vv, w11 = uu * vv;
+        float mx, my;
+        if (staged) {
+            const int cc = left - c0, rr = top - r0;
+            mx = w00 * mxs[rr][cc];                          my = w00 * mys[rr][cc];
+            mx = __builtin_fmaf(w01, mxs[rr][cc + 1], mx);   my = __builtin_fmaf(w01, mys[rr][cc + 1], my);
+            mx = __builtin_fmaf(w10, mxs[rr + 1][cc], mx);   my = __builtin_fmaf(w10, mys[rr + 1][cc], my);
+            mx = __builtin_fmaf(w11, mxs[rr + 1][cc + 1], mx); my = __builtin_fmaf(w11, mys[rr + 1][cc + 1], my);
+        } else {
+            mx = custom_resize_at(aw, ah, hw, hh, x, y, [&](int r, int c) { const unsigned long long v = ax[(size_t)r * hw + c]; return (float)(v & SUM) / (float)(v >> 40); });
+            my = custom_resize_at(aw, ah, hw, hh, x, y, [&](int r, int c) { return (float)(ay[(size_t)r * hw + c] & SUM) / (float)(ax[(size_t)r * hw + c] >> 40); });
+        }
+        dx[(size_t)y * pitch + x] = mx;
+        dy[(size_t)y * pitch + x] = my;
+        const float a = fabsf(mx - (float)x), b = fabsf(my - (float)y);
+        d = fmaxf(a == a ? a : 0.f, b == b ? b : 0.f);
+    }
+    for (int o = 32; o > 0; o >>= 1) d = fmaxf(d, __shfl_xor(d, o));
+    __shared__ float wmax[4];
+    if (threadIdx.x == 0) wmax[threadIdx.y] = d;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        d = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (d > 0.f) atomicMax(disp_word, __float_as_uint(d));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -1243,7 +1402,9 @@ struct ms_ctx {
     size_t mesh_off[MAX_VIEWS] = {};
     int mesh_active[MAX_VIEWS] = {};   // which buffer ms_stitch reads for this view
     bool mesh_set[MAX_VIEWS] = {};
-    DevBuf mesh_tmp;                   // scratch for convertMeshesToMap
+    DevBuf mesh_tmp;                   // scratch for convertMeshesToMap: vertex mesh x|y, two half-resolution accumulators ([count:24|sum_x:40], [sum_y]) used in turn
+    size_t mesh_small_cap = 0, mesh_half_cap = 0, mesh_dirty = 0;   // capacities (floats / cells); 64-bit words the previous update dirtied in its accumulator
+    int mesh_parity = 0;
     std::mutex mesh_mu;
     hipEvent_t last_stitch = nullptr;
     bool stitch_pending = false;
@@ -2080,8 +2241,7 @@ static int measure_mesh_disp(ms_ctx *c, int view, int tgt, hipStream_t st)
     MS_HIP(hipMemsetAsync(word, 0, sizeof(unsigned), st));
     k_mesh_disp<<<std::min(ah, 128), 256, 0, st>>>(base, base + (size_t)ah * c->map_pitch[view], c->map_pitch[view], ah, aw, word);
     MS_LAUNCH_CHECK();
-    MS_HIP(hipStreamSynchronize(st));
-    return MS_OK;
+    return MS_OK;          // (no host synchronisation: the stage-1 kernel reads the word on the device, ms_get_mesh_displacement waits on mesh_ready)
 }
 
 // ---- CPW mesh maps ------------------------------------------------------------------------------
@@ -2104,9 +2264,9 @@ static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st)
     if (c->mesh_chain_set) MS_HIP(hipStreamWaitEvent(st, c->mesh_chain, 0));
     return MS_OK;
 }
-static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st)
+static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st, bool measure = true)
 {
-    if (int e = measure_mesh_disp(c, view, tgt, st)) return e;
+    if (measure) if (int e = measure_mesh_disp(c, view, tgt, st)) return e;
     MS_HIP(hipEventRecord(c->mesh_ready[view], st));
     MS_HIP(hipEventRecord(c->mesh_chain, st));
     c->mesh_chain_set = true;
@@ -2142,12 +2302,16 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     hipStream_t st = as_stream(stream);
     const int aw = c->roi[view].width, ah = c->roi[view].height, hw = aw / 2, hh = ah / 2;
     MS_CHECK(hw >= 2 && hh >= 2, "ms_set_mesh: view too small");
-    // scratch: small mesh x|y, big x|y (ah x aw), half-res sum_x|sum_y|cnt
-    const size_t n_small = (size_t)N * M, n_big = (size_t)aw * ah, n_half = (size_t)hw * hh;
-    const size_t need = (2 * n_small + 2 * n_big + 3 * n_half) * sizeof(float);
-    if (c->mesh_tmp.bytes < need || c->mesh_stage_floats < 2 * n_small) {     // (re)allocation: first call or a larger mesh -- drain earlier updates first
+    // scratch: vertex mesh x|y, then two half-resolution accumulators used in turn (the launch that fills one clears the other)
+    const size_t n_small = (size_t)N * M, n_half = (size_t)hw * hh;
+    size_t half_cap = 0;
+    for (int v = 0; v < c->N; ++v) half_cap = std::max(half_cap, (size_t)(c->roi[v].width / 2) * (c->roi[v].height / 2));
+    if (!c->mesh_tmp.p || c->mesh_small_cap < n_small || c->mesh_half_cap < half_cap || c->mesh_stage_floats < 2 * n_small) {   // first call or a larger mesh: drain earlier updates
         if (c->mesh_chain_set) MS_HIP(hipEventSynchronize(c->mesh_chain));
-        if (c->mesh_tmp.bytes < need) if (int e = c->mesh_tmp.alloc(need)) return e;
+        const size_t bytes = 2 * n_small * sizeof(float) + 4 * half_cap * sizeof(unsigned long long) + 16;
+        if (int e = c->mesh_tmp.alloc(bytes)) return e;
+        MS_HIP(hipMemset(c->mesh_tmp.p, 0, bytes));
+        c->mesh_small_cap = n_small; c->mesh_half_cap = half_cap; c->mesh_dirty = 0; c->mesh_parity = 0;
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
             c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
@@ -2155,9 +2319,15 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
             c->mesh_stage_floats = 2 * n_small;
         }
     }
+    if (!c->disp_dev.p) {
+        if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
+        MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));      // "unbounded" until measured
+    }
     if (int e = mesh_begin_update(c, view, &tgt, st)) return e;
-    float *sm_x = (float *)c->mesh_tmp.p, *sm_y = sm_x + n_small, *big_x = sm_y + n_small, *big_y = big_x + n_big;
-    float *sx = big_y + n_big, *sy = sx + n_half, *cnt = sy + n_half;
+    float *sm_x = (float *)c->mesh_tmp.p, *sm_y = sm_x + n_small;
+    unsigned long long *acc0 = (unsigned long long *)(((uintptr_t)(sm_x + 2 * c->mesh_small_cap) + 7) & ~(uintptr_t)7);
+    unsigned long long *acc = acc0 + (size_t)c->mesh_parity * 2 * c->mesh_half_cap, *other = acc0 + (size_t)(1 - c->mesh_parity) * 2 * c->mesh_half_cap;
+    unsigned long long *ax = acc, *ay = acc + n_half;
     // the caller's arrays may be freed right after return: stage them in pinned memory (one slot per view; a slot is reused only by
     // the next update of the same view, whose copy of the previous one finished long before -- checked on its event)
     if (c->mesh_wait[view] || c->mesh_set[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
@@ -2165,20 +2335,16 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     memcpy(stg, mesh_x, n_small * 4);
     memcpy(stg + n_small, mesh_y, n_small * 4);
     MS_HIP(hipMemcpyAsync(sm_x, stg, 2 * n_small * 4, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemsetAsync(sx, 0, 3 * n_half * 4, st));
-    ms_image smx{sm_x, (size_t)M * 4, N, M, MS_32FC1}, smy{sm_y, (size_t)M * 4, N, M, MS_32FC1};
-    ms_image bx{big_x, (size_t)aw * 4, ah, aw, MS_32FC1}, by{big_y, (size_t)aw * 4, ah, aw, MS_32FC1};
-    if (int e = launch_custom_resize(smx, bx, st)) return e;            // meshwarper.cpp:838-839
-    if (int e = launch_custom_resize(smy, by, st)) return e;
-    k_mesh_scatter<<<dim3(div_up(aw, 64), div_up(ah, 4)), dim3(64, 4), 0, st>>>(big_x, big_y, aw, ah, aw, sx, sy, cnt, hw, hh);   // :859-869
+    unsigned *word = (unsigned *)c->disp_dev.p + 2 * view + tgt;
+    const dim3 grid(div_up(aw, 64), div_up(ah, 4)), blk(64, 4);
+    k_mesh_expand_scatter<<<dim3(div_up(aw, 64), div_up(ah, 4 * MESH_SR)), blk, 0, st>>>(sm_x, sm_y, N, M, aw, ah, ax, ay, hw, hh, other, c->mesh_dirty, word);        // meshwarper.cpp:838-869
     MS_LAUNCH_CHECK();
-    k_mesh_mean<<<div_up((int)n_half, 256), 256, 0, st>>>(sx, sy, cnt, (int)n_half);                                          // :870-875
-    MS_LAUNCH_CHECK();
-    ms_image hx{sx, (size_t)hw * 4, hh, hw, MS_32FC1}, hy{sy, (size_t)hw * 4, hh, hw, MS_32FC1};
     ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
-    if (int e = launch_custom_resize(hx, dx, st)) return e;             // :880,883
-    if (int e = launch_custom_resize(hy, dy, st)) return e;
-    return mesh_end_update(c, view, tgt, st);
+    k_mesh_mean_resize<<<grid, blk, 0, st>>>(ax, ay, hw, hh, (float *)dx.data, (float *)dy.data, c->map_pitch[view], aw, ah, word);   // :870-883
+    MS_LAUNCH_CHECK();
+    c->mesh_dirty = 2 * n_half;
+    c->mesh_parity ^= 1;
+    return mesh_end_update(c, view, tgt, st, false);
 }
 
 // MeshWarper::interpolateMesh (meshwarper.cpp:337-354) + convertMeshesToMap: the RECALIB_INTERP branch of the recalibration thread
@@ -2226,6 +2392,7 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
     std::lock_guard<std::mutex> lk(c->mesh_mu);
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view] || !c->disp_dev.p) return fail(MS_ERR_STATE, "ms_get_mesh_displacement: no mesh set for view %d", view);
     MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     MS_HIP(hipMemcpy(out_px, (const unsigned *)c->disp_dev.p + 2 * view + c->mesh_active[view], sizeof(float), hipMemcpyDeviceToHost));
     return MS_OK;
 }
