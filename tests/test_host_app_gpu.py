@@ -69,9 +69,12 @@ def test_host_app_solves_meshes_while_stitching(ms, cuda, tmp_path):
     """--solve-mesh: the recalibration thread uploads the current frames, remaps them, runs msshim::MeshWarper::calibrateMeshWarp
     (ms_create_mesh: triangle statistics + least-squares CG on its own stream) and swaps the meshes in, while the stitcher thread runs."""
     cfg = synth.CONFIGS["mini6"]
-    info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
-                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 6000, "--solve-mesh")
-    assert info["frames"] == 6000 and info["cpw"] is True
-    assert info["recalibrations"] >= 1 and info["mesh_solver_iterations"] > info["recalibrations"] * 20
-    got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
-    assert (got.max(axis=2) > 0).mean() > 0.25
+    for attempt in range(4):       # the scenario that exposed the stream-ordered allocator losing a solve's upload about once in 30 solves
+        info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
+                             "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 6000, "--solve-mesh")
+        assert info["frames"] == 6000 and info["cpw"] is True
+        # every solve must do real work: a lost upload shows as a solve that "converges" in 0 iterations (and a black panorama)
+        assert info["recalibrations"] >= 1 and info["mesh_solver_iterations"] > info["recalibrations"] * 300, info
+        assert 1.0 < info["max_mesh_displacement_px"] < 20.0
+        got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
+        assert (got.max(axis=2) > 0).mean() > 0.25

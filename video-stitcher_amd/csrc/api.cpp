@@ -24,6 +24,9 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+PinnedScratch &pinned_scratch() { static thread_local PinnedScratch s; return s; }
+DeviceScratch &device_scratch() { static thread_local DeviceScratch s; return s; }
+
 int require_device()
 {
     int n = 0;

@@ -26,6 +26,46 @@ int require_device();
 
 #define MS_LAUNCH_CHECK() MS_HIP(hipGetLastError())
 
+// Per-thread pinned staging memory for the entry points that move host arrays while other threads use the device (the recalibration
+// thread's mesh solve): copies from pinned memory are asynchronous for real and never go through the runtime's shared staging buffers.
+// Grows on demand, lives as long as the thread's library use (deliberately not freed at exit: the runtime may already be gone).
+struct PinnedScratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t n)
+    {
+        if (n > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = (n + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+            cap = want;
+        }
+        return p;
+    }
+};
+PinnedScratch &pinned_scratch();
+// Per-thread device scratch for the same entry points: a grow-only hipMalloc block.  NOT the stream-ordered allocator: with hipMallocAsync /
+// hipFreeAsync, while a second thread was uploading frames and synchronising on events, one mesh solve in ~30 found its freshly uploaded
+// block zeroed or stale (ROCm 7.2; the pool trims on every synchronisation) -- reproduced 5 runs in 25 with stitch_app --solve-mesh, 0 in 55
+// with this block (tests/test_host_app_gpu.py runs the scenario).
+struct DeviceScratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t n)
+    {
+        if (n > cap) {
+            if (p) (void)hipFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = (n + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return nullptr; }
+            cap = want;
+        }
+        return p;
+    }
+};
+DeviceScratch &device_scratch();
+
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(ms_stream s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1259,59 +1259,65 @@ __global__ void __launch_bounds__(256) k_mesh_expand_scatter(const float *__rest
 // displacement of the new maps (see k_mesh_disp)
 constexpr int MESH_FW = 72, MESH_FH = 8;       // LDS footprint (cells) of a 64 x 4 output block: <= 64 * (hw - 1) / aw + 2 columns, likewise rows
 __global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long long *__restrict__ ax, const unsigned long long *__restrict__ ay, int hw, int hh,
-                                                          float *__restrict__ dx, float *__restrict__ dy, int pitch, int aw, int ah, unsigned *disp_word)
+                                                          float *__restrict__ dx, float *__restrict__ dy, int pitch, int aw, int ah, int tiles_x, int n_tiles, unsigned *disp_word)
 {
     __shared__ float mxs[MESH_FH][MESH_FW], mys[MESH_FH][MESH_FW];
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    __shared__ float wmax[4];
     const bool ex = resize_axis_exact(hw, aw), ey = resize_axis_exact(hh, ah);
-    // footprint of the block in the half-resolution maps
-    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4, bx1 = min(bx0 + 63, aw - 1), by1 = min(by0 + 3, ah - 1);
-    int c0, c1, r0, r1;
-    float t;
-    resize_axis(bx0, hw, aw, ex, c0, t); resize_axis(bx1, hw, aw, ex, c1, t);
-    resize_axis(by0, hh, ah, ey, r0, t); resize_axis(by1, hh, ah, ey, r1, t);
-    const int fw = c1 - c0 + 2, fh = r1 - r0 + 2;
-    const bool staged = fw <= MESH_FW && fh <= MESH_FH;             // (always for hw = aw / 2; the direct path keeps odd geometries correct)
     constexpr unsigned long long SUM = (1ull << 40) - 1;
-    if (staged) {
-        for (int k = threadIdx.y * 64 + threadIdx.x; k < fw * fh; k += 256) {
-            const int rr = k / fw, cc = k - rr * fw, r = r0 + rr, c = c0 + cc;
-            float vx = 0.f, vy = 0.f;
-            if (r < hh && c < hw) {            // mean = sum / count; 0 / 0 -> NaN hole, as the reference (remap then yields 0)
-                const unsigned long long a = ax[(size_t)r * hw + c];
-                const float n = (float)(a >> 40);
-                vx = (float)(a & SUM) / n;
-                vy = (float)(ay[(size_t)r * hw + c] & SUM) / n;
-            }
-            mxs[rr][cc] = vx; mys[rr][cc] = vy;
-        }
-        __syncthreads();
-    }
     float d = 0.f;
-    if (x < aw && y < ah) {
-        int left, top;
-        float uu, vv;
-        resize_axis(x, hw, aw, ex, left, uu);
-        resize_axis(y, hh, ah, ey, top, vv);
-        const float w00 = (1.f - uu) * (1.f - vv), w01 = uu * (1.f - vv), w10 = (1.f - uu) * vv, w11 = uu * vv;
-        float mx, my;
+    // a workgroup walks 64 x 4 output tiles grid-stride: one atomic on the displacement word per workgroup, not per tile (thousands of
+    // same-address atomics serialise: they were most of this kernel's time)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int x = txi * 64 + threadIdx.x, y = tyi * 4 + threadIdx.y;
+        // footprint of the tile in the half-resolution maps
+        const int bx0 = txi * 64, by0 = tyi * 4, bx1 = min(bx0 + 63, aw - 1), by1 = min(by0 + 3, ah - 1);
+        int c0, c1, r0, r1;
+        float t;
+        resize_axis(bx0, hw, aw, ex, c0, t); resize_axis(bx1, hw, aw, ex, c1, t);
+        resize_axis(by0, hh, ah, ey, r0, t); resize_axis(by1, hh, ah, ey, r1, t);
+        const int fw = c1 - c0 + 2, fh = r1 - r0 + 2;
+        const bool staged = fw <= MESH_FW && fh <= MESH_FH;             // (always for hw = aw / 2; the direct path keeps odd geometries correct)
         if (staged) {
-            const int cc = left - c0, rr = top - r0;
-            mx = w00 * mxs[rr][cc];                          my = w00 * mys[rr][cc];
-            mx = __builtin_fmaf(w01, mxs[rr][cc + 1], mx);   my = __builtin_fmaf(w01, mys[rr][cc + 1], my);
-            mx = __builtin_fmaf(w10, mxs[rr + 1][cc], mx);   my = __builtin_fmaf(w10, mys[rr + 1][cc], my);
-            mx = __builtin_fmaf(w11, mxs[rr + 1][cc + 1], mx); my = __builtin_fmaf(w11, mys[rr + 1][cc + 1], my);
-        } else {
-            mx = custom_resize_at(aw, ah, hw, hh, x, y, [&](int r, int c) { const unsigned long long v = ax[(size_t)r * hw + c]; return (float)(v & SUM) / (float)(v >> 40); });
-            my = custom_resize_at(aw, ah, hw, hh, x, y, [&](int r, int c) { return (float)(ay[(size_t)r * hw + c] & SUM) / (float)(ax[(size_t)r * hw + c] >> 40); });
+            for (int k = threadIdx.y * 64 + threadIdx.x; k < fw * fh; k += 256) {
+                const int rr = k / fw, cc = k - rr * fw, r = r0 + rr, c = c0 + cc;
+                float vx = 0.f, vy = 0.f;
+                if (r < hh && c < hw) {            // mean = sum / count; 0 / 0 -> NaN hole, as the reference (remap then yields 0)
+                    const unsigned long long a = ax[(size_t)r * hw + c];
+                    const float n = (float)(a >> 40);
+                    vx = (float)(a & SUM) / n;
+                    vy = (float)(ay[(size_t)r * hw + c] & SUM) / n;
+                }
+                mxs[rr][cc] = vx; mys[rr][cc] = vy;
+            }
+            __syncthreads();
         }
-        dx[(size_t)y * pitch + x] = mx;
-        dy[(size_t)y * pitch + x] = my;
-        const float a = fabsf(mx - (float)x), b = fabsf(my - (float)y);
-        d = fmaxf(a == a ? a : 0.f, b == b ? b : 0.f);
+        if (x < aw && y < ah) {
+            int left, top;
+            float uu, vv;
+            resize_axis(x, hw, aw, ex, left, uu);
+            resize_axis(y, hh, ah, ey, top, vv);
+            const float w00 = (1.f - uu) * (1.f - vv), w01 = uu * (1.f - vv), w10 = (1.f - uu) * vv, w11 = uu * vv;
+            float mx, my;
+            if (staged) {
+                const int cc = left - c0, rr = top - r0;
+                mx = w00 * mxs[rr][cc];                            my = w00 * mys[rr][cc];
+                mx = __builtin_fmaf(w01, mxs[rr][cc + 1], mx);     my = __builtin_fmaf(w01, mys[rr][cc + 1], my);
+                mx = __builtin_fmaf(w10, mxs[rr + 1][cc], mx);     my = __builtin_fmaf(w10, mys[rr + 1][cc], my);
+                mx = __builtin_fmaf(w11, mxs[rr + 1][cc + 1], mx); my = __builtin_fmaf(w11, mys[rr + 1][cc + 1], my);
+            } else {
+                mx = custom_resize_at(aw, ah, hw, hh, x, y, [&](int r, int c) { const unsigned long long v = ax[(size_t)r * hw + c]; return (float)(v & SUM) / (float)(v >> 40); });
+                my = custom_resize_at(aw, ah, hw, hh, x, y, [&](int r, int c) { return (float)(ay[(size_t)r * hw + c] & SUM) / (float)(ax[(size_t)r * hw + c] >> 40); });
+            }
+            dx[(size_t)y * pitch + x] = mx;
+            dy[(size_t)y * pitch + x] = my;
+            const float a = fabsf(mx - (float)x), b = fabsf(my - (float)y);
+            d = fmaxf(d, fmaxf(a == a ? a : 0.f, b == b ? b : 0.f));
+        }
+        __syncthreads();                                                 // the staging arrays are rewritten by the next tile
     }
     for (int o = 32; o > 0; o >>= 1) d = fmaxf(d, __shfl_xor(d, o));
-    __shared__ float wmax[4];
     if (threadIdx.x == 0) wmax[threadIdx.y] = d;
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) {
@@ -2340,7 +2346,8 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     k_mesh_expand_scatter<<<dim3(div_up(aw, 64), div_up(ah, 4 * MESH_SR)), blk, 0, st>>>(sm_x, sm_y, N, M, aw, ah, ax, ay, hw, hh, other, c->mesh_dirty, word);        // meshwarper.cpp:838-869
     MS_LAUNCH_CHECK();
     ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
-    k_mesh_mean_resize<<<grid, blk, 0, st>>>(ax, ay, hw, hh, (float *)dx.data, (float *)dy.data, c->map_pitch[view], aw, ah, word);   // :870-883
+    const int tiles_x = div_up(aw, 64), n_tiles = tiles_x * div_up(ah, 4);
+    k_mesh_mean_resize<<<std::min(n_tiles, 1024), blk, 0, st>>>(ax, ay, hw, hh, (float *)dx.data, (float *)dy.data, c->map_pitch[view], aw, ah, tiles_x, n_tiles, word);   // :870-883
     MS_LAUNCH_CHECK();
     c->mesh_dirty = 2 * n_half;
     c->mesh_parity ^= 1;
@@ -2391,9 +2398,11 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
     MS_CHECK(out_px != nullptr, "ms_get_mesh_displacement: null output");
     std::lock_guard<std::mutex> lk(c->mesh_mu);
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view] || !c->disp_dev.p) return fail(MS_ERR_STATE, "ms_get_mesh_displacement: no mesh set for view %d", view);
-    MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
-    MS_HIP(hipMemcpy(out_px, (const unsigned *)c->disp_dev.p + 2 * view + c->mesh_active[view], sizeof(float), hipMemcpyDeviceToHost));
+    float *h = (float *)pinned_scratch().get(sizeof(float));          // pinned landing zone: see PinnedScratch (common.hpp)
+    if (!h) return fail(MS_ERR_NOMEM, "ms_get_mesh_displacement: no pinned staging memory");
+    MS_HIP(hipMemcpy(h, (const unsigned *)c->disp_dev.p + 2 * view + c->mesh_active[view], sizeof(float), hipMemcpyDeviceToHost));
+    *out_px = *h;
     return MS_OK;
 }
 

@@ -66,23 +66,22 @@ extern "C" int ms_knn_match_hamming2(const ms_image *query, const ms_image *trai
     if (nq == 0) return MS_OK;
     MS_CHECK(query->data && (nt == 0 || train->data), "ms_knn_match_hamming2: null descriptors");
     hipStream_t st = as_stream(stream);
-    int4 *out = nullptr;
-    MS_HIP(hipMallocAsync((void **)&out, (size_t)nq * sizeof(int4), st));
+    int4 *out = (int4 *)device_scratch().get((size_t)nq * sizeof(int4));      // per-thread grow-only block: see DeviceScratch (common.hpp)
+    if (!out) return fail(MS_ERR_NOMEM, "ms_knn_match_hamming2: cannot allocate device scratch");
     const int words = query->cols / 4;
     if (words == 8)          // ORB / BRIEF-32
         k_hamming_knn2<8><<<div_up(nq, 4), 256, 0, st>>>((const uint8_t *)query->data, query->step, nq, (const uint8_t *)train->data, train->step, nt, words, out);
     else
         k_hamming_knn2<0><<<div_up(nq, 4), 256, 0, st>>>((const uint8_t *)query->data, query->step, nq, (const uint8_t *)train->data, train->step, nt, words, out);
     hipError_t le = hipGetLastError();
-    std::vector<int4> h;
+    int4 *h = (int4 *)pinned_scratch().get((size_t)nq * sizeof(int4));
     hipError_t ce = hipSuccess;
-    if (le == hipSuccess) {
-        h.resize(nq);
-        ce = hipMemcpyAsync(h.data(), out, (size_t)nq * sizeof(int4), hipMemcpyDeviceToHost, st);
+    if (le == hipSuccess && h) {
+        ce = hipMemcpyAsync(h, out, (size_t)nq * sizeof(int4), hipMemcpyDeviceToHost, st);
         if (ce == hipSuccess) ce = hipStreamSynchronize(st);
     }
-    (void)hipFreeAsync(out, st);
     MS_HIP(le);
+    if (!h) return fail(MS_ERR_NOMEM, "ms_knn_match_hamming2: cannot allocate pinned staging memory");
     MS_HIP(ce);
     for (int q = 0; q < nq; ++q) {        // batchDistance clamps K to the number of train rows: missing neighbours are index -1, distance INT_MAX
         train_idx_host[2 * q] = h[q].x; distance_host[2 * q] = h[q].y;

@@ -20,14 +20,6 @@
 namespace ms {
 namespace {
 
-struct Buf {                                    // stream-ordered device buffer (no device-wide synchronisation: the stitcher keeps running)
-    void *p = nullptr;
-    hipStream_t st = nullptr;
-    ~Buf() { if (p) (void)hipFreeAsync(p, st); }
-    int alloc(size_t n, hipStream_t s) { st = s; MS_HIP(hipMallocAsync(&p, n ? n : 16, s)); return MS_OK; }
-    template <class T> T *as() const { return (T *)p; }
-};
-
 // ------------------------------------------------------------------------------------------------ cv::fillConvexPoly, 3 points
 // drawing.cpp:1109-1271 (line_type 8, shift 0): the polygon outline with Line() (8-connected Bresenham of LineIterator :165-252 with
 // left_to_right, clipped by clipLine :97-148), then the scan conversion with 16.16 fixed-point edges.
@@ -151,6 +143,13 @@ void triangle_mask(int t, float cell_w, float cell_h, std::vector<uint8_t> &mask
     fill_convex3(mask, mw, mh, v);
 }
 
+// moves between the per-thread pinned staging block and the per-thread device scratch (see PinnedScratch / DeviceScratch in common.hpp)
+int copy_async(const void *src, void *dst, size_t bytes, hipStream_t st)
+{
+    if (bytes) MS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+    return MS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device: triangle statistics
 struct TriJob { int x, y, t; };
 
@@ -208,21 +207,25 @@ int view_saliency(const ms_image &im, int M, int N, std::vector<float> &sal, hip
                 slot[((size_t)i * M + j) * 8 + t] = (int)jobs.size();
                 jobs.push_back(jb);
             }
-    Buf dmask, djobs, dout;
-    if (int e = dmask.alloc(masks.size(), st)) return e;
-    if (int e = djobs.alloc(jobs.size() * sizeof(TriJob), st)) return e;
-    if (int e = dout.alloc(jobs.size() * 6 * sizeof(unsigned long long), st)) return e;
-    MS_HIP(hipMemcpyAsync(dmask.p, masks.data(), masks.size(), hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(TriJob), hipMemcpyHostToDevice, st));
-    k_tri_stats<<<(unsigned)jobs.size(), 64, 0, st>>>((const uint8_t *)im.data, im.step, dmask.as<uint8_t>(), mw, mh, djobs.as<TriJob>(), dout.as<unsigned long long>());
+    // one pinned block: masks | jobs (up) and the sums (down); one device block of the same layout
+    const size_t off_jobs = (masks.size() + 15) & ~(size_t)15, off_sums = off_jobs + ((jobs.size() * sizeof(TriJob) + 15) & ~(size_t)15);
+    const size_t total = off_sums + ((jobs.size() * 6 * sizeof(unsigned long long) + 15) & ~(size_t)15);
+    uint8_t *host = (uint8_t *)pinned_scratch().get(total);
+    if (!host) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of pinned staging memory", total);
+    memcpy(host, masks.data(), masks.size());
+    memcpy(host + off_jobs, jobs.data(), jobs.size() * sizeof(TriJob));
+    uint8_t *dev = (uint8_t *)device_scratch().get(total);
+    if (!dev) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of device scratch", total);
+    if (int e = copy_async(host, dev, off_sums, st)) return e;
+    k_tri_stats<<<(unsigned)jobs.size(), 64, 0, st>>>((const uint8_t *)im.data, im.step, dev, mw, mh, (const TriJob *)(dev + off_jobs), (unsigned long long *)(dev + off_sums));
     MS_LAUNCH_CHECK();
-    std::vector<unsigned long long> sums(jobs.size() * 6);
-    MS_HIP(hipMemcpyAsync(sums.data(), dout.p, sums.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (int e = copy_async(dev + off_sums, host + off_sums, (total - off_sums + 15) & ~(size_t)15, st)) return e;
     MS_HIP(hipStreamSynchronize(st));
+    const unsigned long long *sums = (const unsigned long long *)(host + off_sums);
     sal.assign((size_t)N * M * 8, NAN);
     for (size_t k = 0; k < slot.size(); ++k) {
         if (slot[k] < 0) continue;
-        const unsigned long long *o = &sums[(size_t)slot[k] * 6];
+        const unsigned long long *o = sums + (size_t)slot[k] * 6;
         const int cnt = nz[jobs[slot[k]].t];
         const double scale = cnt ? 1. / cnt : 0.;                                      // cv::meanStdDev, stat.cpp:1939-1943
         double nrm = 0;
@@ -516,9 +519,19 @@ int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vecto
 {
     const int R = S.rows, n = S.cols;
     const size_t nnz = S.e.size();
+    // Everything the device needs is laid out in ONE pinned block (PinnedScratch) and moved with one copy into the thread's device scratch:
+    //   doubles: eval[8R] | cval[nnz] | invdiag[n] | b[R] | state      ints: ecol[8R] | crow[nnz] | cptr[n+1]      then the landing zone: state | x[n]
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_eval = 0, o_cval = o_eval + al((size_t)ELL_W * R * 8), o_inv = o_cval + al(nnz * 8), o_b = o_inv + al((size_t)n * 8), o_state = o_b + al((size_t)R * 8);
+    const size_t o_ecol = o_state + al(sizeof(LscgState)), o_crow = o_ecol + al((size_t)ELL_W * R * 4), o_cptr = o_crow + al(nnz * 4), up_bytes = o_cptr + al((size_t)(n + 1) * 4);
+    const size_t o_hstate = up_bytes, o_hx = o_hstate + al(sizeof(LscgState)), host_bytes = o_hx + al((size_t)n * 8);
+    uint8_t *host = (uint8_t *)pinned_scratch().get(host_bytes);
+    if (!host) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of pinned staging memory", host_bytes);
+    memset(host, 0, up_bytes);
+    double *eval = (double *)(host + o_eval), *cval = (double *)(host + o_cval), *invdiag = (double *)(host + o_inv);
+    int *ecol = (int *)(host + o_ecol), *crow = (int *)(host + o_crow), *cptr = (int *)(host + o_cptr);
     // rows: ELL (column-major slabs, padded with 0 * p[0]); entries of a row ordered by column as a column-major SpMV visits them
-    std::vector<int> ecol((size_t)ELL_W * R, 0), fill(R, 0);
-    std::vector<double> eval((size_t)ELL_W * R, 0.0);
+    std::vector<int> fill(R, 0);
     std::vector<Entry> byrow(S.e);
     std::stable_sort(byrow.begin(), byrow.end(), [](const Entry &a, const Entry &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
     for (const Entry &e : byrow) {
@@ -528,79 +541,62 @@ int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vecto
         fill[e.row]++;
     }
     // columns: CSC with rows ascending; Jacobi preconditioner 1 / ||A_col||^2 (1 for an empty column)
-    std::vector<int> cptr(n + 1, 0), crow(nnz);
-    std::vector<double> cval(nnz), invdiag(n, 1.0);
     for (const Entry &e : byrow) cptr[e.col + 1]++;
     for (int j = 0; j < n; ++j) cptr[j + 1] += cptr[j];
     {
-        std::vector<int> pos(cptr.begin(), cptr.end() - 1);
+        std::vector<int> pos(cptr, cptr + n);
         for (const Entry &e : byrow) { crow[pos[e.col]] = e.row; cval[pos[e.col]] = e.val; pos[e.col]++; }
     }
     for (int j = 0; j < n; ++j) {
-        double s = 0;
-        for (int k = cptr[j]; k < cptr[j + 1]; ++k) s += cval[k] * cval[k];
-        if (s > 0) invdiag[j] = 1.0 / s;
+        double sq = 0;
+        for (int k = cptr[j]; k < cptr[j + 1]; ++k) sq += cval[k] * cval[k];
+        invdiag[j] = sq > 0 ? 1.0 / sq : 1.0;
     }
-    Buf d_ecol, d_eval, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, d_x, d_p, d_state, d_p1, d_p3;
-    if (int e = d_ecol.alloc(ecol.size() * 4, st)) return e;
-    if (int e = d_eval.alloc(eval.size() * 8, st)) return e;
-    if (int e = d_cptr.alloc(cptr.size() * 4, st)) return e;
-    if (int e = d_crow.alloc(nnz * 4, st)) return e;
-    if (int e = d_cval.alloc(nnz * 8, st)) return e;
-    if (int e = d_inv.alloc((size_t)n * 8, st)) return e;
-    if (int e = d_res.alloc((size_t)R * 8, st)) return e;
-    if (int e = d_tmp.alloc((size_t)R * 8, st)) return e;
-    if (int e = d_z.alloc((size_t)n * 8, st)) return e;
-    if (int e = d_x.alloc((size_t)n * 8, st)) return e;
-    if (int e = d_p.alloc((size_t)n * 8, st)) return e;
-    if (int e = d_state.alloc(sizeof(LscgState), st)) return e;
-    if (int e = d_p1.alloc(LSCG_PARTS * 8, st)) return e;
-    if (int e = d_p3.alloc(LSCG_PARTS * 16, st)) return e;
-    MS_HIP(hipMemcpyAsync(d_ecol.p, ecol.data(), ecol.size() * 4, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(d_eval.p, eval.data(), eval.size() * 8, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(d_cptr.p, cptr.data(), cptr.size() * 4, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(d_crow.p, crow.data(), nnz * 4, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(d_cval.p, cval.data(), nnz * 8, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(d_inv.p, invdiag.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-    MS_HIP(hipMemcpyAsync(d_res.p, S.b.data(), (size_t)R * 8, hipMemcpyHostToDevice, st));     // residual = b - A 0
-    MS_HIP(hipMemsetAsync(d_tmp.p, 0, (size_t)R * 8, st));
-    MS_HIP(hipMemsetAsync(d_x.p, 0, (size_t)n * 8, st));
-    MS_HIP(hipMemsetAsync(d_p.p, 0, (size_t)n * 8, st));
-    LscgState init_state{};
-    init_state.pending = init_state.done = -1;
-    MS_HIP(hipMemcpyAsync(d_state.p, &init_state, sizeof init_state, hipMemcpyHostToDevice, st));
+    memcpy(host + o_b, S.b.data(), (size_t)R * 8);                       // residual = b - A 0
+    LscgState *init_state = (LscgState *)(host + o_state);
+    init_state->pending = init_state->done = -1;
+    // device: the uploaded block, then the work vectors tmp[R] | x[n] | p[n] (zero) | z[n] | part1 | part3
+    const size_t w_tmp = 0, w_x = w_tmp + al((size_t)R * 8), w_p = w_x + al((size_t)n * 8), w_z = w_p + al((size_t)n * 8), w_p1 = w_z + al((size_t)n * 8),
+                 w_p3 = w_p1 + al(LSCG_PARTS * 8), work_bytes = w_p3 + al(LSCG_PARTS * 16);
+    uint8_t *U = (uint8_t *)device_scratch().get(up_bytes + work_bytes);
+    if (!U) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of device scratch", up_bytes + work_bytes);
+    uint8_t *W = U + up_bytes;
+    if (int e = copy_async(host, U, up_bytes, st)) return e;
+    MS_HIP(hipMemsetAsync(W, 0, w_z, st));
+    const int *d_ecol = (const int *)(U + o_ecol), *d_crow = (const int *)(U + o_crow), *d_cptr = (const int *)(U + o_cptr);
+    const double *d_eval = (const double *)(U + o_eval), *d_cval = (const double *)(U + o_cval), *d_inv = (const double *)(U + o_inv);
+    double *d_res = (double *)(U + o_b), *d_tmp = (double *)(W + w_tmp), *d_x = (double *)(W + w_x), *d_p = (double *)(W + w_p), *d_z = (double *)(W + w_z);
+    double *d_p1 = (double *)(W + w_p1), *d_p3 = (double *)(W + w_p3);
+    LscgState *ds = (LscgState *)(U + o_state);
 
     const double tol = tolerance > 0 ? tolerance : DBL_EPSILON;
     const int max_it = max_iterations > 0 ? max_iterations : 2 * n;
     const int g_rows = std::min(LSCG_PARTS, div_up(R, 256)), g_cols = std::min(LSCG_PARTS, div_up(n * 16, 256)), g_upd = div_up(n, 256);
-    LscgState *ds = d_state.as<LscgState>();
     // prologue: normal residual of x0 = 0, rhsNorm2, threshold, p = z
-    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, -1, 1, 0, d_cptr.as<int>(), d_crow.as<int>(), d_cval.as<double>(), d_inv.as<double>(), d_res.as<double>(),
-                                        d_tmp.as<double>(), d_z.as<double>(), ds, d_p1.as<double>(), d_p3.as<double>());
-    k_lscg_update<<<g_upd, 256, 0, st>>>(n, -1, 1, g_cols, tol, d_z.as<double>(), d_x.as<double>(), d_p.as<double>(), ds, d_p3.as<double>());
+    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, -1, 1, 0, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
+    k_lscg_update<<<g_upd, 256, 0, st>>>(n, -1, 1, g_cols, tol, d_z, d_x, d_p, ds, d_p3);
     MS_LAUNCH_CHECK();
-    LscgState hs{};
+    LscgState *hs = (LscgState *)(host + o_hstate);
     int it = 0;
     for (; it < max_it; ++it) {
-        k_lscg_rows<<<g_rows, 256, 0, st>>>(R, d_ecol.as<int>(), d_eval.as<double>(), d_p.as<double>(), d_res.as<double>(), d_tmp.as<double>(), ds, d_p1.as<double>());
-        k_lscg_cols<<<g_cols, 256, 0, st>>>(n, it, 0, g_rows, d_cptr.as<int>(), d_crow.as<int>(), d_cval.as<double>(), d_inv.as<double>(), d_res.as<double>(),
-                                            d_tmp.as<double>(), d_z.as<double>(), ds, d_p1.as<double>(), d_p3.as<double>());
-        k_lscg_update<<<g_upd, 256, 0, st>>>(n, it, 0, g_cols, tol, d_z.as<double>(), d_x.as<double>(), d_p.as<double>(), ds, d_p3.as<double>());
+        k_lscg_rows<<<g_rows, 256, 0, st>>>(R, d_ecol, d_eval, d_p, d_res, d_tmp, ds, d_p1);
+        k_lscg_cols<<<g_cols, 256, 0, st>>>(n, it, 0, g_rows, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
+        k_lscg_update<<<g_upd, 256, 0, st>>>(n, it, 0, g_cols, tol, d_z, d_x, d_p, ds, d_p3);
         if ((it & 63) == 63) {                  // the kernels of a finished solve return at once; look at the flag now and then
-            MS_HIP(hipMemcpyAsync(&hs, ds, sizeof hs, hipMemcpyDeviceToHost, st));
+            if (int e = copy_async(ds, hs, al(sizeof(LscgState)), st)) return e;
             MS_HIP(hipStreamSynchronize(st));
-            if (hs.pending != -1) break;
+            if (hs->pending != -1) break;
         }
     }
     MS_LAUNCH_CHECK();
-    MS_HIP(hipMemcpyAsync(&hs, ds, sizeof hs, hipMemcpyDeviceToHost, st));
-    x.resize(n);
-    MS_HIP(hipMemcpyAsync(x.data(), d_x.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    if (int e = copy_async(ds, hs, al(sizeof(LscgState)), st)) return e;
+    if (int e = copy_async(d_x, host + o_hx, al((size_t)n * 8), st)) return e;
     MS_HIP(hipStreamSynchronize(st));
+    x.assign((const double *)(host + o_hx), (const double *)(host + o_hx) + n);
     if (info) {
         info->rows = R; info->cols = n; info->nnz = (int)nnz;
-        info->iterations = hs.pending >= 0 ? hs.pending : hs.pending == -2 ? 0 : max_it;
-        info->error = hs.rhs_norm2 > 0 ? std::sqrt(hs.res_norm2 / hs.rhs_norm2) : 0.0;
+        info->iterations = hs->pending >= 0 ? hs->pending : hs->pending == -2 ? 0 : max_it;
+        info->error = hs->rhs_norm2 > 0 ? std::sqrt(hs->res_norm2 / hs->rhs_norm2) : 0.0;
     }
     return MS_OK;
 }

@@ -242,6 +242,7 @@ int main(int argc, char **argv)
         std::thread recalibrater;
         std::atomic<int> recalibrations{0};
         std::atomic<int> solver_iterations{0};
+        std::atomic<float> max_disp{0.f};
         std::string recal_failure;
         if (o.solve_mesh)
             // recalibrateMesh (meshwarper.cpp:378-386) with the mesh actually solved: upload the current frames on the recalibration stream,
@@ -255,6 +256,7 @@ int main(int argc, char **argv)
                     struct Matches { int src_img_idx, dst_img_idx; std::vector<DMatch> matches; std::vector<unsigned char> inliers_mask; int num_inliers; };
                     msshim::MeshWarper mw(o.views, 10, 10, warp_scale, 1.0, 1.0);
                     mw.params().theta_rule = 1;
+                    mw.params().global_dist = std::max(4, std::min(30, o.out_w / 128));    // GLOBAL_DIST = 30 is tuned to 1080p views; scaled for small rigs
                     std::vector<DevMat> recal_full(o.views), images(o.views);
                     std::vector<ms_view_geom> g(o.views);
                     for (int i = 0; i < o.views; ++i) {
@@ -302,6 +304,15 @@ int main(int argc, char **argv)
                         }
                         const ms_mesh_info info = mw.calibrateMeshWarp(comp, images, feats, pairwise, (ms_stream)recal_stream);
                         solver_iterations += info.iterations;
+                        if (getenv("STITCH_APP_TRACE")) {
+                            size_t nm = 0; for (auto &pm : pairwise) nm += pm.matches.size();
+                            fprintf(stderr, "round %d: matches %zu rows %d nnz %d iterations %d error %.3g\n", round, nm, info.rows, info.nnz, info.iterations, info.error);
+                        }
+                        for (int i = 0; i < o.views; ++i) {
+                            float dpx = 0.f;
+                            msshim::check(ms_get_mesh_displacement(comp.raw(), i, &dpx));
+                            if (dpx > max_disp.load()) max_disp.store(dpx);
+                        }
                         ++round; ++recalibrations;
                     }
                 } catch (const std::exception &e) { recal_failure = e.what(); }
@@ -367,9 +378,9 @@ int main(int argc, char **argv)
             fclose(f);
         }
         printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"upload\": %s, "
-               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"checksum\": \"%016llx\"}\n",
+               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"max_mesh_displacement_px\": %.2f, \"checksum\": \"%016llx\"}\n",
                o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.upload ? "true" : "false",
-               consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), checksum);
+               consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), (double)max_disp.load(), checksum);
     } catch (const msshim::Error &e) {
         fprintf(stderr, "stitch_app: msstitch error %d: %s\n", e.code, e.what());
         return 1;
