@@ -55,7 +55,7 @@ def test_fill_convex_poly_known_small_cases():
     assert mo.fill_convex_poly(3, 5, [(-5, -5), (30, -5), (-5, 30)]).all()
 
 
-def rig(n=3, w=90, h=60, seed=0):
+def rig(n=3, w=90, h=60, seed=0):   # n = 1: no matches (there is no other view)
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:h, 0:w]
     images = []
@@ -67,7 +67,7 @@ def rig(n=3, w=90, h=60, seed=0):
     for v in range(n):
         dst = (v + 1) % n
         pts = []
-        for _ in range(12):
+        for _ in range(12 if n > 1 else 0):
             x1, y1 = rng.uniform(w * 0.8, w - 1), rng.uniform(4, h - 4)
             pts.append((x1, y1, x1 - w * 0.7 + rng.normal(0, 1.5), y1 + rng.normal(0, 1.0), dst))
         matches.append(pts)

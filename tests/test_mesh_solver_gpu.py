@@ -167,3 +167,34 @@ def test_solved_mesh_drives_the_compositor(ms, cuda, oracle):
     b.close()
     assert np.array_equal(host(out16), ref16)
     comp.close()
+
+
+@pytest.mark.parametrize("case", ["single_view_temporal", "mesh_2x2", "border_matches", "mesh_40x40"])
+def test_create_mesh_edge_cases(ms, cuda, case):
+    rng = np.random.default_rng(11)
+    if case == "single_view_temporal":
+        images, _ = rig(n=1, seed=8)
+        matches = [[]]
+        temporal = [[(x, y, x + 1.5, y - 0.5) for x, y in zip(rng.uniform(5, 85, 15), rng.uniform(5, 55, 15))]]
+        kw = dict(M=6, N=5, alphas=(1.0, 0.01, 0.00005, 0.5))
+    elif case == "mesh_2x2":
+        images, matches = rig(n=2, seed=9)
+        temporal, kw = None, dict(M=2, N=2, alphas=mo.DEFAULT_ALPHAS)
+    elif case == "border_matches":
+        images, matches = rig(n=3, seed=10)
+        h, w = images[0].shape[:2]
+        # points on the image border, outside it (ignored, meshwarper.cpp:641-644) and on the last mesh line, where float rounding can put the cell index at M - 1
+        matches[0] += [(0.0, 0.0, 0.0, 0.0, 1), (w - 1e-3, h - 1e-3, w - 1e-3, h - 1e-3, 1), (-1.0, 5.0, 3.0, 5.0, 1), (3.0, 5.0, float(w), 5.0, 1),
+                       (np.nextafter(np.float32(w), np.float32(0)), 10.0, 20.0, 10.0, 1)]
+        temporal, kw = None, dict(M=6, N=5, alphas=mo.DEFAULT_ALPHAS)
+    else:
+        images, matches = rig(n=2, seed=12, w=333, h=207)
+        temporal, kw = None, dict(M=40, N=40, alphas=mo.DEFAULT_ALPHAS)
+    n = len(images)
+    prm = ms.mesh_default_params(mesh_cols=kw["M"], mesh_rows=kw["N"], focal_length=60.0, theta_rule=1, global_dist=8, alphas=kw["alphas"])
+    mx, my, info = ms.create_mesh([to_dev(im) for im in images], matches, prm, temporal=temporal)
+    rx, ry, rinfo = mo.create_mesh(images, matches, kw["M"], kw["N"], alphas=kw["alphas"], focal=60.0, global_dist=8, temporal=temporal,
+                                   theta_fn=lambda s, d: mo.generic_theta(s, d, n))
+    assert (info["rows"], info["cols"], info["nnz"]) == (rinfo["rows"], rinfo["cols"], rinfo["nnz"])
+    assert np.abs(mx - rx).max() < 1e-3 and np.abs(my - ry).max() < 1e-3, (np.abs(mx - rx).max(), np.abs(my - ry).max())
+    assert abs(info["iterations"] - rinfo["iterations"]) <= max(3, rinfo["iterations"] // 50)

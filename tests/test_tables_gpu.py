@@ -289,3 +289,54 @@ def test_seam_scale_calibration_pipeline(ms, cuda, oracle, dilate):
     ref16, refmask = b.blend()
     assert np.array_equal(host(out16), ref16) and np.array_equal(host(comp.result_mask()), refmask)
     b.close(); comp.close()
+
+
+@pytest.mark.parametrize("kind", ["wild", "folded", "collapsed", "shifted_out", "nan_vertices", "huge"])
+def test_mesh_to_map_adversarial_meshes(ms, cuda, oracle, kind):
+    """The two-launch expansion (LDS-aggregated integer scatter with a global fallback, fused mean / resize / displacement) on meshes that
+    leave its fast paths: displacements far beyond the LDS window, folds, every pixel landing in one cell (counts far above any window,
+    sums beyond 2^24 where the reference's float sums stop being exact), pixels scattered out of the view, NaN / Inf vertices.  Maps must
+    equal the oracle's convertMeshesToMap wherever the reference itself is order-independent, the reported displacement must equal the maps'."""
+    comp, cfg, _ = make_rig(ms, "cfg2" if kind == "huge" else "mini6", enable_cpw=True)
+    rng = np.random.default_rng(len(kind))
+    views = (3,) if kind == "huge" else (0, 3, 5)
+    for i in views:
+        r = comp.view_geom(i).roi
+        N, M = (9, 11) if kind != "huge" else (40, 40)
+        mx, my = synth.mesh(r.width, r.height, N, M, phase=0.3 * i, amp=3.0)
+        if kind == "wild":
+            mx = mx + rng.uniform(-90, 90, mx.shape).astype(np.float32); my = my + rng.uniform(-60, 60, my.shape).astype(np.float32)
+        elif kind == "folded":
+            mx = mx[:, ::-1].copy(); my = my[::-1].copy()                    # mirrored: every pixel lands far from where it starts
+        elif kind == "collapsed":
+            mx[:] = np.float32(r.width / 2 + 0.5); my[:] = np.float32(r.height / 2 + 0.5)
+        elif kind == "shifted_out":
+            mx = mx + np.float32(r.width * 0.8); my = my - np.float32(r.height * 0.6)
+        elif kind == "nan_vertices":
+            mx[2, 3] = np.nan; my[4, 5] = np.inf; mx[6, 7] = -np.inf; mx[1, 1] = 1e30
+        elif kind == "huge":
+            mx = mx + (40 * np.sin(np.arange(M) / 3.0)[None, :]).astype(np.float32)
+        mx = np.ascontiguousarray(mx, np.float32); my = np.ascontiguousarray(my, np.float32)
+        comp.set_mesh(i, mx, my)
+        gx, gy = [host(t) for t in comp.mesh_maps(i)]
+        rx, ry = oracle.convert_mesh_to_map(mx, my, r.width, r.height)
+        if kind == "collapsed":
+            # one cell receives every pixel: the reference's float sum is no longer exact there (order-dependent), ours is the exact sum;
+            # everything else is a hole on both sides and the one mean agrees to float accuracy
+            assert np.array_equal(np.isnan(gx), np.isnan(rx)) and np.array_equal(np.isnan(gy), np.isnan(ry))
+            ok = ~np.isnan(rx)
+            assert np.allclose(gx[ok], rx[ok], rtol=1e-3) and np.allclose(gy[~np.isnan(ry)], ry[~np.isnan(ry)], rtol=1e-3)
+        else:
+            assert np.array_equal(gx, rx, equal_nan=True) and np.array_equal(gy, ry, equal_nan=True)
+        yy, xx = np.mgrid[0:r.height, 0:r.width].astype(np.float32)
+        with np.errstate(invalid="ignore"):
+            d = np.fmax(np.abs(gx - xx), np.abs(gy - yy))
+        want = np.float32(np.nanmax(d)) if np.isfinite(d).any() else np.float32(0)
+        assert comp.mesh_displacement(i) == want
+        # a second, ordinary update right after must not see anything the adversarial one left in the accumulators
+        sx, sy = synth.mesh(r.width, r.height, 10, 10, phase=0.9, amp=4.0)
+        comp.set_mesh(i, sx, sy)
+        g2 = [host(t) for t in comp.mesh_maps(i)]
+        r2 = oracle.convert_mesh_to_map(sx, sy, r.width, r.height)
+        assert np.array_equal(g2[0], r2[0], equal_nan=True) and np.array_equal(g2[1], r2[1], equal_nan=True)
+    comp.close()
