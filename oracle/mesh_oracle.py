@@ -286,6 +286,8 @@ def local_term(S, matches, sizes, idx, alpha, focal, compose_scale, work_scale, 
         x1, y1, x2, y2 = F(x1), F(y1), F(x2), F(y2)
         if x1 < 0 or x2 < 0 or y1 < 0 or y2 < 0 or x1 >= w1 or x2 >= w2 or y1 >= h1 or y2 >= h2:
             continue
+        if not np.isfinite([x1, y1, x2, y2]).all():
+            continue        # NaN passes the reference's range test and is undefined behaviour there; skipped (stated deviation)
         t1, l1, u1, v1 = _cell(x1, y1, w1, h1, M, N)
         t2, l2, u2, v2 = _cell(x2, y2, w2, h2, M, N)
         if l1 + 1 >= M or l2 + 1 >= M or t1 + 1 >= N or t2 + 1 >= N:
@@ -313,6 +315,8 @@ def temporal_term(S, matches, sizes, idx, alpha):
     for m in matches:
         x1, y1, x2, y2 = F(m[0]), F(m[1]), F(m[2]), F(m[3])
         if x1 < 0 or x2 < 0 or y1 < 0 or y2 < 0 or x1 >= w or x2 >= w or y1 >= h or y2 >= h:
+            continue
+        if not np.isfinite([x1, y1, x2, y2]).all():
             continue
         t1, l1, u1, v1 = _cell(x1, y1, w, h, M, N)
         if l1 + 1 >= M or t1 + 1 >= N:
@@ -389,7 +393,7 @@ def assemble(images, matches, M, N, alphas=DEFAULT_ALPHAS, global_dist=DEFAULT_G
     S = System(n, M, N)
     for idx in range(n):
         local_term(S, matches[idx], sizes, idx, alphas[0], focal, compose_scale, work_scale, theta_fn)
-        pts = [(cv_round(m[0]), cv_round(m[1])) for m in matches[idx]]
+        pts = [(cv_round(m[0]), cv_round(m[1])) for m in matches[idx] if np.isfinite(m[0]) and np.isfinite(m[1]) and abs(m[0]) < 1e9 and abs(m[1]) < 1e9]
         global_term(S, pts, sizes[idx], idx, alphas[1], global_dist)
         smoothness_term(S, saliency(images[idx], M, N) if sal is None else sal[idx], sizes[idx], idx, alphas[2])
         if alphas[3] != 0.0 and temporal is not None:

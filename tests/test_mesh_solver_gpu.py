@@ -185,7 +185,7 @@ def test_create_mesh_edge_cases(ms, cuda, case):
         h, w = images[0].shape[:2]
         # points on the image border, outside it (ignored, meshwarper.cpp:641-644) and on the last mesh line, where float rounding can put the cell index at M - 1
         matches[0] += [(0.0, 0.0, 0.0, 0.0, 1), (w - 1e-3, h - 1e-3, w - 1e-3, h - 1e-3, 1), (-1.0, 5.0, 3.0, 5.0, 1), (3.0, 5.0, float(w), 5.0, 1),
-                       (np.nextafter(np.float32(w), np.float32(0)), 10.0, 20.0, 10.0, 1)]
+                       (np.nextafter(np.float32(w), np.float32(0)), 10.0, 20.0, 10.0, 1), (float("nan"), 5.0, 3.0, 5.0, 1), (4.0, 5.0, 3.0, float("inf"), 1)]
         temporal, kw = None, dict(M=6, N=5, alphas=mo.DEFAULT_ALPHAS)
     else:
         images, matches = rig(n=2, seed=12, w=333, h=207)

@@ -13,6 +13,7 @@
 //   host    triangle masks (cv::fillConvexPoly restated), coefficient arithmetic in the reference's float expressions, CSR/CSC layout.
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <vector>
 #include "common.hpp"
@@ -311,6 +312,7 @@ void local_term(LinSys &S, const ms_mesh_match *m, int count, const ms_image *vi
         const float w1 = (float)views[idx].cols, h1 = (float)views[idx].rows, w2 = (float)views[dst].cols, h2 = (float)views[dst].rows;
         const float x1 = m[k].x1, y1 = m[k].y1, x2 = m[k].x2, y2 = m[k].y2;
         if (x1 < 0 || x2 < 0 || y1 < 0 || y2 < 0 || x1 >= w1 || x2 >= w2 || y1 >= h1 || y2 >= h2) continue;
+        if (!(std::isfinite(x1) && std::isfinite(y1) && std::isfinite(x2) && std::isfinite(y2))) continue;      // NaN passes the reference's range test (undefined there)
         const Cell c1 = locate(x1, y1, w1, h1, M, N), c2 = locate(x2, y2, w2, h2, M, N);
         // float rounding can put a point on the last mesh line; the reference would index past the mesh row there (undefined) -- skipped
         if (c1.l + 1 >= M || c2.l + 1 >= M || c1.t + 1 >= N || c2.t + 1 >= N) continue;
@@ -332,6 +334,7 @@ void temporal_term(LinSys &S, const ms_mesh_match *m, int count, const ms_image 
     for (int k = 0; k < count; ++k) {
         const float x1 = m[k].x1, y1 = m[k].y1, x2 = m[k].x2, y2 = m[k].y2;
         if (x1 < 0 || x2 < 0 || y1 < 0 || y2 < 0 || x1 >= w || x2 >= w || y1 >= h || y2 >= h) continue;
+        if (!(std::isfinite(x1) && std::isfinite(y1) && std::isfinite(x2) && std::isfinite(y2))) continue;
         const Cell c = locate(x1, y1, w, h, M, N);
         if (c.l + 1 >= M || c.t + 1 >= N) continue;
         for (int r = 0; r < 2; ++r) put_bilinear(S, r, M * N * idx, c, a, false);
@@ -345,7 +348,11 @@ void global_term(LinSys &S, const ms_mesh_match *m, int count, const ms_image &v
     const int M = S.M, N = S.N;
     const float a = std::sqrt(P.alphas[1]);
     std::vector<int> px(count), py(count);
-    for (int k = 0; k < count; ++k) { px[k] = (int)std::nearbyint((double)m[k].x1); py[k] = (int)std::nearbyint((double)m[k].y1); }
+    for (int k = 0; k < count; ++k) {
+        const bool ok = std::isfinite(m[k].x1) && std::isfinite(m[k].y1) && std::fabs(m[k].x1) < 1e9f && std::fabs(m[k].y1) < 1e9f;
+        px[k] = ok ? (int)std::nearbyint((double)m[k].x1) : INT_MIN / 2;        // (a point that far away never zeroes a tau)
+        py[k] = ok ? (int)std::nearbyint((double)m[k].y1) : INT_MIN / 2;
+    }
     int col = N * M * 2 * idx;
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < M; ++j) {
