@@ -154,6 +154,9 @@ MS_API int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream stream);
  * RGB888toYUV420pInvoker (OCV/imgproc/src/color.cpp:9082-9160).  src 8UC3 with even width/height; dst contiguous
  * 8UC1 of (rows*3/2) x cols = planar I420.  Also what bench.py gathers across GPUs (half the bytes of BGR). */
 MS_API int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream stream);
+/* cuda::cvtColor(gpu_img, gpu_img, CV_BGR2GRAY) of featurefinder::findFeatures (APP/featurefinder.cpp:34) -> RGB2GrayConvert
+ * (OCV/core/include/opencv2/core/cuda/detail/color_detail.hpp:97-101, :444-447): (b * 1868 + g * 9617 + r * 4899 + 2^13) >> 14. */
+MS_API int ms_bgr_to_gray(const ms_image *src, ms_image *dst, ms_stream stream);
 /* The same conversion for n frames of one geometry (same size and step) in one launch: the egress of a batch of panoramas. */
 MS_API int ms_bgr_to_i420_batch(const ms_image *src, ms_image *dst, int n, ms_stream stream);
 

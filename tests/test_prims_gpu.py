@@ -295,3 +295,15 @@ def test_bgr_to_i420_batch_equals_single_calls(ms, cuda):
         assert np.array_equal(host(d), host(ms.bgr_to_i420(s)))
     with pytest.raises(ms.MsError):
         ms.bgr_to_i420_batch_prepared([srcs[0], srcs[1][:44]], dsts[:2])()
+
+
+def test_bgr_to_gray(ms, cuda):
+    """cuda::cvtColor(BGR2GRAY) (color_detail.hpp:444-447): exact integer arithmetic, every size / pitch path."""
+    rng = np.random.default_rng(5)
+    for h, w in ((37, 64), (20, 61), (3, 2), (1, 1)):
+        src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = ((src[..., 0].astype(np.uint32) * 1868 + src[..., 1].astype(np.uint32) * 9617 + src[..., 2].astype(np.uint32) * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+        assert np.array_equal(host(ms.bgr_to_gray(to_dev(src))), want)
+        assert np.array_equal(host(ms.bgr_to_gray(to_dev_roi(src, rng))), want)
+    white = np.full((2, 8, 3), 255, np.uint8)
+    assert (host(ms.bgr_to_gray(to_dev(white))) == 255).all()

@@ -226,6 +226,14 @@ int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream s)
     return launch_bgr_to_i420(*src, *dst, as_stream(s));
 }
 
+int ms_bgr_to_gray(const ms_image *src, ms_image *dst, ms_stream s)
+{
+    PRE() IMG(src, "ms_bgr_to_gray src") IMG(dst, "ms_bgr_to_gray dst")
+    MS_CHECK(src->type == MS_8UC3 && dst->type == MS_8UC1, "ms_bgr_to_gray: 8UC3 -> 8UC1");
+    SAME(src, dst, "ms_bgr_to_gray")
+    return launch_bgr_to_gray(*src, *dst, as_stream(s));
+}
+
 int ms_bgr_to_i420_batch(const ms_image *src, ms_image *dst, int n, ms_stream s)
 {
     PRE()

@@ -570,6 +570,35 @@ int launch_nv12_to_bgr(const ms_image &src, ms_image &dst, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------
+// cuda::cvtColor(BGR2GRAY) of featurefinder::findFeatures (APP/featurefinder.cpp:34) -> RGB2GrayConvert<bidx = 0>
+// (core/include/opencv2/core/cuda/detail/color_detail.hpp:97-101, :444-447): CV_DESCALE(b * 1868 + g * 9617 + r * 4899, 14).
+// One lane = 4 pixels (12-byte load, one dword store).
+__global__ void __launch_bounds__(256) k_bgr_to_gray(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = blockIdx.y * BY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *p = row_ptr<uint8_t>(src, sstep, y) + (size_t)x * 3;
+    uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + x;
+    const int n = min(4, w - x);
+    uint8_t px[12];
+    if (n == 4 && ((sstep | (size_t)src) & 3) == 0) __builtin_memcpy(px, __builtin_assume_aligned(p, 4), 12);
+    else for (int i = 0; i < 3 * n; ++i) px[i] = p[i];
+    unsigned q = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < n) q |= (((unsigned)px[3 * k] * 1868u + (unsigned)px[3 * k + 1] * 9617u + (unsigned)px[3 * k + 2] * 4899u + (1u << 13)) >> 14) << (8 * k);
+    if (n == 4 && ((dstep | (size_t)dst) & 3) == 0) *reinterpret_cast<unsigned *>(d) = q;
+    else for (int k = 0; k < n; ++k) d[k] = (uint8_t)(q >> (8 * k));
+}
+int launch_bgr_to_gray(const ms_image &src, ms_image &dst, hipStream_t st)
+{
+    k_bgr_to_gray<<<dim3(div_up(div_up(src.cols, 4), BX), div_up(src.rows, BY)), dim3(BX, BY), 0, st>>>(
+        (const uint8_t *)src.data, src.step, src.cols, src.rows, (uint8_t *)dst.data, dst.step);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // cvtColor(COLOR_BGR2YUV_I420)  [imgproc/src/color.cpp:8745-8756, 9082-9160]: BT.601 fixed point (shift 20), chroma from
 // the top-left pixel of each 2x2 block, planar I420 output.  One lane = 2 rows x 4 pixels (12-byte row loads).
 __device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t)min(max(v, 0), 255); }

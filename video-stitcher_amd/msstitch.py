@@ -76,7 +76,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray",
 ]
 
 _lib = None
@@ -308,6 +308,12 @@ def bgr_to_i420(src, dst=None):
     if dst is None:
         dst = _new((src.shape[0] * 3 // 2, src.shape[1]), _torch().uint8)
     _chk(load().ms_bgr_to_i420(C.byref(img(src)), C.byref(img(dst)), _stream()))
+    return dst
+
+
+def bgr_to_gray(src):
+    dst = _new(tuple(src.shape[:2]), _torch().uint8)
+    _chk(load().ms_bgr_to_gray(C.byref(img(src)), C.byref(img(dst)), _stream()))
     return dst
 
 
