@@ -1,0 +1,40 @@
+"""bench.py's contract on a real GPU: one JSON line with the required keys at N = 1, and the N > 1 control flow (ownership, I420 egress,
+double-buffered gather, max-over-ranks timing) exercised with two ranks sharing the one GPU over gloo (MS_BENCH_SHARE_GPU=1: a debug mode,
+not a scaling measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_line_has_the_contract_keys():
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 1000 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "workload" in d["config"]
+
+
+def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
+    env = dict(os.environ, MS_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "gather" in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
