@@ -30,8 +30,11 @@ def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, ban
         meshes = []
         for i in range(n):
             r = comp.view_geom(i).roi
-            comp.set_mesh(i, *synth.mesh(r.width, r.height, 6, 7, phase=0.4 * i, amp=float(rng.uniform(0.5, 5.0))))
+            mesh = synth.mesh(r.width, r.height, int(rng.integers(3, 13)), int(rng.integers(3, 13)), phase=0.4 * i, amp=float(rng.uniform(0.5, 12.0)))
+            comp.set_mesh(i, *mesh)
             meshes.append(tuple(host(m) for m in comp.mesh_maps(i)))
+            want = oracle.convert_mesh_to_map(mesh[0], mesh[1], r.width, r.height)       # convertMeshesToMap, bit for bit (NaN holes included)
+            assert np.array_equal(meshes[-1][0], want[0], equal_nan=True) and np.array_equal(meshes[-1][1], want[1], equal_nan=True)
     frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
     pg = comp.pano_geom()
     out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
