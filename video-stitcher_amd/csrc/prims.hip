@@ -631,35 +631,70 @@ __device__ __forceinline__ void bgr_to_i420_cell(const uint8_t *__restrict__ src
         else for (int k = 0; k < n; ++k) yd[k] = (uint8_t)(yq[r] >> (8 * k));
     }
 }
-__global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst)
+// 2 rows x 8 pixels per lane when the geometry allows (width a multiple of 8, 4-byte aligned rows): two 24-byte row loads, the luma rows as
+// two 8-byte stores and the four chroma samples of each plane as one dword store -- no byte stores (the 4-pixel cell writes chroma bytewise)
+__device__ __forceinline__ void bgr_to_i420_cell8(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, int x, int y)
 {
-    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    constexpr int SH = 20, HALF = 1 << (SH - 1);
+    constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+    uint8_t *Y = dst, *U = dst + (size_t)w * h, *V = U + (size_t)(w / 2) * (h / 2);
+    unsigned uq = 0, vq = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        uint8_t px[24];
+        __builtin_memcpy(px, __builtin_assume_aligned(row_ptr<uint8_t>(src, sstep, y + r) + (size_t)x * 3, 4), 24);
+        unsigned yq[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = px[3 * k], g = px[3 * k + 1], rr = px[3 * k + 2];
+            yq[k >> 2] |= (unsigned)clamp_u8((CRY * rr + CGY * g + CBY * b + HALF + (16 << SH)) >> SH) << (8 * (k & 3));
+            if (r == 0 && (k & 1) == 0) {
+                uq |= (unsigned)clamp_u8((CRU * rr + CGU * g + CBU * b + HALF + (128 << SH)) >> SH) << (8 * (k >> 1));
+                vq |= (unsigned)clamp_u8((CBU * rr + CGV * g + CBV * b + HALF + (128 << SH)) >> SH) << (8 * (k >> 1));
+            }
+        }
+        *reinterpret_cast<uint2 *>(Y + (size_t)(y + r) * w + x) = make_uint2(yq[0], yq[1]);
+    }
+    *reinterpret_cast<unsigned *>(U + (size_t)(y / 2) * (w / 2) + x / 2) = uq;
+    *reinterpret_cast<unsigned *>(V + (size_t)(y / 2) * (w / 2) + x / 2) = vq;
+}
+__global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, int wide)
+{
+    const int x = (wide ? 8 : 4) * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
     if (x >= w || y >= h) return;
-    bgr_to_i420_cell(src, sstep, w, h, dst, x, y);
+    if (wide) bgr_to_i420_cell8(src, sstep, w, h, dst, x, y);
+    else bgr_to_i420_cell(src, sstep, w, h, dst, x, y);
 }
 // the same for up to I420_BATCH frames of one geometry in one launch (the egress of a batch of panoramas: one launch instead of one per frame)
 struct I420Batch { const uint8_t *src[I420_BATCH]; uint8_t *dst[I420_BATCH]; };
-__global__ void __launch_bounds__(256) k_bgr_to_i420_batch(I420Batch T, size_t sstep, int w, int h)
+__global__ void __launch_bounds__(256) k_bgr_to_i420_batch(I420Batch T, size_t sstep, int w, int h, int wide)
 {
-    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    const int x = (wide ? 8 : 4) * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
     if (x >= w || y >= h) return;
-    bgr_to_i420_cell(T.src[blockIdx.z], sstep, w, h, T.dst[blockIdx.z], x, y);
+    if (wide) bgr_to_i420_cell8(T.src[blockIdx.z], sstep, w, h, T.dst[blockIdx.z], x, y);
+    else bgr_to_i420_cell(T.src[blockIdx.z], sstep, w, h, T.dst[blockIdx.z], x, y);
 }
 int launch_bgr_to_i420_batch(const ms_image *src, ms_image *dst, int n, hipStream_t st)
 {
     for (int i0 = 0; i0 < n; i0 += I420_BATCH) {
         const int m = std::min(I420_BATCH, n - i0);
         I420Batch T{};
-        for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
-        k_bgr_to_i420_batch<<<dim3(div_up(div_up(src[0].cols, 4), BX), div_up(src[0].rows / 2, BY), m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].cols, src[0].rows);
+        bool wide = (src[0].cols & 7) == 0 && (src[0].step & 3) == 0 && (((size_t)src[0].cols * src[0].rows) & 7) == 0 && (((size_t)(src[0].cols / 2) * (src[0].rows / 2)) & 3) == 0;
+        for (int i = 0; i < m; ++i) {
+            T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data;
+            wide = wide && ((size_t)T.src[i] & 3) == 0 && ((size_t)T.dst[i] & 7) == 0;
+        }
+        k_bgr_to_i420_batch<<<dim3(div_up(div_up(src[0].cols, wide ? 8 : 4), BX), div_up(src[0].rows / 2, BY), m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].cols, src[0].rows, wide ? 1 : 0);
         MS_LAUNCH_CHECK();
     }
     return MS_OK;
 }
 int launch_bgr_to_i420(const ms_image &src, ms_image &dst, hipStream_t st)
 {
-    k_bgr_to_i420<<<dim3(div_up(div_up(src.cols, 4), BX), div_up(src.rows / 2, BY)), dim3(BX, BY), 0, st>>>(
-        (const uint8_t *)src.data, src.step, src.cols, src.rows, (uint8_t *)dst.data);
+    const bool wide = (src.cols & 7) == 0 && ((src.step | (size_t)src.data) & 3) == 0 && ((size_t)dst.data & 7) == 0 &&
+                      (((size_t)src.cols * src.rows) & 7) == 0 && (((size_t)(src.cols / 2) * (src.rows / 2)) & 3) == 0;      // plane offsets keep the vector stores aligned
+    k_bgr_to_i420<<<dim3(div_up(div_up(src.cols, wide ? 8 : 4), BX), div_up(src.rows / 2, BY)), dim3(BX, BY), 0, st>>>(
+        (const uint8_t *)src.data, src.step, src.cols, src.rows, (uint8_t *)dst.data, wide ? 1 : 0);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
