@@ -2308,6 +2308,7 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     hipStream_t st = as_stream(stream);
     const int aw = c->roi[view].width, ah = c->roi[view].height, hw = aw / 2, hh = ah / 2;
     MS_CHECK(hw >= 2 && hh >= 2, "ms_set_mesh: view too small");
+    MS_CHECK((long long)aw * ah < (1ll << 24) && aw < 65536 && ah < 65536, "ms_set_mesh: view %dx%d exceeds the scatter accumulators ([count:24 | sum:40])", aw, ah);
     // scratch: vertex mesh x|y, then two half-resolution accumulators used in turn (the launch that fills one clears the other)
     const size_t n_small = (size_t)N * M, n_half = (size_t)hw * hh;
     size_t half_cap = 0;
