@@ -5,9 +5,8 @@
 //
 // Split of the work:
 //   device  k_tri_stats     masked sum / sum of squares of every (vertex, triangle) cell crop -- the only pass over pixels
-//           k_lscg_rows     tmp = A p           (ELL, one thread per row; deferred residual update folded in)
+//           k_lscg_step     tail of iteration i - 1 (beta, x += alpha p, p = z + beta p) + head of iteration i (tmp = A p, ELL, one thread per row)
 //           k_lscg_cols     A^T residual, z     (CSC, 16 lanes per column)
-//           k_lscg_update   x += alpha p ; p = z + beta p
 //           all fp64; every reduction is a fixed-order tree over per-block partials (<= LSCG_PARTS blocks), re-summed by each consumer
 //           block, so the solve is run-to-run reproducible and needs no in-launch hand-off between workgroups.
 //   host    triangle masks (cv::fillConvexPoly restated), coefficient arithmetic in the reference's float expressions, CSR/CSC layout.
@@ -405,10 +404,10 @@ constexpr int ELL_W = 8;                        // no row of the system has more
 
 struct LscgState {                              // written only by workgroup 0 of the kernel named, read by later kernels
     double alpha;                               // k_lscg_cols
-    double abs_new[2];                          // k_lscg_update, by iteration parity (the other slot is abs_old)
-    double rhs_norm2, res_norm2, threshold;     // k_lscg_update
-    int pending;                                // k_lscg_update: -1 running, >= 0 converged in that iteration, -2 zero right-hand side
-    int done;                                   // k_lscg_rows copies `pending` here: the flag k_lscg_update itself may read while it writes `pending`
+    double abs_new[2];                          // k_lscg_step, by iteration parity (the other slot is abs_old)
+    double rhs_norm2, res_norm2, threshold;     // k_lscg_step
+    int pending;                                // k_lscg_step: -1 running, >= 0 converged in that iteration, -2 zero right-hand side
+    int done;                                   // k_lscg_cols copies `pending` here: the flag k_lscg_step itself may read while it writes `pending`
 };
 
 __device__ double block_sum_impl(double v, double *lds)     // fixed-order tree over the 256 threads
@@ -436,25 +435,59 @@ __device__ double sum_parts(const double *__restrict__ part, int stride, int n, 
 
 __device__ double block_sum(double v, double *lds) { return block_sum_impl(v, lds); }
 
-// residual -= alpha_prev * tmp_prev (deferred from the previous iteration); tmp = A p; part1[block] = sum tmp^2
-__global__ void __launch_bounds__(256) k_lscg_rows(int R, const int *__restrict__ ecol, const double *__restrict__ eval, const double *__restrict__ p,
-                                                   double *__restrict__ residual, double *__restrict__ tmp, LscgState *__restrict__ S, double *__restrict__ part1)
+// One launch = the tail of iteration iter - 1 and the head of iteration iter (two launches per iteration instead of three):
+//   tail: residualNorm2 = sum nr.nr -> converged?  beta = abs_new / abs_old;  x += alpha p;  p' = z + beta p   (p' into the other p buffer)
+//   head: residual -= alpha tmp (deferred);  tmp = A p'  with p' formed on the fly from z and p (the same expression, so the same bits);
+//         part1[block] = sum tmp^2
+// iter = 0 runs the prologue's tail (p' = z, rhsNorm2, threshold); final = 1 runs a tail only (after the last iteration).
+__global__ void __launch_bounds__(256) k_lscg_step(int R, int n, int iter, int final, int nparts3, double tol, const int *__restrict__ ecol, const double *__restrict__ eval,
+                                                   const double *__restrict__ z, const double *__restrict__ p_in, double *__restrict__ p_out, double *__restrict__ x,
+                                                   double *__restrict__ residual, double *__restrict__ tmp, LscgState *__restrict__ S,
+                                                   const double *__restrict__ part3, double *__restrict__ part1)
 {
     __shared__ double lds[256];
-    const int pend = S->pending;
-    if (blockIdx.x == 0 && threadIdx.x == 0) S->done = pend;
-    if (pend != -1) return;
-    const double alpha_prev = S->alpha;
+    if (S->done != -1) return;
+    const int u = iter - 1;                                 // the iteration whose tail this is; -1 = prologue
+    const bool init = iter == 0;
+    const double res_norm2 = sum_parts(part3, 2, nparts3, lds), abs_new = sum_parts(part3 + 1, 2, nparts3, lds);
+    const double alpha = S->alpha;                          // of iteration u (0 in the prologue)
+    double threshold, beta;
+    bool converged;
+    if (init) {
+        threshold = tol * tol * res_norm2;                  // rhsNorm2 == residualNorm2: x0 = 0
+        converged = res_norm2 == 0 || res_norm2 < threshold;
+        beta = 0;
+    } else {
+        threshold = S->threshold;
+        converged = res_norm2 < threshold;
+        beta = abs_new / S->abs_new[(u + 1) & 1];
+    }
+    const int gid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+    for (int j = gid; j < n; j += nthreads) {
+        const double pj = p_in[j];
+        x[j] = x[j] + alpha * pj;
+        if (!converged) p_out[j] = z[j] + beta * pj;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->abs_new[u & 1] = abs_new;
+        S->res_norm2 = res_norm2;
+        if (init) { S->rhs_norm2 = res_norm2; S->threshold = threshold; }
+        if (converged) S->pending = init ? (res_norm2 == 0 ? -2 : 0) : u;
+    }
+    if (converged || final) return;
     double acc = 0;
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
-        residual[r] = residual[r] - alpha_prev * tmp[r];
+    for (int r = gid; r < R; r += nthreads) {
+        residual[r] = residual[r] - alpha * tmp[r];
         double t = 0;
-        for (int k = 0; k < ELL_W; ++k) t += eval[(size_t)k * R + r] * p[ecol[(size_t)k * R + r]];
+        for (int k = 0; k < ELL_W; ++k) {
+            const int c = ecol[(size_t)k * R + r];
+            t += eval[(size_t)k * R + r] * (z[c] + beta * p_in[c]);
+        }
         tmp[r] = t;
         acc += t * t;
     }
-    const double s = block_sum(acc, lds);
-    if (threadIdx.x == 0) part1[blockIdx.x] = s;
+    const double sacc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part1[blockIdx.x] = sacc;
 }
 
 // alpha = abs_new / sum(part1); normal residual nr = A^T (residual - alpha tmp); z = invdiag nr; partials of nr.nr and nr.z
@@ -465,7 +498,9 @@ __global__ void __launch_bounds__(256) k_lscg_cols(int n, int iter, int init, in
                                                    const double *__restrict__ part1, double *__restrict__ part3)
 {
     __shared__ double lds[256];
-    if (S->pending != -1) return;
+    const int pend = S->pending;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->done = pend;          // the flag k_lscg_step reads (it writes `pending` itself)
+    if (pend != -1) return;
     double alpha = 0;
     if (!init) alpha = S->abs_new[(iter + 1) & 1] / sum_parts(part1, 1, nparts1, lds);
     if (blockIdx.x == 0 && threadIdx.x == 0) S->alpha = alpha;
@@ -487,39 +522,6 @@ __global__ void __launch_bounds__(256) k_lscg_cols(int n, int iter, int init, in
     }
     const double snn = block_sum(a_nn, lds), snz = block_sum(a_nz, lds);
     if (threadIdx.x == 0) { part3[blockIdx.x * 2] = snn; part3[blockIdx.x * 2 + 1] = snz; }
-}
-
-// residualNorm2 = sum nr.nr -> converged?  beta = abs_new / abs_old;  x += alpha p;  p = z + beta p
-__global__ void __launch_bounds__(256) k_lscg_update(int n, int iter, int init, int nparts3, double tol, const double *__restrict__ z, double *__restrict__ x,
-                                                     double *__restrict__ p, LscgState *__restrict__ S, const double *__restrict__ part3)
-{
-    __shared__ double lds[256];
-    if (S->done != -1) return;
-    const double res_norm2 = sum_parts(part3, 2, nparts3, lds), abs_new = sum_parts(part3 + 1, 2, nparts3, lds);
-    const double alpha = S->alpha;
-    double threshold, beta;
-    bool converged;
-    if (init) {
-        threshold = tol * tol * res_norm2;                  // rhsNorm2 == residualNorm2: x0 = 0
-        converged = res_norm2 == 0 || res_norm2 < threshold;
-        beta = 0;
-    } else {
-        threshold = S->threshold;
-        converged = res_norm2 < threshold;
-        beta = abs_new / S->abs_new[(iter + 1) & 1];
-    }
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < n) {
-        const double pj = p[j];
-        x[j] = x[j] + alpha * pj;
-        if (!converged) p[j] = z[j] + beta * pj;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        S->abs_new[iter & 1] = abs_new;
-        S->res_norm2 = res_norm2;
-        if (init) { S->rhs_norm2 = res_norm2; S->threshold = threshold; }
-        if (converged) S->pending = init ? (res_norm2 == 0 ? -2 : 0) : iter;
-    }
 }
 
 int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vector<double> &x, ms_mesh_info *info, hipStream_t st)
@@ -562,8 +564,8 @@ int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vecto
     memcpy(host + o_b, S.b.data(), (size_t)R * 8);                       // residual = b - A 0
     LscgState *init_state = (LscgState *)(host + o_state);
     init_state->pending = init_state->done = -1;
-    // device: the uploaded block, then the work vectors tmp[R] | x[n] | p[n] (zero) | z[n] | part1 | part3
-    const size_t w_tmp = 0, w_x = w_tmp + al((size_t)R * 8), w_p = w_x + al((size_t)n * 8), w_z = w_p + al((size_t)n * 8), w_p1 = w_z + al((size_t)n * 8),
+    // device: the uploaded block, then the work vectors tmp[R] | x[n] | p[2][n] (zero) | z[n] | part1 | part3
+    const size_t w_tmp = 0, w_x = w_tmp + al((size_t)R * 8), w_p = w_x + al((size_t)n * 8), w_z = w_p + 2 * al((size_t)n * 8), w_p1 = w_z + al((size_t)n * 8),
                  w_p3 = w_p1 + al(LSCG_PARTS * 8), work_bytes = w_p3 + al(LSCG_PARTS * 16);
     uint8_t *U = (uint8_t *)device_scratch().get(up_bytes + work_bytes);
     if (!U) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of device scratch", up_bytes + work_bytes);
@@ -572,29 +574,30 @@ int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vecto
     MS_HIP(hipMemsetAsync(W, 0, w_z, st));
     const int *d_ecol = (const int *)(U + o_ecol), *d_crow = (const int *)(U + o_crow), *d_cptr = (const int *)(U + o_cptr);
     const double *d_eval = (const double *)(U + o_eval), *d_cval = (const double *)(U + o_cval), *d_inv = (const double *)(U + o_inv);
-    double *d_res = (double *)(U + o_b), *d_tmp = (double *)(W + w_tmp), *d_x = (double *)(W + w_x), *d_p = (double *)(W + w_p), *d_z = (double *)(W + w_z);
+    double *d_res = (double *)(U + o_b), *d_tmp = (double *)(W + w_tmp), *d_x = (double *)(W + w_x), *d_z = (double *)(W + w_z);
+    double *d_pb[2] = {(double *)(W + w_p), (double *)(W + w_p + al((size_t)n * 8))};
     double *d_p1 = (double *)(W + w_p1), *d_p3 = (double *)(W + w_p3);
     LscgState *ds = (LscgState *)(U + o_state);
 
     const double tol = tolerance > 0 ? tolerance : DBL_EPSILON;
     const int max_it = max_iterations > 0 ? max_iterations : 2 * n;
-    const int g_rows = std::min(LSCG_PARTS, div_up(R, 256)), g_cols = std::min(LSCG_PARTS, div_up(n * 16, 256)), g_upd = div_up(n, 256);
-    // prologue: normal residual of x0 = 0, rhsNorm2, threshold, p = z
-    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, -1, 1, 0, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
-    k_lscg_update<<<g_upd, 256, 0, st>>>(n, -1, 1, g_cols, tol, d_z, d_x, d_p, ds, d_p3);
-    MS_LAUNCH_CHECK();
+    const int g_step = std::min(LSCG_PARTS, div_up(std::max(R, n), 256)), g_cols = std::min(LSCG_PARTS, div_up(n * 16, 256));
     LscgState *hs = (LscgState *)(host + o_hstate);
+    // prologue: normal residual of x0 = 0; its tail (rhsNorm2, threshold, p = z) is the first k_lscg_step
+    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, -1, 1, 0, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
+    MS_LAUNCH_CHECK();
     int it = 0;
     for (; it < max_it; ++it) {
-        k_lscg_rows<<<g_rows, 256, 0, st>>>(R, d_ecol, d_eval, d_p, d_res, d_tmp, ds, d_p1);
-        k_lscg_cols<<<g_cols, 256, 0, st>>>(n, it, 0, g_rows, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
-        k_lscg_update<<<g_upd, 256, 0, st>>>(n, it, 0, g_cols, tol, d_z, d_x, d_p, ds, d_p3);
+        k_lscg_step<<<g_step, 256, 0, st>>>(R, n, it, 0, g_cols, tol, d_ecol, d_eval, d_z, d_pb[it & 1], d_pb[(it + 1) & 1], d_x, d_res, d_tmp, ds, d_p3, d_p1);
+        k_lscg_cols<<<g_cols, 256, 0, st>>>(n, it, 0, g_step, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
         if ((it & 63) == 63) {                  // the kernels of a finished solve return at once; look at the flag now and then
             if (int e = copy_async(ds, hs, al(sizeof(LscgState)), st)) return e;
             MS_HIP(hipStreamSynchronize(st));
             if (hs->pending != -1) break;
         }
     }
+    if (it == max_it)                           // the tail of the last iteration (x += alpha p, the convergence test)
+        k_lscg_step<<<g_step, 256, 0, st>>>(R, n, max_it, 1, g_cols, tol, d_ecol, d_eval, d_z, d_pb[max_it & 1], d_pb[(max_it + 1) & 1], d_x, d_res, d_tmp, ds, d_p3, d_p1);
     MS_LAUNCH_CHECK();
     if (int e = copy_async(ds, hs, al(sizeof(LscgState)), st)) return e;
     if (int e = copy_async(d_x, host + o_hx, al((size_t)n * 8), st)) return e;
