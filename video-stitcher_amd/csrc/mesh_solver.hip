@@ -401,6 +401,7 @@ void smoothness_term(LinSys &S, const std::vector<float> &sal, const ms_image &v
 // ------------------------------------------------------------------------------------------------ device: least-squares CG, fp64
 constexpr int LSCG_PARTS = 512;                 // at most this many workgroups produce partial sums (2 x the CU count)
 constexpr int ELL_W = 8;                        // no row of the system has more than 8 coefficients
+constexpr int LSCG_BLOCK = 64;                  // iterations between two looks at the convergence flag
 
 struct LscgState {                              // written only by workgroup 0 of the kernel named, read by later kernels
     double alpha;                               // k_lscg_cols
@@ -408,7 +409,8 @@ struct LscgState {                              // written only by workgroup 0 o
     double rhs_norm2, res_norm2, threshold;     // k_lscg_step
     int pending;                                // k_lscg_step: -1 running, >= 0 converged in that iteration, -2 zero right-hand side
     int done;                                   // k_lscg_cols copies `pending` here: the flag k_lscg_step itself may read while it writes `pending`
-};
+    int iter_step, iter_cols;                   // the iteration each kernel is at: k_lscg_cols advances iter_step, k_lscg_step hands its value to iter_cols
+};                                              // (kept on the device: the launches of every iteration are identical)
 
 __device__ double block_sum_impl(double v, double *lds)     // fixed-order tree over the 256 threads
 {
@@ -439,14 +441,19 @@ __device__ double block_sum(double v, double *lds) { return block_sum_impl(v, ld
 //   tail: residualNorm2 = sum nr.nr -> converged?  beta = abs_new / abs_old;  x += alpha p;  p' = z + beta p   (p' into the other p buffer)
 //   head: residual -= alpha tmp (deferred);  tmp = A p'  with p' formed on the fly from z and p (the same expression, so the same bits);
 //         part1[block] = sum tmp^2
-// iter = 0 runs the prologue's tail (p' = z, rhsNorm2, threshold); final = 1 runs a tail only (after the last iteration).
-__global__ void __launch_bounds__(256) k_lscg_step(int R, int n, int iter, int final, int nparts3, double tol, const int *__restrict__ ecol, const double *__restrict__ eval,
-                                                   const double *__restrict__ z, const double *__restrict__ p_in, double *__restrict__ p_out, double *__restrict__ x,
+// The iteration index lives in the state: 0 runs the prologue's tail (p' = z, rhsNorm2, threshold), max_it a tail only, beyond that nothing.
+__global__ void __launch_bounds__(256) k_lscg_step(int R, int n, int max_it, int nparts3, double tol, const int *__restrict__ ecol, const double *__restrict__ eval,
+                                                   const double *__restrict__ z, double *__restrict__ p0, double *__restrict__ p1, double *__restrict__ x,
                                                    double *__restrict__ residual, double *__restrict__ tmp, LscgState *__restrict__ S,
                                                    const double *__restrict__ part3, double *__restrict__ part1)
 {
     __shared__ double lds[256];
-    if (S->done != -1) return;
+    const int iter = S->iter_step;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->iter_cols = iter;
+    if (S->done != -1 || iter > max_it) return;
+    const bool final = iter == max_it;                      // after the last iteration: its tail only
+    const double *__restrict__ p_in = (iter & 1) ? p1 : p0;
+    double *__restrict__ p_out = (iter & 1) ? p0 : p1;
     const int u = iter - 1;                                 // the iteration whose tail this is; -1 = prologue
     const bool init = iter == 0;
     const double res_norm2 = sum_parts(part3, 2, nparts3, lds), abs_new = sum_parts(part3 + 1, 2, nparts3, lds);
@@ -492,15 +499,18 @@ __global__ void __launch_bounds__(256) k_lscg_step(int R, int n, int iter, int f
 
 // alpha = abs_new / sum(part1); normal residual nr = A^T (residual - alpha tmp); z = invdiag nr; partials of nr.nr and nr.z
 // init = 1: the prologue (alpha = 0, tmp = 0): nr = A^T b
-__global__ void __launch_bounds__(256) k_lscg_cols(int n, int iter, int init, int nparts1, const int *__restrict__ cptr, const int *__restrict__ crow,
+__global__ void __launch_bounds__(256) k_lscg_cols(int n, int max_it, int init, int nparts1, const int *__restrict__ cptr, const int *__restrict__ crow,
                                                    const double *__restrict__ cval, const double *__restrict__ invdiag, const double *__restrict__ residual,
                                                    const double *__restrict__ tmp, double *__restrict__ z, LscgState *__restrict__ S,
                                                    const double *__restrict__ part1, double *__restrict__ part3)
 {
     __shared__ double lds[256];
-    const int pend = S->pending;
-    if (blockIdx.x == 0 && threadIdx.x == 0) S->done = pend;          // the flag k_lscg_step reads (it writes `pending` itself)
-    if (pend != -1) return;
+    const int pend = S->pending, iter = init ? -1 : S->iter_cols;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->done = pend;                                       // the flag k_lscg_step reads (it writes `pending` itself)
+        if (!init) S->iter_step = iter + 1;
+    }
+    if (pend != -1 || iter >= max_it) return;
     double alpha = 0;
     if (!init) alpha = S->abs_new[(iter + 1) & 1] / sum_parts(part1, 1, nparts1, lds);
     if (blockIdx.x == 0 && threadIdx.x == 0) S->alpha = alpha;
@@ -584,20 +594,23 @@ int solve_lscg(const LinSys &S, int max_iterations, double tolerance, std::vecto
     const int g_step = std::min(LSCG_PARTS, div_up(std::max(R, n), 256)), g_cols = std::min(LSCG_PARTS, div_up(n * 16, 256));
     LscgState *hs = (LscgState *)(host + o_hstate);
     // prologue: normal residual of x0 = 0; its tail (rhsNorm2, threshold, p = z) is the first k_lscg_step
-    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, -1, 1, 0, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
+    k_lscg_cols<<<g_cols, 256, 0, st>>>(n, max_it, 1, 0, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
     MS_LAUNCH_CHECK();
-    int it = 0;
-    for (; it < max_it; ++it) {
-        k_lscg_step<<<g_step, 256, 0, st>>>(R, n, it, 0, g_cols, tol, d_ecol, d_eval, d_z, d_pb[it & 1], d_pb[(it + 1) & 1], d_x, d_res, d_tmp, ds, d_p3, d_p1);
-        k_lscg_cols<<<g_cols, 256, 0, st>>>(n, it, 0, g_step, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
-        if ((it & 63) == 63) {                  // the kernels of a finished solve return at once; look at the flag now and then
-            if (int e = copy_async(ds, hs, al(sizeof(LscgState)), st)) return e;
-            MS_HIP(hipStreamSynchronize(st));
-            if (hs->pending != -1) break;
+    auto launch_block = [&](hipStream_t s2) {              // LSCG_BLOCK iterations; past the end (or after convergence) the launches return at once
+        for (int k = 0; k < LSCG_BLOCK; ++k) {
+            k_lscg_step<<<g_step, 256, 0, s2>>>(R, n, max_it, g_cols, tol, d_ecol, d_eval, d_z, d_pb[0], d_pb[1], d_x, d_res, d_tmp, ds, d_p3, d_p1);
+            k_lscg_cols<<<g_cols, 256, 0, s2>>>(n, max_it, 0, g_step, d_cptr, d_crow, d_cval, d_inv, d_res, d_tmp, d_z, ds, d_p1, d_p3);
         }
+    };
+    // (Replaying one block as a captured HIP graph was measured: no faster than the direct launches -- the cost is the dependency between
+    // consecutive kernels, not their submission.)
+    int rc = MS_OK;
+    for (int done_its = 0; done_its <= max_it; done_its += LSCG_BLOCK) {      // <= : the tail of the last iteration is one more step
+        launch_block(st);
+        if (copy_async(ds, hs, al(sizeof(LscgState)), st) != MS_OK || hipStreamSynchronize(st) != hipSuccess) { rc = fail(MS_ERR_HIP, "ms_create_mesh: solver synchronisation failed"); break; }
+        if (hs->pending != -1) break;
     }
-    if (it == max_it)                           // the tail of the last iteration (x += alpha p, the convergence test)
-        k_lscg_step<<<g_step, 256, 0, st>>>(R, n, max_it, 1, g_cols, tol, d_ecol, d_eval, d_z, d_pb[max_it & 1], d_pb[(max_it + 1) & 1], d_x, d_res, d_tmp, ds, d_p3, d_p1);
+    if (rc != MS_OK) return rc;
     MS_LAUNCH_CHECK();
     if (int e = copy_async(ds, hs, al(sizeof(LscgState)), st)) return e;
     if (int e = copy_async(d_x, host + o_hx, al((size_t)n * 8), st)) return e;
