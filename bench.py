@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--egress-convert", action="store_true", help="N>1 egress as 8UC3 canvas + ms_bgr_to_i420_batch instead of ms_stitch_i420 (A/B)")
     ap.add_argument("--emulate-gather", action="store_true", help="single GPU: run the per-frame egress conversion of the N>1 path without the collective (host/GPU cost of that leg)")
     ap.add_argument("--gather-format", default="i420", choices=["i420", "bgr"],
                     help="what the sink rank receives: planar I420 of the pano rows (the encoder input of consume(), timed.cpp:308-316; "
@@ -327,14 +328,21 @@ def main():
         slabs = [torch.zeros((F, fh, cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     import ctypes
     Fs = F // S
-    subruns = [[comps[k].prepared(frames[k * Fs:(k + 1) * Fs], out8u=outs[b][k * Fs:(k + 1) * Fs]) for k in range(S)] for b in range(2)]
-    handles = [ctypes.c_void_p(st.cuda_stream) for st in streams]
-
     gather = world > 1 and not args.no_gather
     egress = gather or args.emulate_gather
-    # egress of the N>1 path: the pano ROI rows of every canvas of the step -> one I420 slab each, one launch once the contexts have joined,
+    direct_i420 = i420 and egress and not args.egress_convert       # the level-0 band kernel writes the I420 slabs itself (ms_stitch_i420)
+    if direct_i420:
+        for b in range(2):
+            slabs[b][:, :(yb - ya)] = 16; slabs[b][:, (yb - ya):] = 128          # black outside the panorama ROI, written once
+        assert comp.i420_rows() == (ya, yb - ya)
+        subruns = [[comps[k].prepared_i420(frames[k * Fs:(k + 1) * Fs], [slabs[b][j] for j in range(k * Fs, (k + 1) * Fs)]) for k in range(S)] for b in range(2)]
+    else:
+        subruns = [[comps[k].prepared(frames[k * Fs:(k + 1) * Fs], out8u=outs[b][k * Fs:(k + 1) * Fs]) for k in range(S)] for b in range(2)]
+    handles = [ctypes.c_void_p(st.cuda_stream) for st in streams]
+
+    # egress of the N>1 path (only with --egress-convert; by default the stitch writes I420 directly): the pano ROI rows of every canvas of the step -> one I420 slab each, one launch once the contexts have joined,
     # on a stream of its own (one launch per context on that context's stream measured 4 % slower)
-    to_i420 = [ms.bgr_to_i420_batch_prepared([outs[b][j][ya:yb] for j in range(F)], [slabs[b][j] for j in range(F)]) for b in range(2)] if (i420 and egress) else None
+    to_i420 = [ms.bgr_to_i420_batch_prepared([outs[b][j][ya:yb] for j in range(F)], [slabs[b][j] for j in range(F)]) for b in range(2)] if (i420 and egress and not direct_i420) else None
 
     egress_stream = torch.cuda.Stream(device=dev) if to_i420 else None
     egress_handle = ctypes.c_void_p(egress_stream.cuda_stream) if to_i420 else None

@@ -357,6 +357,15 @@ MS_API int ms_get_mask(const ms_ctx *ctx, int view, ms_image *mask);
 MS_API int ms_get_weight_level(const ms_ctx *ctx, int view, int level, ms_image *w);
 MS_API int ms_get_mesh_maps(const ms_ctx *ctx, int view, ms_image *xmesh, ms_image *ymesh);
 
+/* Encoder-ready output: the panorama as planar I420, what consume() produces with cvtColor(BGR2YUV_I420) for the encoder (APP/timed.cpp:308-316),
+ * written by the level-0 band kernel itself (no 8UC3 canvas, no conversion pass: 1.5 instead of 3 + 4.5 bytes per pixel of traffic).
+ * out_i420[f]: contiguous 8UC1 image of (rows * 3 / 2) x out_width holding the canvas rows [first_row, first_row + rows) given by
+ * ms_get_i420_rows (the even-aligned row span of the panorama ROI).  Only panorama pixels are written: initialise each buffer once to black
+ * (Y = 16, U = V = 128; equals ms_bgr_to_i420 of a zeroed canvas).  Bit-identical to ms_stitch(out8u) + ms_bgr_to_i420 of those rows.
+ * Needs the tiled band path (>= 1 band, panorama width a multiple of 8, no view sharding); MS_ERR_UNSUPPORTED otherwise. */
+MS_API int ms_stitch_i420(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out_i420, ms_stream stream);
+MS_API int ms_get_i420_rows(const ms_ctx *ctx, int *first_canvas_row, int *rows);
+
 /* per-kernel GPU time of the last ms_stitch_timed call (hipEvents on `stream`), for bench.py's roofline.
  * names/ms: arrays of `cap` entries; returns the number of kernels recorded. */
 MS_API int ms_stitch_timed(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,

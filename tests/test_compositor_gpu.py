@@ -451,3 +451,40 @@ def test_state_errors(ms, cuda):
     with pytest.raises(ms.MsError, match="must be built first"):
         comp.init_blender()
     comp.close()
+
+
+@pytest.mark.parametrize("rig,cpw", [("mini6", False), ("cfg2", False), ("mini6", True), ("cfg5", False)])
+def test_stitch_i420_equals_canvas_then_conversion(ms, cuda, rig, cpw):
+    """ms_stitch_i420: the level-0 band kernel writes the encoder's planar I420 itself; must equal ms_stitch(out8u) followed by
+    cvtColor(BGR2YUV_I420) (ms_bgr_to_i420) of the same canvas rows, bit for bit, for batches of frames."""
+    comp, cfg, _ = make_rig(ms, rig, enable_cpw=cpw, max_frames=2)
+    if cpw:
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 8, 9, phase=0.2 * i, amp=5.0))
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(2)]
+    canv = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda) for _ in range(2)]
+    comp.stitch(frames, out8u=canv)
+    y0, rows = comp.i420_rows()
+    pg = comp.pano_geom()
+    assert y0 % 2 == 0 and rows % 2 == 0 and y0 <= pg.canvas_y and y0 + rows >= min(cfg["out_h"], pg.canvas_y + pg.dst_roi_final.height)
+    outs = comp.new_i420(2)
+    comp.stitch_i420(frames, outs)
+    torch.cuda.synchronize()
+    for t in range(2):
+        want = host(ms.bgr_to_i420(canv[t][y0:y0 + rows]))
+        got = host(outs[t])
+        assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    # a second call into the same buffers gives the same bytes (nothing accumulates)
+    comp.stitch_i420(frames, outs)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(outs[1]), host(ms.bgr_to_i420(canv[1][y0:y0 + rows])))
+    comp.close()
+
+
+def test_stitch_i420_needs_the_tiled_band_path(ms, cuda):
+    comp, cfg, _ = make_rig(ms, "mini6", simple_kernels=True)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 0)) for i in range(cfg["n"])]]
+    with pytest.raises(ms.MsError):
+        comp.stitch_i420(frames, comp.new_i420(1))
+    comp.close()

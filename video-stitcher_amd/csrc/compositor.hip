@@ -1032,6 +1032,40 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                     }
                 }
             }
+            if (out.pi[f]) {        // cvtColor(BGR2YUV_I420) of the clamped canvas pixel, written straight into the planar slab (see ms_stitch_i420)
+                const int iy = y + P.canvas_y - P.i_y0, cx0 = x0 + P.canvas_x;
+                if (iy >= 0 && iy < P.i_rows) {
+                    constexpr int SH = 20, HALF = 1 << (SH - 1);
+                    constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+                    uint8_t *Yp = out.pi[f] + (size_t)iy * P.out_w;
+                    uint8_t *Up = out.pi[f] + (size_t)P.out_w * P.i_rows + (size_t)(iy >> 1) * (P.out_w >> 1), *Vp = Up + (size_t)(P.out_w >> 1) * (P.i_rows >> 1);
+                    const bool crow = (iy & 1) == 0;                       // chroma comes from the top-left pixel of each 2 x 2 block
+                    uint8_t yv[8], uv[8], vv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int b = min(max(px[k][0], 0), 255), g = min(max(px[k][1], 0), 255), rr = min(max(px[k][2], 0), 255);
+                        yv[k] = (uint8_t)min(max((CRY * rr + CGY * g + CBY * b + HALF + (16 << SH)) >> SH, 0), 255);
+                        uv[k] = (uint8_t)min(max((CRU * rr + CGU * g + CBU * b + HALF + (128 << SH)) >> SH, 0), 255);
+                        vv[k] = (uint8_t)min(max((CBU * rr + CGV * g + CBV * b + HALF + (128 << SH)) >> SH, 0), 255);
+                    }
+                    if (nvalid == 8 && cx0 >= 0 && cx0 + 8 <= P.out_w) {
+                        __builtin_memcpy(Yp + cx0, yv, 8);
+                        if (crow) {
+                            const int k0 = cx0 & 1;                           // first even canvas column of the cell
+                            const uint8_t u4[4] = {uv[k0], uv[k0 + 2], uv[k0 + 4], uv[k0 + 6]}, v4[4] = {vv[k0], vv[k0 + 2], vv[k0 + 4], vv[k0 + 6]};
+                            __builtin_memcpy(Up + ((cx0 + k0) >> 1), u4, 4);
+                            __builtin_memcpy(Vp + ((cx0 + k0) >> 1), v4, 4);
+                        }
+                    } else {
+                        for (int k = 0; k < nvalid; ++k) {
+                            const int cx = cx0 + k;
+                            if (cx < 0 || cx >= P.out_w) continue;
+                            Yp[cx] = yv[k];
+                            if (crow && (cx & 1) == 0) { Up[cx >> 1] = uv[k]; Vp[cx >> 1] = vv[k]; }
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -2106,6 +2140,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     P.mask_pitch = P.fw;
     P.alpha = (float)(1. / 255.);
     P.canvas_x = c->canvas_x; P.canvas_y = c->canvas_y; P.out_w = c->cfg.out_width; P.out_h = c->cfg.out_height;
+    P.i_y0 = c->canvas_y & ~1; P.i_rows = std::max(0, std::min(c->cfg.out_height & ~1, (c->canvas_y + P.fh + 1) & ~1) - P.i_y0);
     if (int e = c->den.alloc(den_total * sizeof(float))) return e;
     if (int e = c->result_mask.alloc((size_t)P.fw * P.fh)) return e;
     MS_HIP(hipMemsetAsync(c->den.p, 0, den_total * sizeof(float), st));
@@ -2419,7 +2454,7 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
     } while (0)
 
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
-                       int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{})
+                       int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{}, ms_image *out_i420 = nullptr)
 {
     if (!c) return fail(MS_ERR_INVALID, "null context");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_stitch: call ms_build_maps / masks / ms_init_blender first");
@@ -2458,6 +2493,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
                      "ms_stitch: out16s[%d] must be 16SC3 %dx%d", f, P.fw, P.fh);
             out.p16[f] = (int16_t *)out16s[f].data; out.step16[f] = (unsigned)out16s[f].step;
         }
+        if (out_i420 && out_i420[f].data) {
+            MS_CHECK(out_i420[f].type == MS_8UC1 && out_i420[f].cols == P.out_w && out_i420[f].rows == P.i_rows * 3 / 2 && out_i420[f].step == (size_t)P.out_w,
+                     "ms_stitch_i420: out[%d] must be a contiguous 8UC1 image of %d x %d (I420 of canvas rows %d..%d)", f, P.out_w, P.i_rows * 3 / 2, P.i_y0, P.i_y0 + P.i_rows - 1);
+            out.pi[f] = (uint8_t *)out_i420[f].data;
+        }
+    }
+    if (out_i420) {
+        if (!(P.nb >= 1 && c->blend_vec[0] && c->cfg.reserved[0] == 0 && S.mode == 0 && (P.out_w & 1) == 0 && P.i_rows > 0))
+            return fail(MS_ERR_UNSUPPORTED, "ms_stitch_i420: needs the tiled level-0 band kernel (>= 1 band, pano width a multiple of 8, no view sharding) and an even canvas width");
     }
     MeshTable mesh{};
     const bool cpw = c->cfg.enable_cpw != 0;
@@ -2612,6 +2656,20 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
 int ms_stitch(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, ms_stream stream)
 {
     return stitch_impl(c, n_frames, views, out8u, out16s, as_stream(stream), 0, nullptr, nullptr, nullptr);
+}
+
+int ms_stitch_i420(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out_i420, ms_stream stream)
+{
+    if (!out_i420) return fail(MS_ERR_INVALID, "ms_stitch_i420: null output");
+    return stitch_impl(c, n_frames, views, nullptr, nullptr, as_stream(stream), 0, nullptr, nullptr, nullptr, ShardArgs{}, out_i420);
+}
+
+int ms_get_i420_rows(const ms_ctx *c, int *first_canvas_row, int *rows)
+{
+    if (!c || !first_canvas_row || !rows) return fail(MS_ERR_INVALID, "ms_get_i420_rows: null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_i420_rows: call ms_init_blender first");
+    *first_canvas_row = c->pano.i_y0; *rows = c->pano.i_rows;
+    return MS_OK;
 }
 
 int ms_stitch_timed(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, ms_stream stream,

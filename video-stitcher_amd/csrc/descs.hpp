@@ -44,6 +44,7 @@ struct PanoDesc {
     int mask_pitch;
     int fw, fh;                   // dst_roi_final size
     int canvas_x, canvas_y, out_w, out_h;
+    int i_y0, i_rows;             // even-aligned canvas rows covering the pano ROI: what the I420 output holds
     // per level: one byte per 64 x 16 cell of the pano = the view that OWNS it (exactly one view has non-zero weights there, all of them
     // exactly 1.0f, hence w_sum + 1e-5 == 1.00001f), or 255.  nullptr where the level has no such map.
     const uint8_t *pure[MAX_LEVELS];
@@ -65,7 +66,8 @@ struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pit
 // max |mesh map - identity| of the active mesh of each view, as float bits in device memory (written by ms_set_mesh), and the bound
 // under which CPW stage 1 may skip the tiles stage 2 cannot reach (WarpTile::flags bit 1 = reachable within that bound)
 struct DispTable { const unsigned *p[MAX_VIEWS]; unsigned limit_bits; };
-struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *p16[MAX_FRAMES]; unsigned step16[MAX_FRAMES]; };
+struct OutTable { uint8_t *p8[MAX_FRAMES]; unsigned step8[MAX_FRAMES]; int16_t *p16[MAX_FRAMES]; unsigned step16[MAX_FRAMES];
+                  uint8_t *pi[MAX_FRAMES]; };       // pi: planar I420 of the canvas rows [i_y0, i_y0 + i_rows) (ms_stitch_i420)
 
 
 // ---- work lists (built once in ms_init_blender, plan.cpp-style host code in compositor.hip) ----------

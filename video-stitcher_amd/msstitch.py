@@ -76,7 +76,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows",
 ]
 
 _lib = None
@@ -567,6 +567,38 @@ class Compositor:
             _chk(fn(ctx, n, views, o8, o16, stream if stream is not None else _stream()))
         run.keepalive = (frames, out8u, out16s, views, o8, o16)
         return run
+
+    def i420_rows(self):
+        """(first canvas row, rows) of the even-aligned span the I420 output holds."""
+        a, b = C.c_int(0), C.c_int(0)
+        _chk(load().ms_get_i420_rows(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def new_i420(self, n_frames=1):
+        """Black I420 buffers (Y = 16, U = V = 128) of the size ms_stitch_i420 writes."""
+        torch = _torch()
+        _, rows = self.i420_rows()
+        w = self.cfg.out_width
+        outs = []
+        for _ in range(n_frames):
+            t = torch.full((rows * 3 // 2, w), 128, dtype=torch.uint8, device="cuda")
+            t[:rows] = 16
+            outs.append(t)
+        return outs
+
+    def prepared_i420(self, frames, out_i420):
+        n, views, _, _ = self._tables(frames, None, None)
+        oi = (Image * n)(*[img(t) for t in out_i420])
+        fn, ctx = load().ms_stitch_i420, self._ctx
+
+        def run(stream=None):
+            _chk(fn(ctx, n, views, oi, stream if stream is not None else _stream()))
+        run.keepalive = (frames, out_i420, views, oi)
+        return run
+
+    def stitch_i420(self, frames, out_i420):
+        """The panorama as planar I420 (encoder input), written by the level-0 band kernel: no 8UC3 canvas, no conversion pass."""
+        self.prepared_i420(frames, out_i420)()
 
     def partial_bytes(self):
         load().ms_partial_bytes.restype = C.c_size_t
