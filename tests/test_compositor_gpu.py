@@ -156,6 +156,32 @@ def test_full_size_config2_matches_oracle(ms, cuda, oracle):
     comp.close()
 
 
+@pytest.mark.parametrize("rig,cpw", [("cfg5", False), ("cfg2", True)])
+def test_full_size_config5_and_config3_match_oracle(ms, cuda, oracle, rig, cpw):
+    """BASELINE.json configs[4] geometry (12 x 4K -> 7680 x 3840, SURVEY App. C: pano ROI 7680 x 768, two full-width views) and configs[2]
+    (config 2 + CPW, 40 x 40 meshes) at full size against the oracle, one frame, bit-exact."""
+    comp, cfg, gains = make_rig(ms, rig, enable_cpw=cpw)
+    frames_np = [synth.frame(cfg["w"], cfg["h"], i, 1) for i in range(cfg["n"])]
+    pg = comp.pano_geom()
+    if rig == "cfg5":
+        assert pg.dst_roi_final.tuple() == (-3839, 1536, 7680, 768) and pg.num_bands == 5      # SURVEY App. C
+    meshes = None
+    if cpw:
+        meshes = []
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 40, 40, phase=0.1 * i + 0.7, amp=8.0))
+            meshes.append(tuple(host(m) for m in comp.mesh_maps(i)))
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames_np]], out16s=[out16])
+    torch.cuda.synchronize()
+    oracle.set_num_threads(16)
+    ref16, refmask = run_oracle(oracle, comp, cfg, gains, frames_np, meshes)
+    assert np.array_equal(host(comp.result_mask()), refmask)
+    assert np.array_equal(host(out16), ref16)
+    comp.close()
+
+
 @pytest.mark.parametrize("rig,cpw", [("cfg2", False), ("cfg2", True), ("cfg5", False), ("mini6", True), ("mini4", False)])
 def test_tiled_kernels_equal_simple_kernels(ms, cuda, rig, cpw):
     """The work-list / multi-pixel-per-lane kernels against the one-pixel-per-lane kernels (same library,
