@@ -94,6 +94,15 @@ public:
         if (out16s) o16 = wrap(*out16s);
         check(ms_stitch(ctx_, (int)(v.size() / n_), v.data(), out8u ? &o8 : nullptr, out16s ? &o16 : nullptr, s));
     }
+    // stitch_one + consume()'s cvtColor(BGR2YUV_I420) (timed.cpp:308-316) in one: i420[f] = contiguous 8UC1 (rows * 3 / 2) x out_w, rows from i420Rows()
+    template <class Mat> void stitch_one_i420(const std::vector<Mat> &full_imgs, std::vector<Mat> &i420, ms_stream s = nullptr)
+    {
+        std::vector<ms_image> v, o;
+        for (const Mat &m : full_imgs) v.push_back(wrap(m));
+        for (const Mat &m : i420) o.push_back(wrap(m));
+        check(ms_stitch_i420(ctx_, (int)(v.size() / n_), v.data(), o.data(), s));
+    }
+    void i420Rows(int &first_canvas_row, int &rows) const { check(ms_get_i420_rows(ctx_, &first_canvas_row, &rows)); }
     // MultiBandBlender::feed_online(img, idx, stream) / blend(dst, dst_mask, gpuOut, true) call shape (timed.cpp:110,137)
     template <class Mat> void feed_online(const Mat &img, int idx, ms_stream s = nullptr) { ms_image v = wrap(img); check(ms_feed(ctx_, idx, &v, s)); }
     template <class Mat> void blend(Mat *out8u, Mat *out16s, ms_stream s = nullptr)

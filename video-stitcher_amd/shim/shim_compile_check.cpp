@@ -19,6 +19,8 @@ int shim_compile_check()
         comp.stitch_one(frames, &a, (FakeGpuMat *)nullptr);
         for (int i = 0; i < 6; ++i) comp.feed_online(frames[i], i);
         comp.blend(&a, (FakeGpuMat *)nullptr);
+        std::vector<FakeGpuMat> slabs(1);
+        comp.stitch_one_i420(frames, slabs);
         // MeshWarper over ImageFeatures / MatchesInfo shaped types
         struct Pt { float x, y; }; struct KeyPoint { Pt pt; }; struct Size { int width, height; };
         struct Features { Size img_size; std::vector<KeyPoint> keypoints; };
