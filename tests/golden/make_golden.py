@@ -58,3 +58,19 @@ psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-9))
 np.savez_compressed(os.path.join(HERE, "blender_2view.npz"), corners=np.array(corners), sizes=np.array(sizes), num_bands=3,
                     img0=imgs[0], img1=imgs[1], mask0=masks[0], mask1=masks[1], out=out, out_mask=omask, psnr_vs_feather_free=psnr)
 print("wrote golden vectors; blend PSNR vs plain copy = %.1f dB" % psnr)
+
+# recalibration path (regression vectors of the numpy oracles): cv::remap's CPU arithmetic, Hamming 2-NN, a small CPW mesh solve
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import features_oracle as FO  # noqa: E402
+import mesh_oracle as MO  # noqa: E402
+from test_mesh_oracle import rig  # noqa: E402
+q = rng.integers(0, 256, size=(40, 32), dtype=np.uint8) & np.uint8(0x33)
+t = rng.integers(0, 256, size=(57, 32), dtype=np.uint8) & np.uint8(0x33)
+kidx, kdist = FO.knn2(q, t)
+images, matches = rig(n=3, seed=21)
+gx, gy, ginfo = MO.create_mesh(images, matches, 6, 5, focal=60.0, global_dist=8, theta_fn=lambda s, d: MO.generic_theta(s, d, 3))
+np.savez_compressed(os.path.join(HERE, "recalibration_small.npz"), src=src, mx=mx, my=my, cv_remap=O.cv_remap_linear(src, mx, my),
+                    q=q, t=t, knn_idx=kidx, knn_dist=kdist, sal0=MO.saliency(images[0], 6, 5),
+                    mesh_images=np.stack(images), mesh_matches=np.array([m for l in matches for m in l], np.float64), mesh_counts=np.array([len(l) for l in matches]),
+                    mesh_x=gx, mesh_y=gy, mesh_iterations=ginfo["iterations"], mesh_rows=ginfo["rows"], mesh_nnz=ginfo["nnz"])
+print("wrote recalibration_small.npz: %d iterations" % ginfo["iterations"])
