@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function ${MS_EXTRA_FLAGS:-}"
 mkdir -p ../build
 newest_hdr=$(ls -t *.hpp ../../include/ms_stitch.h | head -1)
 pids=()

@@ -2579,7 +2579,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             break;
         }
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
-        if (c->down_vec[l] && c->cfg.reserved[0] == 0) {   // level-l widths are multiples of 8: tile list, 2 rows x 4 cols per lane
+        if (c->down_vec[l] && c->cfg.reserved[0] == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
             if (l == 0) k_down_t<uint8_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
             else        k_down_t<int16_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);

@@ -87,7 +87,11 @@ struct BlendTile { short x0, y0; unsigned view_mask; };                         
 #endif
 constexpr int WARP_TW = MS_WARP_TW, WARP_TH = MS_WARP_TH;      // k_warp_t tile (4 px per lane)
 constexpr int WARP_BX = WARP_TW / 4;            // lanes across a tile row
-constexpr int DOWN_TW = 128, DOWN_TH = 16;     // k_down_t output tile (4 x 2 px per thread, 32 x 8 threads)
+#ifndef MS_DOWN_ROWS
+#define MS_DOWN_ROWS 4
+#endif
+constexpr int DOWN_ROWS = MS_DOWN_ROWS;                      // output rows per lane of k_down_t (2 r + 3 input rows are read for r output rows)
+constexpr int DOWN_TW = 128, DOWN_TH = 8 * DOWN_ROWS;       // k_down_t output tile (4 x DOWN_ROWS px per thread, 32 x 8 threads)
 constexpr int BLEND_TW = 256, BLEND_TH = 16;   // k_blend8_t tile (8 x 2 px per thread, 32 x 8 threads)
 
 }  // namespace ms

@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
     }
 }
 
-// ---- pyrDown, tile list, 2 rows x 4 cols per lane (block 32 x 8) -------------------------------------
+// ---- pyrDown, tile list, DOWN_ROWS (4) rows x 4 cols per lane (block 32 x 8): 11 input rows for 4 output rows (2 rows per lane: 7 for 2, 16 % slower) ----
 // Packed 16-bit arithmetic: every input value is in [0,255] (8-bit pixels, or a Gaussian level of them -- see the invariant at
 // up_2x8_pk), so the vertical sums are <= 16*255 and the full 5x5 sums <= 256*255 = 65280 < 2^16: two columns share one
 // register and plain 32-bit adds never carry between the halves.  Same result as rne_shift(sum, 8) per pixel
@@ -602,32 +602,33 @@ __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ til
     const DownTile T = tiles[blockIdx.x];
     const int c = blockIdx.y, f = blockIdx.z, v = T.view;
     const LevelDesc &Li = views[v].lv[l], &Lo = views[v].lv[l + 1];
+    constexpr int RO = DOWN_ROWS, RI = 2 * RO + 3;          // output rows per lane, input rows they need
     const int t = (T.x0 >> 2) + (int)threadIdx.x;
-    const int y = T.y0 + 2 * (int)threadIdx.y;
+    const int y = T.y0 + RO * (int)threadIdx.y;
     if (4 * t >= Lo.w || y >= Lo.h) return;
     const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
-    const bool two = (y + 1) < Lo.h;
+    const int nrow = min(RO, Lo.h - y);                     // valid output rows of this lane
     const int sy = 2 * y, last = Li.h - 1;
-    int ridx[7];
+    int ridx[RI];
     ridx[0] = abs(sy - 2); ridx[1] = abs(sy - 1); ridx[2] = sy;
 #pragma unroll
-    for (int j = 3; j < 7; ++j) { const int r = sy + j - 2; ridx[j] = r > last ? 2 * last - r : r; }
-    if (!two) { ridx[5] = ridx[4]; ridx[6] = ridx[4]; }
-    typename Row11<TIN>::type raw[7];
+    for (int j = 3; j < RI; ++j) { const int r = sy + j - 2; ridx[j] = r > last ? 2 * last - r : r; }
 #pragma unroll
-    for (int j = 0; j < 7; ++j) raw[j] = fetch_row11(in + (size_t)ridx[j] * Li.pitch, t, Li.w);
-    Down7 r[7];
+    for (int j = 5; j < RI; ++j) if (j > 2 * nrow + 2) ridx[j] = ridx[4];      // rows only the missing outputs would read: any valid row
+    typename Row11<TIN>::type raw[RI];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) r[j] = down_row(raw[j], t, Li.w);
-    Down7 v0, v1;                     // vertical 1 4 6 4 1 of rows 0..4 (output row y) and rows 2..6 (output row y+1)
+    for (int j = 0; j < RI; ++j) raw[j] = fetch_row11(in + (size_t)ridx[j] * Li.pitch, t, Li.w);
+    Down7 r[RI];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        v0.a[k] = (r[0].a[k] + r[4].a[k]) + 4u * (r[1].a[k] + r[3].a[k]) + 6u * r[2].a[k];
-        v1.a[k] = (r[2].a[k] + r[6].a[k]) + 4u * (r[3].a[k] + r[5].a[k]) + 6u * r[4].a[k];
-    }
+    for (int j = 0; j < RI; ++j) r[j] = down_row(raw[j], t, Li.w);
     int16_t *out = gout + (size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + 4 * t;
-    *reinterpret_cast<uint2 *>(out) = down_hpass<TIN>(v0);
-    if (two) *reinterpret_cast<uint2 *>(out + Lo.pitch) = down_hpass<TIN>(v1);
+#pragma unroll
+    for (int o = 0; o < RO; ++o) {                          // vertical 1 4 6 4 1 of input rows 2o .. 2o+4
+        Down7 vv;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) vv.a[k] = (r[2 * o].a[k] + r[2 * o + 4].a[k]) + 4u * (r[2 * o + 1].a[k] + r[2 * o + 3].a[k]) + 6u * r[2 * o + 2].a[k];
+        if (o < nrow) *reinterpret_cast<uint2 *>(out + (size_t)o * Lo.pitch) = down_hpass<TIN>(vv);
+    }
 }
 
 }  // namespace ms
