@@ -21,6 +21,12 @@
  *     opencv_modules.hpp, ...), and no golden image ships with its tests (opencv_extra absent).
  *     The restatement follows the kernels line by line; tolerances are the reference's own
  *     (test_remap.cpp:169, test_pyramids.cpp:80,120, test_blenders.cuda.cpp:90).
+ *     Indirect anchors to executions of the real reference (tests/test_oracle_crosscheck.py): the gaps the surveyor MEASURED between the
+ *     reference's CPU code and the CUDA arithmetic (pyrDown 1 / 0.17 %, pyrUp 1 / 5.1 %, remap 6 / 55 % on noise and
+ *     3 / 2.1 % on a smoothed image) are reproduced between this oracle and its restatements of the CPU flavours (orc_cv_remap_linear_8u,
+ *     the (x + 128) >> 8 pyramids): 1 / 0.2 %, 1 / 5 %, 6 / 61.6 %, 3 / 1.97 %; the oracle also meets the criteria of the reference's own
+ *     CUDA.Remap / CUDA.Resize / pyramid / CUDA-vs-CPU blender tests against those tests' gold functions.
+ *   - orc_cv_remap_linear_8u (cv::remap's CPU fixed-point arithmetic): same status.
  *
  * Floating-point conventions fixed by this oracle (the HIP kernels reproduce them bit-for-bit):
  *   - fp32 everywhere the CUDA kernels use float; compiled with -ffp-contract=off.
