@@ -320,7 +320,7 @@ def main():
     pg = comp.pano_geom()
     fh = pg.dst_roi_final.height
     outs = [[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(F)] for _ in range(2)]
-    ya, yb = pg.canvas_y & ~1, min(cfg["out_h"], (pg.canvas_y + fh + 1) & ~1)       # even-aligned pano rows of the canvas
+    ya, yb = max(0, pg.canvas_y & ~1), min(cfg["out_h"] & ~1, (pg.canvas_y + fh + 1) & ~1)       # even-aligned pano rows of the canvas
     i420 = args.gather_format == "i420" and cfg["out_w"] % 2 == 0
     if i420:
         slabs = [torch.zeros((F, (yb - ya) * 3 // 2, cfg["out_w"]), dtype=torch.uint8, device=dev) for _ in range(2)]

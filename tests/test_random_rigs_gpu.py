@@ -50,6 +50,21 @@ def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, ban
     ref, refmask = b.blend()
     assert b.num_bands == pg.num_bands
     assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    # the planar I420 output must equal canvas + cvtColor(BGR2YUV_I420) wherever it is supported (any parity of the canvas offset)
+    canvas = torch.zeros((out_w // 2, out_w, 3), dtype=torch.uint8, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out8u=[canvas])
+    y0, rows = comp.i420_rows()
+    slabs = comp.new_i420(1)
+    try:
+        comp.stitch_i420([[to_dev(f) for f in frames]], slabs)
+        supported = True
+    except ms.MsError:
+        supported = False
+    if supported:
+        torch.cuda.synchronize()
+        assert np.array_equal(host(slabs[0]), host(ms.bgr_to_i420(canvas[y0:y0 + rows])))
+    else:                         # small pyramids never reach the tiled level-0 kernel: the call must refuse, not approximate
+        assert pg.dst_roi.width % 8 != 0 or pg.num_bands <= 2 or rows == 0
     b.close(); comp.close()
 
 

@@ -2140,7 +2140,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     P.mask_pitch = P.fw;
     P.alpha = (float)(1. / 255.);
     P.canvas_x = c->canvas_x; P.canvas_y = c->canvas_y; P.out_w = c->cfg.out_width; P.out_h = c->cfg.out_height;
-    P.i_y0 = c->canvas_y & ~1; P.i_rows = std::max(0, std::min(c->cfg.out_height & ~1, (c->canvas_y + P.fh + 1) & ~1) - P.i_y0);
+    P.i_y0 = std::max(0, c->canvas_y & ~1); P.i_rows = std::max(0, std::min(c->cfg.out_height & ~1, (c->canvas_y + P.fh + 1) & ~1) - P.i_y0);
     if (int e = c->den.alloc(den_total * sizeof(float))) return e;
     if (int e = c->result_mask.alloc((size_t)P.fw * P.fh)) return e;
     MS_HIP(hipMemsetAsync(c->den.p, 0, den_total * sizeof(float), st));
