@@ -9,6 +9,15 @@ for p in (os.path.join(ROOT, "video-stitcher_amd"), os.path.join(ROOT, "oracle")
         sys.path.insert(0, p)
 
 
+try:        # hypothesis tests draw the same examples on every run (a round-end `pytest -x` must not depend on luck); MS_TEST_RANDOM=1 explores
+    from hypothesis import settings as _hs
+    _hs.register_profile("ms_fixed", derandomize=True, database=None)
+    _hs.register_profile("ms_random", database=None)
+    _hs.load_profile("ms_random" if os.environ.get("MS_TEST_RANDOM") == "1" else "ms_fixed")
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

