@@ -24,7 +24,7 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def make_rig(ms, name, enable_cpw=False, max_frames=1, mask_mode=1, projection=None, simple_kernels=False, lds_stage=False, shards=1, shard_index=0):
+def make_rig(ms, name, enable_cpw=False, max_frames=1, mask_mode=1, projection=None, simple_kernels=False, lds_stage=None, shards=1, shard_index=0):
     """Compositor for one of synth.CONFIGS, calibrated end to end on the device."""
     cfg = synth.CONFIGS[name]
     proj = ms.PROJ_SPHERICAL if projection is None else projection

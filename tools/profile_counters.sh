@@ -6,7 +6,7 @@ set -uo pipefail
 TAG=${1:-r01}; CFG=${2:-cfg2}; F=${3:-16}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/ctr_$TAG; mkdir -p $OUT
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --frames $F --streams 1 --config $CFG"
+B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --frames $F --streams 1 --config $CFG ${BENCH_EXTRA:-}"
 i=0
 for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
          "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
@@ -14,7 +14,8 @@ for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ
          "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
          "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum" \
-         "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+         "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+         "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   case " ${PASSES:-1 2 3 6 7} " in *" $i "*) ;; *) continue;; esac     # passes 4/5 (TA/TCP groups) abort in rocprofv3 on this image
   timeout 300 rocprofv3 --kernel-trace --pmc $G -d $OUT/p$i -o p$i -- $B > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.txt
@@ -36,7 +37,7 @@ for f in sorted(glob.glob(out + "/p*.txt")):
                 rows.setdefault(m.group(1).strip(), {})[m.group(2)] = (float(m.group(3)), float(m.group(5)))
 with open("gpurun_out/counters_%s.txt" % tag, "w") as fo:
     for k, d in rows.items():
-        if not any(t in k for t in ("k_warp_t", "k_blend", "k_down", "k_stage1", "k_remap", "k_single")):
+        if not any(t in k for t in ("k_warp_t", "k_warp_a", "k_calib", "k_blend", "k_down", "k_stage1", "k_remap", "k_single")):
             continue
         fo.write(k + "\n")
         for c, (v, dur) in sorted(d.items()):

@@ -152,6 +152,19 @@ __device__ __forceinline__ int rne_shift(int s, int k)
 }
 
 
+// row * pitch for index arithmetic, both below 2^24: the full-rate 24-bit multiplier (v_mul_u32_u24 / v_mad_u32_u24) instead of the quarter-rate
+// v_mul_lo_u32 / v_mad_u64_u32 the compiler emits for int * int and (size_t) * int
+__device__ __forceinline__ unsigned mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
+
+// acc + 6 x with two full-rate v_lshl_add_u32 (x + 2x, then acc + 2 (3x)) instead of the quarter-rate v_mul_lo_u32 the compiler picks for
+// `6u * x` on packed 16-bit pairs (the value does not fit the 24-bit multiplier).  The empty asm keeps instcombine from re-forming the multiply.
+__device__ __forceinline__ unsigned mad6(unsigned x, unsigned acc)
+{
+    unsigned x3 = x + (x << 1);
+    asm volatile("" : "+v"(x3));
+    return acc + (x3 << 1);
+}
+
 // ---- backward warp maps (build_warp_maps.cu:67-134), split into a column term, a row term and a combine -----
 // so that the dense-map kernel (ms_build_warp_maps / ms_build_maps) and the fused per-frame kernel (which keeps
 // only the 1-D tables and never reads dense maps) execute the SAME fp32 operations and agree bit for bit.

@@ -684,7 +684,7 @@ __device__ __forceinline__ void up_rows_load(const int16_t *__restrict__ cs, int
     const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
     const int jb = max(j0 - 2, 0);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
+    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (mul24(rr[r], cpitch) + (unsigned)jb));
 }
 __device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
 {
@@ -697,15 +697,15 @@ __device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, un
         // taps t0 = hi(w0), (t1,t2) = w1, (t3,t4) = w2, t5 = lo(w3)
         const unsigned t01 = __builtin_amdgcn_alignbyte(w1, w0, 2), t23 = __builtin_amdgcn_alignbyte(w2, w1, 2),
                        t45 = __builtin_amdgcn_alignbyte(w3, w2, 2);
-        he[r][0] = t01 + 6u * w1 + t23;                  // (he0, he1), he_q = t_q + 6 t_{q+1} + t_{q+2}
-        he[r][1] = t23 + 6u * w2 + t45;                  // (he2, he3)
+        he[r][0] = mad6(w1, t01 + t23);                  // (he0, he1), he_q = t_q + 6 t_{q+1} + t_{q+2}
+        he[r][1] = mad6(w2, t23 + t45);                  // (he2, he3)
         ho[r][0] = 4u * (w1 + t23);                      // (ho0, ho1), ho_q = 4 (t_{q+1} + t_{q+2})
         ho[r][1] = 4u * (w2 + t45);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        ue[2 * q] = rne6_pk(he[0][q] + 6u * he[1][q] + he[2][q]);
-        ue[2 * q + 1] = rne6_pk(ho[0][q] + 6u * ho[1][q] + ho[2][q]);
+        ue[2 * q] = rne6_pk(mad6(he[1][q], he[0][q] + he[2][q]));
+        ue[2 * q + 1] = rne6_pk(mad6(ho[1][q], ho[0][q] + ho[2][q]));
         uo[2 * q] = rne6_pk(4u * (he[1][q] + he[2][q]));
         uo[2 * q + 1] = rne6_pk(4u * (ho[1][q] + ho[2][q]));
     }
@@ -750,16 +750,16 @@ __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, u
         bad |= (w0 & 0xfc000000u) | (w1 & 0xfc00fc00u) | (w2 & 0xfc00fc00u) | (w3 & 0x0000fc00u);   // taps: hi(w0), w1, w2, lo(w3)
         const unsigned t01 = __builtin_amdgcn_alignbyte(w1, w0, 2), t23 = __builtin_amdgcn_alignbyte(w2, w1, 2),
                        t45 = __builtin_amdgcn_alignbyte(w3, w2, 2);
-        he[r][0] = t01 + 6u * w1 + t23;
-        he[r][1] = t23 + 6u * w2 + t45;
+        he[r][0] = mad6(w1, t01 + t23);
+        he[r][1] = mad6(w2, t23 + t45);
         ho[r][0] = 4u * (w1 + t23);
         ho[r][1] = 4u * (w2 + t45);
     }
     if (bad) return false;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        ue[2 * q] = rne6_pk(he[0][q] + 6u * he[1][q] + he[2][q]);
-        ue[2 * q + 1] = rne6_pk(ho[0][q] + 6u * ho[1][q] + ho[2][q]);
+        ue[2 * q] = rne6_pk(mad6(he[1][q], he[0][q] + he[2][q]));
+        ue[2 * q + 1] = rne6_pk(mad6(ho[1][q], ho[0][q] + ho[2][q]));
         uo[2 * q] = rne6_pk(4u * (he[1][q] + he[2][q]));
         uo[2 * q + 1] = rne6_pk(4u * (ho[1][q] + ho[2][q]));
     }
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
 #pragma unroll
         for (int q = 0; q < 4; ++q) accp[c][0][q] = accp[c][1][q] = 0u;
 
-    const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (size_t)y0 * P.qpitch[l] + x0;
+    const size_t pplane = (size_t)P.qh[l] * P.qpitch[l], po = (size_t)f * S.pstride + P.poff[l] + (mul24(y0, P.qpitch[l]) + (unsigned)x0);
     if (MODE == 2) {
         for (int s = 0; s < S.n_parts; ++s)
 #pragma unroll
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[0][k] = w[1][k] = 1.f;       // (unused: the owner path adds L itself)
         } else if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
-            const uint8_t *mp = views[v].wm0 + (size_t)ly * views[v].wm0_pitch + lx;
+            const uint8_t *mp = views[v].wm0 + (mul24(ly, views[v].wm0_pitch) + (unsigned)lx);
             const uint2 ma = *reinterpret_cast<const uint2 *>(mp), mb = *reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch);
             if ((ma.x | ma.y | mb.x | mb.y) == 0u) continue;          // all 16 weights zero: (short)(L * 0) == 0
             int m0[8], m1[8];
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                 w[1][k] = __builtin_fmaf(P.alpha, (float)m1[k], 0.f);
             }
         } else {
-            const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
+            const float *wp = L.wgt + (mul24(ly, L.wpitch) + (unsigned)lx);
             const float4 wa = *reinterpret_cast<const float4 *>(wp), wb = *reinterpret_cast<const float4 *>(wp + 4);
             const float4 wc = *reinterpret_cast<const float4 *>(wp + L.wpitch), wd = *reinterpret_cast<const float4 *>(wp + L.wpitch + 4);
             w[0][0] = wa.x; w[0][1] = wa.y; w[0][2] = wa.z; w[0][3] = wa.w; w[0][4] = wb.x; w[0][5] = wb.y; w[0][6] = wb.z; w[0][7] = wb.w;
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
         }
         const LevelDesc &C = views[v].lv[l + 1];
         const size_t fplane = (size_t)L.h * L.pitch, cplane = (size_t)C.h * C.pitch;
-        const size_t fo = (size_t)ly * L.pitch + lx;
+        const size_t fo = mul24(ly, L.pitch) + (unsigned)lx;
         // the three colour planes are software-pipelined: the reads of plane c+1 (3 coarse rows + 2 fine rows) are issued before
         // plane c is computed, so a view costs about one memory round trip instead of three
         uint4 craw[2][3];
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
     }
     float den[2][8];
     if (owner == 255) {
-        const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
+        const float *dp = P.den[l] + (mul24(y0, P.dpitch[l]) + (unsigned)x0);
         const float4 da = *reinterpret_cast<const float4 *>(dp), db = *reinterpret_cast<const float4 *>(dp + 4);
         const float4 dc = *reinterpret_cast<const float4 *>(dp + P.dpitch[l]), dd = *reinterpret_cast<const float4 *>(dp + P.dpitch[l] + 4);
         den[0][0] = da.x; den[0][1] = da.y; den[0][2] = da.z; den[0][3] = da.w; den[0][4] = db.x; den[0][5] = db.y; den[0][6] = db.z; den[0][7] = db.w;
@@ -964,7 +964,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
 
     if (!L0) {
         const size_t plane = (size_t)P.qh[l] * P.qpitch[l];
-        int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)y0 * P.qpitch[l] + x0;
+        int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (mul24(y0, P.qpitch[l]) + (unsigned)x0);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
         for (int r = 0; r < 2; ++r) {
             const int y = y0 + r;
             if (y >= P.fh) continue;
-            const uint8_t *mrow = P.mask + (size_t)y * P.mask_pitch;
+            const uint8_t *mrow = P.mask + mul24(y, P.mask_pitch);
             int px[8][3];
             const int nvalid = min(8, P.fw - x0);
             int mk[8];
@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                 for (int c = 0; c < 3; ++c) px[k][c] = m ? ((k & 1) ? ((int)resp[c][r][k >> 1] >> 16) : (int)(int16_t)(resp[c][r][k >> 1] & 0xffffu)) : 0;
             }
             if (out.p16[f]) {
-                int16_t *d = (int16_t *)((char *)out.p16[f] + (size_t)y * out.step16[f]) + 3 * x0;
+                int16_t *d = (int16_t *)((char *)out.p16[f] + mul24(y, (int)out.step16[f])) + 3 * x0;
                 if (nvalid == 8) {
                     unsigned wds[12];
 #pragma unroll
@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
             if (out.p8[f]) {
                 const int cy = y + P.canvas_y, cx0 = x0 + P.canvas_x;
                 if (cy >= 0 && cy < P.out_h) {
-                    uint8_t *d = out.p8[f] + (size_t)cy * out.step8[f] + 3 * (size_t)cx0;
+                    uint8_t *d = out.p8[f] + ((long long)mul24(cy, (int)out.step8[f]) + 3 * cx0);
                     if (nvalid == 8 && cx0 >= 0 && cx0 + 8 <= P.out_w) {
                         unsigned wds[6];
 #pragma unroll
@@ -1037,8 +1037,8 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                 if (iy >= 0 && iy < P.i_rows) {
                     constexpr int SH = 20, HALF = 1 << (SH - 1);
                     constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
-                    uint8_t *Yp = out.pi[f] + (size_t)iy * P.out_w;
-                    uint8_t *Up = out.pi[f] + (size_t)P.out_w * P.i_rows + (size_t)(iy >> 1) * (P.out_w >> 1), *Vp = Up + (size_t)(P.out_w >> 1) * (P.i_rows >> 1);
+                    uint8_t *Yp = out.pi[f] + mul24(iy, P.out_w);
+                    uint8_t *Up = out.pi[f] + (size_t)P.out_w * P.i_rows + mul24(iy >> 1, P.out_w >> 1), *Vp = Up + (size_t)(P.out_w >> 1) * (P.i_rows >> 1);
                     const bool crow = (iy & 1) == 0;                       // chroma comes from the top-left pixel of each 2 x 2 block
                     uint8_t yv[8], uv[8], vv[8];
 #pragma unroll
@@ -1434,8 +1434,8 @@ struct ms_ctx {
     DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
-    size_t warp_lds_bytes = 0;         // dynamic LDS of k_warp_t: largest staged source tile
-    int warp_lds_tiles = 0;
+    int warp_lds_tiles = 0;            // tiles whose source bounding box fits a staging buffer of k_warp_a
+    int n_cus = 256;
     double plan_fraction = 1.0;        // needed level-0 pixels / padded pixels
     // CPW mesh maps, double buffered
     DevBuf mesh[2];
@@ -1620,7 +1620,7 @@ static int build_plan(ms_ctx *c)
         if (c->cfg.reserved[2] == 0) xcd_order(tiles);
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
-        c->warp_lds_bytes = 0; c->warp_lds_tiles = 0;
+        c->warp_lds_tiles = 0;
         if (!tiles.empty()) {
             MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
             if (c->warp_tiled) {   // source bounding box of every tile (static: the projection maps do not change per frame)
@@ -1628,7 +1628,17 @@ static int build_plan(ms_ctx *c)
                 MS_LAUNCH_CHECK();
                 MS_HIP(hipMemcpy(tiles.data(), c->warp_tiles.p, tiles.size() * sizeof(WarpTile), hipMemcpyDeviceToHost));
                 for (const WarpTile &t : tiles)
-                    if (t.flags & 1) { c->warp_lds_bytes = std::max(c->warp_lds_bytes, (size_t)warp_lds_pitch(t.sw) * t.sh + 16); ++c->warp_lds_tiles; }
+                    if (t.flags & 1) ++c->warp_lds_tiles;
+                if (getenv("MS_DEBUG_PLAN")) {
+                    int big = 0, last = 0, interior = 0; long long bytes = 0;
+                    for (const WarpTile &t : tiles) {
+                        if (t.flags & 1) bytes += 16ll * warp_lds_np(t.sw) * t.sh;
+                        else if (t.sw > 0 && 16 * warp_lds_np(t.sw) * t.sh > WA_BUF_BYTES) ++big; else ++last;
+                        interior += (t.flags & 4) != 0;
+                    }
+                    fprintf(stderr, "[plan] warp tiles %zu: staged %d (mean %.0f B), box too large %d, last row / empty %d; interior %d\n", tiles.size(), c->warp_lds_tiles,
+                            c->warp_lds_tiles ? (double)bytes / c->warp_lds_tiles : 0.0, big, last, interior);
+                }
             }
         }
     }
@@ -1772,6 +1782,10 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     if (cfg->reserved[5] != 0 && (cfg->reserved[0] == 0 || cfg->enable_cpw)) {
         delete c;
         return fail(MS_ERR_INVALID, "ms_create: the CPU-flavoured remap (reserved[5]) runs in the reference kernels only (reserved[0] = 1) and without CPW");
+    }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c->n_cus = cus;
     }
     if (hipEventCreateWithFlags(&c->last_stitch, hipEventDisableTiming) != hipSuccess) { delete c; return fail(MS_ERR_HIP, "hipEventCreate failed"); }
     *out = c;
@@ -2549,17 +2563,23 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.reserved[0] == 0)
-            MS_PROJ_LAUNCH(k_warp_t, (true, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, 0, (const float2 *)c->tabs.p);
+            MS_PROJ_LAUNCH(k_warp_t, (true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
     } else if (c->warp_tiled && c->cfg.reserved[0] == 0) {
-        int lds_ok = c->cfg.reserved[1] != 0 && c->warp_lds_bytes > 0;   // opt-in: LDS staging of the source tiles (measured slower than direct gathers)
-        for (int i = 0; i < F * N; ++i) lds_ok = lds_ok && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
-        if (lds_ok)
-            MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), c->warp_lds_bytes, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 1, (const float2 *)c->tabs.p);
-        else
-            MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, 0, (const float2 *)c->tabs.p);
+        // opt-in (reserved[1] = 1 or MS_WARP_ASYNC=1): source tiles staged in LDS by asynchronous LDS-DMA, persistent waves (k_warp_a) -- bit-identical,
+        // measured slower than the direct gathers on config 2 (353 vs 242 us per 16 frames: at its 1.6-2.1 x minification only 54 % of the tiles' source
+        // boxes fit a staging buffer and 10 waves per CU cannot hide what 20 do; profiles/r02_warp_probes.txt)
+        static const bool env_on = [] { const char *e = getenv("MS_WARP_ASYNC"); return e && atoi(e) != 0; }();
+        bool staged = c->warp_lds_tiles > 0 && (c->cfg.reserved[1] == 1 || (env_on && c->cfg.reserved[1] != 2));
+        for (int i = 0; i < F * N; ++i) staged = staged && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
+        if (staged) {
+            const long long items = (long long)c->n_warp_tiles * F;
+            const int grid = (int)std::min<long long>(items, (long long)c->n_cus * (160 * 1024 / (2 * WA_BUF_BYTES)));
+            MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+        } else
+            MS_PROJ_LAUNCH(k_warp_t, (false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
     } else if (c->cfg.reserved[5] != 0) {
         k_warp<false, true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

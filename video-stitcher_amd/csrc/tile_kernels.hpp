@@ -172,16 +172,16 @@ __device__ __forceinline__ void warp_coltab4(const ViewDesc &V, int x, float2 ct
     }
 }
 
-// Staged source tile: the tile's source bounding box is copied row by row, PACKED (3 B/px), in 16-byte chunks that are
-// 16-byte aligned in global memory; LDS row pitch in bytes = chunks * 16 with an odd chunk count (bank spread).
-__host__ __device__ __forceinline__ int warp_lds_pitch(int sw)
-{
-    const int chunks = (3 * sw + 15 + 15) / 16 + 1;       // worst-case leading misalignment of 15 bytes, +1 chunk of slack
-    return 16 * (chunks | 1);
-}
-constexpr int WARP_LDS_CAP_BYTES = 36 * 1024;             // 4 workgroups per CU
+// ---- source tile staged in LDS (k_warp_a) ------------------------------------------------------------------------------
+// The source bounding box of a tile is copied row by row, PACKED (3 B/px), in 16-byte chunks that are 16-byte aligned in global
+// memory, by LDS-DMA (global_load_lds_dwordx4: lane i of a wave-instruction lands at base + 16 i, so the LDS image is chunk-linear);
+// a row takes `np` chunk slots, np odd (rows then start on different LDS banks).
+__host__ __device__ __forceinline__ int warp_lds_ncopy(int sw) { return (3 * sw + 15 + 15) / 16; }   // worst-case leading misalignment of 15 bytes
+__host__ __device__ __forceinline__ int warp_lds_np(int sw) { return (warp_lds_ncopy(sw) + 1) | 1; }  // + one chunk of slack for the 12-byte reads
+constexpr int WA_BUF_BYTES = 8 * 1024;                    // one staged tile; a wave owns two (double buffer): 10 waves per CU
 
 // Bounding box (in source pixels) of every in-image bilinear tap of a tile: run once when the tables are built.
+// flags bit 0 = the box fits a staging buffer and does not touch the last image row (whose 16-byte chunks could run past the buffer).
 __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int src_rows, int src_cols)
 {
     __shared__ int s_box[4];
@@ -206,52 +206,47 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
     }
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        if (s_box[1] < 0) { T.sx0 = T.sy0 = T.sw = T.sh = 0; T.flags = 0; }
+        T.flags &= ~1;
+        if (s_box[1] < 0) { T.sx0 = T.sy0 = T.sw = T.sh = 0; }
         else {
             const int sx0 = s_box[0] & ~3;
             const int sw = ((s_box[1] - sx0 + 1) + 3) & ~3, sh = s_box[3] - s_box[2] + 1;
             T.sx0 = (short)sx0; T.sy0 = (short)s_box[2]; T.sw = (short)sw; T.sh = (short)sh;
-            T.flags = (short)((warp_lds_pitch(sw) * sh <= WARP_LDS_CAP_BYTES) ? 1 : 0);
+            if (16 * warp_lds_np(sw) * sh <= WA_BUF_BYTES && s_box[2] + sh < src_rows) T.flags |= 1;
         }
         tiles[blockIdx.x] = T;
     }
 }
 
 // One lane owns WARP_NG groups of 4 consecutive pixels (rows y and y + 16/WARP_NG of the tile): all WARP_NG*8 tap-row
-// loads are in flight together, so a wave pays the memory round trip once for 2x the pixels (the kernel is bound by
-// dependent-load latency x waves in flight, not by bytes).
+// loads are in flight together, so a wave pays the memory round trip once for 2x the pixels.
 #ifndef MS_WARP_NG
 #define MS_WARP_NG 2
 #endif
 constexpr int WARP_NG = MS_WARP_NG;
 constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = WARP_BX x WARP_BY lanes
 
-// PROJ = the context's projection (one per context): a compile-time constant keeps the coordinate code free of per-pixel branches
-template <bool CPW, bool STAGED, int PROJ>
-__global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
-                                                         SrcTable src, int src_rows, int src_cols, MeshTable mesh,
-                                                         const uint8_t *__restrict__ stage, long long stage_stride,
-                                                         uint8_t *__restrict__ g0, long long g0_stride, int lds_ok, const float2 *__restrict__ tabs)
+// One tile of Gaussian level 0 with the taps gathered straight from global memory (unaligned 8-byte reads): lane (tx, ty) of a
+// WARP_BX x WARP_BY arrangement.  Software pipeline over the WARP_NG row groups of the lane -- the tap reads of group g+1 are in
+// flight while group g is blended.  PROJ = the context's projection (compile-time: no per-pixel branches in the coordinate code).
+template <bool CPW, int PROJ>
+__device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
+                                                 const SrcTable &src, int src_rows, int src_cols, const MeshTable &mesh,
+                                                 const uint8_t *__restrict__ stage, long long stage_stride,
+                                                 uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
 {
-    extern __shared__ uint4 s_tile4[];                       // optional staged source tile (packed BGR rows)
-    const WarpTile T = tiles[blockIdx.x];
-    const int f = blockIdx.z, v = T.view;
+    const int v = T.view;
     const ViewDesc &V = views[v];
-    const int x = T.x0 + 4 * (int)threadIdx.x;
+    const int x = T.x0 + 4 * tx;
     int ys[WARP_NG];
     bool active[WARP_NG];
 #pragma unroll
-    for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + (int)threadIdx.y + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
+    for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + ty + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
     const uint8_t *sp;
     unsigned sstep;
     int srows, scols;
     if (CPW) { sp = stage + (size_t)f * stage_stride + V.s1_off; sstep = (unsigned)V.s1_pitch; srows = V.ah; scols = V.aw; }
     else { sp = src.p[f * n_views + v]; sstep = src.step[f * n_views + v]; srows = src_rows; scols = src_cols; }
-    const bool use_lds = STAGED && !CPW && lds_ok && (T.flags & 1);
-
-    if (!STAGED) {
-    // default form: software pipeline over the WARP_NG row groups of the lane -- the tap reads of group g+1 are in flight while
-    // group g is blended (measured 5 % faster than issuing all groups first; the LDS-staged form below is opt-in and slower)
     const LevelDesc &L = V.lv[0];
     const size_t plane = (size_t)L.h * L.pitch;
     float xc[2][4], yc[2][4];
@@ -263,12 +258,12 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
         if (T.flags & 4) {            // interior tile: table addresses come from the tile entry alone, so these loads do not wait for
                                       // the view descriptor (one round trip less on the wave's critical path)
             float4 a, b;
-            const float2 *cp = tabs + T.ctab + 4 * (int)threadIdx.x;
+            const float2 *cp = tabs + T.ctab + 4 * tx;
             __builtin_memcpy(&a, __builtin_assume_aligned(cp, 8), 16);
             __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
             ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g) rt[g] = tabs[T.rtab + (int)threadIdx.y + g * WARP_BY];
+            for (int g = 0; g < WARP_NG; ++g) rt[g] = tabs[T.rtab + ty + g * WARP_BY];
         } else {
             warp_coltab4(V, min(x, V.pw - 4), ct);
 #pragma unroll
@@ -300,13 +295,16 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
 #if defined(MS_PROBE) && MS_PROBE == 1       // roofline probe: same instructions, every tap read from one 4 KiB window (cache resident)
-            const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep) & 0xfffu;
-#else
-            const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
+            off &= 0xfffu;
 #endif
+#if defined(MS_PROBE) && MS_PROBE == 10      // no-gather probe (WRONG pixels): no tap reads at all
+            r1[b][k] = Px2{off, off * 3u}; r2[b][k] = Px2{off ^ 0x55u, off + 7u};
+#else
             r1[b][k] = load_px2(sp, off);
             r2[b][k] = load_px2(sp + sstep, off);
+#endif
         }
     };
     issue(0);
@@ -326,12 +324,7 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
                     t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
                     if (!t[j].fast) fix_border_taps(r1[b][k + j], r2[b][k + j], t[j].x1, t[j].y1, srows, scols);
                 }
-    #if defined(MS_PROBE) && MS_PROBE == 2       // roofline probe: real addresses and loads, no bilinear arithmetic
-                for (int j = 0; j < 2; ++j)
-                    for (int c = 0; c < 3; ++c) o[j][c] = (float)((r1[b][k + j].lo >> (8 * c)) & 0xff) + (float)(r2[b][k + j].hi & 1);
-#else
                 blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
-#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -340,121 +333,217 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
                                         : sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[c]);
             }
             uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
+#if defined(MS_PROBE) && MS_PROBE == 9       // no-store probe: the stores (almost) never execute
+            if (packed[0] == 0x12345678u && packed[1] == 0x9abcdef0u && packed[2] == 0x0fedcba9u)
+#endif
+            {
             *reinterpret_cast<unsigned *>(d) = packed[0];
             *reinterpret_cast<unsigned *>(d + plane) = packed[1];
             *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    return;
-    }
-    float xc[WARP_NG][4], yc[WARP_NG][4];
-#pragma unroll
-    for (int g = 0; g < WARP_NG; ++g) {
-        if (active[g]) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[g], yc[g]);
-        else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) xc[g][k] = yc[g][k] = -1.f;
+}
+
+template <bool CPW, int PROJ>
+__global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                         SrcTable src, int src_rows, int src_cols, MeshTable mesh,
+                                                         const uint8_t *__restrict__ stage, long long stage_stride,
+                                                         uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    warp_tile_direct<CPW, PROJ>(T, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                g0, g0_stride, tabs);
+}
+
+// ---- the same tiles with the source staged in LDS by asynchronous LDS-DMA: persistent, self-pipelined waves -------------------
+// Measured on the direct kernel (profiles/r02_warp_probes.txt): the gathers cost per lane-dword the texture-address path handles
+// (an unaligned 8-byte tap read touches 3 dwords, 48 per lane and tile), and they do not overlap the kernel's other half, its VALU
+// work, at 5 waves per SIMD.  Here a wave stages the bounding box of its NEXT tile (about 4.6 KiB for a 32 x 16 tile at the 1.6 x 1.7
+// minification of config 2 = 18 coalesced dwords per lane) with global_load_lds_dwordx4 -- no VGPRs, no ds_write, completion counted
+// on vmcnt -- while it samples the CURRENT tile out of LDS (ds_read2_b32 + ds_read_b32 per tap row, v_alignbyte to the pixel).
+// The buffers are private to the wave: no barrier anywhere, only the wave's own s_waitcnt.  Tiles whose box does not fit (strong
+// minification) or touches the last image row, and samples with a tap outside the image, take the direct path.
+// Same fp32 operations on the same bytes as warp_tile_direct: bit-identical results.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)      // lds_dst: wave-uniform LDS byte address; lane i lands at + 16 i
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wa_stage(const WarpTile &T, const uint8_t *sp, unsigned sstep, unsigned lds_buf, int lane)
+{
+    const int np = warp_lds_np(T.sw), ncopy = warp_lds_ncopy(T.sw), total = np * T.sh;
+    const float rnp = 1.0f / (float)np;
+    const uint8_t *tile0 = sp + (size_t)T.sy0 * sstep + 3 * (int)T.sx0;
+    for (int q0 = 0; q0 < total; q0 += 64) {
+        const int q = q0 + lane;
+        const int r = (int)(((float)q + 0.5f) * rnp), c = q - r * np;       // (q + 0.5) / np is >= 0.5 / np away from an integer: exact for q < 2^16
+        if (q < total && c < ncopy) {
+            const uintptr_t row = (uintptr_t)(tile0 + (size_t)r * sstep);
+            glds16((const void *)((row & ~(uintptr_t)15) + 16u * (unsigned)c), lds_buf + 16u * (unsigned)q0);
         }
     }
+}
+// the three dwords around the 6 tap bytes at LDS byte offset `off`, as the (lo, hi) pair an unaligned 8-byte global read returns
+__device__ __forceinline__ Px2 lds_px2(const uint8_t *lds, unsigned off)
+{
+    const unsigned *w = reinterpret_cast<const unsigned *>(lds + (off & ~3u));
+    const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
+    const unsigned sh = off & 3u;
+    Px2 px;
+    px.lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    px.hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return px;
+}
 
-    const int lp = warp_lds_pitch(T.sw);                     // bytes
-    const uint8_t *tile0 = sp + (size_t)T.sy0 * sstep + (size_t)T.sx0 * 3;   // first byte of the bounding box
-    if (use_lds) {
-        // cooperative copy global -> LDS: lane (tx, ty) moves 16-byte chunks tx, tx+16, .. of rows ty, ty+BY, ..
-        // (every chunk is 16-byte aligned in global memory and in LDS: one dwordx4 load + one ds_write_b128)
-        uint8_t *lds = reinterpret_cast<uint8_t *>(s_tile4);
-        const int nch = lp >> 4;
-        const uint8_t *img_end = sp + (size_t)(srows - 1) * sstep + (size_t)scols * 3;
-        for (int r = (int)threadIdx.y; r < T.sh; r += WARP_BY) {
-            const uint8_t *row = tile0 + (size_t)r * sstep;
-            const uint8_t *arow = row - ((size_t)row & 15);
-            for (int ch = (int)threadIdx.x; ch < nch; ch += WARP_BX) {
-                const uint8_t *p = arow + 16 * ch;
-                uint4 q;
-                if (p + 16 <= img_end) q = *reinterpret_cast<const uint4 *>(p);
-                else {                                            // last bytes of the last image row: stay inside the buffer
-                    uint8_t tmp[16];
-                    for (int i = 0; i < 16; ++i) tmp[i] = (p + i < img_end) ? p[i] : (uint8_t)0;
-                    __builtin_memcpy(&q, tmp, 16);
-                }
-                *reinterpret_cast<uint4 *>(lds + (size_t)r * lp + 16 * ch) = q;
-            }
-        }
-        __syncthreads();
-    }
-
-    // phase 1: tap addresses -> all WARP_NG*8 row reads in flight.  Only the coordinates and the loaded bytes stay live across
-    // the wait; weights are rebuilt from the coordinates afterwards (2 v_floor per sample instead of 7 registers each).
-    Px2 r1[WARP_NG][4], r2[WARP_NG][4];
-    if (use_lds) {
-        const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_tile4);
-        const unsigned a0 = (unsigned)((size_t)tile0 & 15), astep = sstep & 15;
+// column terms of the lane's 4 pixels and row terms of its row groups, for tile T (loads only: consumed one iteration later)
+__device__ __forceinline__ void wa_tables(const WarpTile &T, const ViewDesc *__restrict__ views, const float2 *__restrict__ tabs, int tx, int ty,
+                                          float2 ct[4], float2 rt[WARP_NG])
+{
+    if (T.flags & 4) {
+        float4 a, b;
+        const float2 *cp = tabs + T.ctab + 4 * tx;
+        __builtin_memcpy(&a, __builtin_assume_aligned(cp, 8), 16);
+        __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
+        ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x1 = f2i_rd(xc[g][k]), y1 = f2i_rd(yc[g][k]);
-                const int lx = min(max(x1 - T.sx0, 0), T.sw - 2), ly = min(max(y1 - T.sy0, 0), T.sh - 2);
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    // byte offset of pixel (ly+rr, lx) inside its staged row = leading misalignment of that row + 3*lx
-                    const unsigned off = (unsigned)(ly + rr) * lp + ((a0 + (unsigned)(ly + rr) * astep) & 15) + 3u * lx;
-                    const unsigned *w = reinterpret_cast<const unsigned *>(lds + (off & ~3u));
-                    const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
-                    const unsigned sh = off & 3u;
-                    Px2 px;
-                    px.lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                    px.hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                    if (rr == 0) r1[g][k] = px; else r2[g][k] = px;
-                }
-            }
+        for (int g = 0; g < WARP_NG; ++g) rt[g] = tabs[T.rtab + ty + g * WARP_BY];
     } else {
+        const ViewDesc &V = views[T.view];
+        warp_coltab4(V, min(T.x0 + 4 * tx, V.pw - 4), ct);
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned off = tap_offset(f2i_rd(xc[g][k]), f2i_rd(yc[g][k]), srows, scols, sstep);      // images are < 4 GiB
-                r1[g][k] = load_px2(sp, off);
-                r2[g][k] = load_px2(sp + sstep, off);
-            }
+        for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(T.y0 + ty + g * WARP_BY, V.ph - 1) - V.top, V.ah)];
     }
-    // phase 2: weights, border fix-up, 4 fmas per channel (two samples per v_pk_fma_f32), gain, pack, store
-    const LevelDesc &L = V.lv[0];
-    const size_t plane = (size_t)L.h * L.pitch;
+}
+
+template <int PROJ>
+__global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tiles, int n_tiles, const ViewDesc *__restrict__ views, int n_views,
+                                               SrcTable src, int srows, int scols, uint8_t *__restrict__ g0, long long g0_stride,
+                                               const float2 *__restrict__ tabs, int n_frames)
+{
+    extern __shared__ uint4 s_wa[];                           // 2 x WA_BUF_BYTES
+    const uint8_t *lds = reinterpret_cast<const uint8_t *>(s_wa);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)s_wa);
+    const int lane = (int)threadIdx.x, tx = lane & (WARP_BX - 1), ty = lane / WARP_BX;
+    const int stride = (int)gridDim.x;
+    auto advance = [&](int &t_, int &f_) { t_ += stride; while (t_ >= n_tiles) { t_ -= n_tiles; ++f_; } };
+    int t = (int)blockIdx.x - stride, f = 0;
+    advance(t, f);
+    if (f >= n_frames) return;
+    int tn = t, fn = f;
+    advance(tn, fn);
+    WarpTile T = tiles[t], Tn = tiles[fn < n_frames ? tn : t];
+    float2 ct[4], rt[WARP_NG];
+    wa_tables(T, views, tabs, tx, ty, ct, rt);
+    int buf = 0;
+    if (T.flags & 1) wa_stage(T, src.p[f * n_views + T.view], src.step[f * n_views + T.view], lds0, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the first tile has landed
+    MeshTable none{};
+    for (;;) {
+        // the NEXT tile of this wave: its tables (ordinary loads, consumed one iteration later) and then its staging copy into the other
+        // buffer, in flight while this tile is sampled.  Nothing issued after the copy is waited for before the s_waitcnt below.
+        const bool more = fn < n_frames;
+        float2 ctn[4], rtn[WARP_NG];
+        if (more) {
+            wa_tables(Tn, views, tabs, tx, ty, ctn, rtn);
+            if (Tn.flags & 1) wa_stage(Tn, src.p[fn * n_views + Tn.view], src.step[fn * n_views + Tn.view], lds0 + (unsigned)((buf ^ 1) * WA_BUF_BYTES), lane);
+        } else {
 #pragma unroll
-    for (int g = 0; g < WARP_NG; ++g) {
-        if (!active[g]) continue;
-        unsigned packed[3] = {0, 0, 0};
+            for (int k = 0; k < 4; ++k) ctn[k] = ct[k];
 #pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-            float o[2][3];
-            Taps t[2];
+            for (int g = 0; g < WARP_NG; ++g) rtn[g] = rt[g];
+        }
+        int tnn = tn, fnn = fn;                                // descriptor two tiles ahead (scalar load: its latency hides behind this tile)
+        advance(tnn, fnn);
+        const WarpTile Tnn = tiles[fnn < n_frames ? tnn : t];
+        if (!(T.flags & 1)) {
+            warp_tile_direct<false, PROJ>(T, f, tx, ty, views, n_views, src, srows, scols, none, nullptr, 0, g0, g0_stride, tabs);
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // the staging copy of the next tile has landed
+        } else {
+            const int v = T.view;
+            const ViewDesc &V = views[v];
+            const int x = T.x0 + 4 * tx;
+            const uint8_t *sp = src.p[f * n_views + v];
+            const unsigned sstep = src.step[f * n_views + v];
+            const uint8_t *lb = lds + buf * WA_BUF_BYTES;
+            const unsigned pitch = 16u * (unsigned)warp_lds_np(T.sw);
+            const unsigned a0 = (unsigned)(((uintptr_t)sp + (size_t)T.sy0 * sstep + 3u * (unsigned)T.sx0) & 15u), astep = sstep & 15u;
+            int ys[WARP_NG];
+            bool active[WARP_NG];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                t[j] = make_taps(xc[g][k + j], yc[g][k + j], srows, scols);
-                if (!t[j].fast) {                 // a tap outside the image (or invalid coordinates)
-                    if (use_lds) {                // (the staged box only covers interior samples)
-                        const unsigned off = tap_offset(t[j].x1, t[j].y1, srows, scols, sstep);
-                        r1[g][k + j] = load_px2(sp, off);
-                        r2[g][k + j] = load_px2(sp + sstep, off);
+            for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + ty + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
+            float xc[WARP_NG][4], yc[WARP_NG][4];
+            Px2 r1[WARP_NG][4], r2[WARP_NG][4];
+            bool slow = false;
+#pragma unroll
+            for (int g = 0; g < WARP_NG; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (active[g]) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[g][k], yc[g][k]);
+                    else xc[g][k] = yc[g][k] = -1.f;
+                    const int x1 = f2i_rd(xc[g][k]), y1 = f2i_rd(yc[g][k]);
+                    const bool fast = (unsigned)x1 < (unsigned)(scols - 2) && (unsigned)y1 < (unsigned)(srows - 1);
+                    slow = slow || (active[g] && !fast);
+                    // inside the staged box for every sample the box was built from (active and fast); clamped so that the others read valid LDS
+                    const int lx = min(max(x1 - (int)T.sx0, 0), (int)T.sw - 2), ly = min(max(y1 - (int)T.sy0, 0), (int)T.sh - 2);
+                    const unsigned o1 = (unsigned)ly * pitch + ((a0 + (unsigned)ly * astep) & 15u) + 3u * (unsigned)lx;
+                    const unsigned o2 = (unsigned)(ly + 1) * pitch + ((a0 + (unsigned)(ly + 1) * astep) & 15u) + 3u * (unsigned)lx;
+                    r1[g][k] = lds_px2(lb, o1);
+                    r2[g][k] = lds_px2(lb, o2);
+                }
+            if (__builtin_amdgcn_ballot_w64(slow)) {            // a tap outside the image somewhere in the wave: those samples re-read from global memory
+#pragma unroll
+                for (int g = 0; g < WARP_NG; ++g)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const Taps tt = make_taps(xc[g][k], yc[g][k], srows, scols);
+                        if (active[g] && !tt.fast) {
+                            const unsigned off = tap_offset(tt.x1, tt.y1, srows, scols, sstep);
+                            r1[g][k] = load_px2(sp, off);
+                            r2[g][k] = load_px2(sp + sstep, off);
+                            fix_border_taps(r1[g][k], r2[g][k], tt.x1, tt.y1, srows, scols);
+                        }
                     }
-                    fix_border_taps(r1[g][k + j], r2[g][k + j], t[j].x1, t[j].y1, srows, scols);
+            }
+            const LevelDesc &L = V.lv[0];
+            const size_t plane = (size_t)L.h * L.pitch;
+            unsigned packed[WARP_NG][3];
+#pragma unroll
+            for (int g = 0; g < WARP_NG; ++g) {
+                packed[g][0] = packed[g][1] = packed[g][2] = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    float o[2][3];
+                    const Taps t0 = make_taps(xc[g][k], yc[g][k], srows, scols), t1 = make_taps(xc[g][k + 1], yc[g][k + 1], srows, scols);
+                    blend_taps2(t0, t1, r1[g][k], r2[g][k], r1[g][k + 1], r2[g][k + 1], o[0], o[1]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            packed[g][c] = sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[g][c]);
                 }
             }
-            blend_taps2(t[0], t[1], r1[g][k], r2[g][k], r1[g][k + 1], r2[g][k + 1], o[0], o[1]);
+            // everything this wave has asked of the vector memory path has landed: the next tile's tables and staging copy (they had this
+            // tile's sampling to arrive) and, long ago, the previous tile's stores.  Only then are this tile's stores issued: they stay
+            // in flight across the next iteration.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    packed[c] = CPW ? sat_u8_into(o[j][c], k + j, packed[c])
-                                    : sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[c]);
-            }
+            for (int g = 0; g < WARP_NG; ++g)
+                if (active[g]) {
+                    uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
+                    *reinterpret_cast<unsigned *>(d) = packed[g][0];
+                    *reinterpret_cast<unsigned *>(d + plane) = packed[g][1];
+                    *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[g][2];
+                }
         }
-        uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
-        *reinterpret_cast<unsigned *>(d) = packed[0];
-        *reinterpret_cast<unsigned *>(d + plane) = packed[1];
-        *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+        if (!more) break;
+        T = Tn; t = tn; f = fn; Tn = Tnn; tn = tnn; fn = fnn; buf ^= 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ct[k] = ctn[k];
+#pragma unroll
+        for (int g = 0; g < WARP_NG; ++g) rt[g] = rtn[g];
     }
 }
 
@@ -589,8 +678,8 @@ __device__ __forceinline__ uint2 down_hpass(const Down7 &v)
         o01 = __builtin_amdgcn_perm(v.a[1], v.a[0], 0x07060302u); o12 = __builtin_amdgcn_perm(v.a[2], v.a[1], 0x07060302u);
         o23 = __builtin_amdgcn_perm(v.a[3], v.a[2], 0x07060302u); o34 = __builtin_amdgcn_perm(v.a[4], v.a[3], 0x07060302u);
     }
-    const unsigned s01 = e01 + 6u * e12 + e23 + 4u * (o01 + o12);
-    const unsigned s23 = e23 + 6u * e34 + e45 + 4u * (o23 + o34);
+    const unsigned s01 = mad6(e12, e01 + e23 + 4u * (o01 + o12));
+    const unsigned s23 = mad6(e34, e23 + e45 + 4u * (o23 + o34));
     return make_uint2(rne8_pk(s01), rne8_pk(s23));
 }
 
@@ -626,7 +715,7 @@ __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ til
     for (int o = 0; o < RO; ++o) {                          // vertical 1 4 6 4 1 of input rows 2o .. 2o+4
         Down7 vv;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) vv.a[k] = (r[2 * o].a[k] + r[2 * o + 4].a[k]) + 4u * (r[2 * o + 1].a[k] + r[2 * o + 3].a[k]) + 6u * r[2 * o + 2].a[k];
+        for (int k = 0; k < 7; ++k) vv.a[k] = mad6(r[2 * o + 2].a[k], (r[2 * o].a[k] + r[2 * o + 4].a[k]) + 4u * (r[2 * o + 1].a[k] + r[2 * o + 3].a[k]));
         if (o < nrow) *reinterpret_cast<uint2 *>(out + (size_t)o * Lo.pitch) = down_hpass<TIN>(vv);
     }
 }

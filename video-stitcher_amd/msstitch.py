@@ -414,11 +414,11 @@ class Compositor:
     """stitch_calib tables once (build_maps / build_masks / init_blender), then stitch() per frame batch."""
 
     def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
-                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=False, shards=1, shard_index=0, cv_remap=False):
+                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=None, shards=1, shard_index=0, cv_remap=False):
         cfg = Config(num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
                      out_size[0], out_size[1], max_frames)
         cfg.reserved[0] = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
-        cfg.reserved[1] = 1 if lds_stage else 0        # opt-in: stage the warp kernel's source tiles through LDS
+        cfg.reserved[1] = 0 if lds_stage is None else (1 if lds_stage else 2)   # True: warp source tiles staged in LDS by LDS-DMA (opt-in, measured slower); False forces the direct gathers even under MS_WARP_ASYNC=1
         cfg.reserved[3] = shards; cfg.reserved[4] = shard_index   # view sharding
         cfg.reserved[5] = 1 if cv_remap else 0         # cv::remap's CPU arithmetic for the projection warp (needs simple_kernels, no CPW)
         self._ctx = C.c_void_p()
