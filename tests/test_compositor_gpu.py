@@ -514,3 +514,50 @@ def test_stitch_i420_needs_the_tiled_band_path(ms, cuda):
     with pytest.raises(ms.MsError):
         comp.stitch_i420(frames, comp.new_i420(1))
     comp.close()
+
+
+def test_create_destroy_cycles_release_device_memory(ms, cuda):
+    """Every device buffer of a context belongs to it (RAII): create -> calibrate -> set meshes -> update_mask -> stitch -> destroy,
+    repeated, must not lower the free device memory (owner maps, re-warped masks and the mesh displacement words used to leak)."""
+    def cycle():
+        comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 6, 6, phase=0.3 * i, amp=3.0))
+        comp.update_mask(1)
+        pg = comp.pano_geom()
+        out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+        comp.stitch([[to_dev(synth.frame(cfg["w"], cfg["h"], i, 0)) for i in range(cfg["n"])]], out16s=[out16])
+        torch.cuda.synchronize()
+        comp.close()
+        del out16
+    cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (1 << 20), "six create/destroy cycles lost %d bytes of device memory" % (free0 - free1)
+
+
+def test_second_stream_is_ordered_behind_the_first(ms, cuda):
+    """A context has one set of per-batch intermediates: a call on another stream than the previous one waits for it on the GPU
+    (the reference creates a fresh cuda::Stream per stitch_online call), so back-to-back calls on two streams stay correct."""
+    import ctypes
+    comp, cfg, gains = make_rig(ms, "mini6")
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    fa = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 1)) for i in range(cfg["n"])]]
+    fb = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 2)) for i in range(cfg["n"])]]
+    want = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(2)]
+    comp.stitch(fa, out16s=[want[0]]); torch.cuda.synchronize()
+    comp.stitch(fb, out16s=[want[1]]); torch.cuda.synchronize()
+    got = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(2)]
+    s1, s2 = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    ra, rb = comp.prepared(fa, out16s=[got[0]]), comp.prepared(fb, out16s=[got[1]])
+    for _ in range(20):
+        ra(ctypes.c_void_p(s1.cuda_stream)); rb(ctypes.c_void_p(s2.cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    comp.close()

@@ -32,8 +32,12 @@ int require_device();
 struct PinnedScratch {
     void *p = nullptr;
     size_t cap = 0;
+    int dev = -1;                 // the block belongs to the device that was current when it was allocated
     void *get(size_t n)
     {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; dev = cur; }
         if (n > cap) {
             if (p) (void)hipHostFree(p);
             p = nullptr; cap = 0;
@@ -52,8 +56,15 @@ PinnedScratch &pinned_scratch();
 struct DeviceScratch {
     void *p = nullptr;
     size_t cap = 0;
+    int dev = -1;                 // a thread that switches devices (hipSetDevice) must not reuse another GPU's block
     void *get(size_t n)
     {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) {         // (the old block is freed on its own device)
+            if (p) { if (dev >= 0) (void)hipSetDevice(dev); (void)hipFree(p); (void)hipSetDevice(cur); }
+            p = nullptr; cap = 0; dev = cur;
+        }
         if (n > cap) {
             if (p) (void)hipFree(p);
             p = nullptr; cap = 0;
@@ -193,10 +204,11 @@ __device__ __forceinline__ void warp_combine(int proj, const float2 c, const flo
     oy = __builtin_fmaf(P.k[5], z_, __builtin_fmaf(P.k[4], y_, P.k[3] * x_));
     const float oz = __builtin_fmaf(P.k[8], z_, __builtin_fmaf(P.k[7], y_, P.k[6] * x_));
     // Divide unconditionally and select (no trap on the GPU): straight-line code instead of a divergent block per pixel.  x/z and y/z
-    // share the denominator: one refined reciprocal (rcp + 2 Newton steps) and, per numerator, quotient + 2 residual corrections -- the
-    // compiler's own correctly rounded sequence without the div_scale / div_fixup wrappers, i.e. the same bits whenever z and the
-    // quotients are in the normal range (always, for a pixel that can land in an image).  The dense-map kernels (ms_build_maps,
-    // ms_build_warp_maps) and the per-frame kernels all go through this function, so they agree bit for bit by construction.
+    // share the denominator: one refined reciprocal (v_rcp_f32 + ONE Newton step) and, per numerator, quotient + two residual corrections.
+    // This is NOT claimed to be IEEE division for every operand (no div_scale / div_fixup, one refinement step): what the results contract
+    // needs is that every kernel that produces map coordinates -- the dense-map kernels (ms_build_maps, ms_build_warp_maps) and the
+    // per-frame kernels -- goes through this one function, so that they agree bit for bit by construction; against the oracle's glibc
+    // maps the tolerance is 1e-3 px.
     const bool ok = proj == MS_PROJ_PLANE || oz > 0;
     const float r0 = __builtin_amdgcn_rcpf(oz);
     const float e0 = __builtin_fmaf(-oz, r0, 1.f);
@@ -211,11 +223,12 @@ __device__ __forceinline__ void warp_combine(int proj, const float2 c, const flo
 }
 
 // ---- IEEE fp32 division with the reciprocal shared between numerators -----------------------------------
-// normalizeUsingWeightKernel32F divides the three colour channels of a pixel by the same (w + 1e-5).  The
-// compiler's correctly-rounded division is  rcp -> 2 Newton steps on the reciprocal -> quotient -> 2 residual
-// corrections (plus div_scale/div_fixup for extreme exponents, which cannot occur here: |a| <= 32768,
-// 1e-5 <= d < 64).  DivBy keeps the refined reciprocal and repeats only the quotient part per channel: the same
-// fp32 operations, hence the same bits (checked exhaustively over all int16 numerators by ms_selftest_divide).
+// normalizeUsingWeightKernel32F divides the three colour channels of a pixel by the same (w + 1e-5).  DivBy refines the
+// hardware reciprocal with ONE Newton step, forms the quotient and applies two residual corrections; there is no
+// div_scale / div_fixup (|a| <= 32768 and 1e-5 <= d < 64: no extreme exponents).  That this equals the compiler's correctly
+// rounded a / d bit for bit is NOT argued from the instruction sequence: it is checked -- ms_selftest_divide compares both
+// over all 65536 int16 numerators for every denominator handed to it, and ms_init_blender runs that check over the distinct
+// denominators of the context's own tables (MS_CHECK_DIVIDE=1, on by default in the test suite).
 struct DivBy {
     float d, r;
     __device__ __forceinline__ explicit DivBy(float den) : d(den)

@@ -18,6 +18,7 @@
 // the 16S pyramids are evaluated in exact integer arithmetic, accumulate/normalise keep the fp32
 // multiply/divide + truncation, and int16 accumulation wraps exactly like `short +=`.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -1361,8 +1362,13 @@ __global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long lo
 }
 
 // ------------------------------------------------------------------------------------------------
+// an owned device allocation: released with its owner (ms_ctx members, function-local scratch), never copied
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     int alloc(size_t n)
     {
         release();
@@ -1445,9 +1451,11 @@ struct ms_ctx {
     DevBuf mesh_tmp;                   // scratch for convertMeshesToMap: vertex mesh x|y, two half-resolution accumulators ([count:24|sum_x:40], [sum_y]) used in turn
     size_t mesh_small_cap = 0, mesh_half_cap = 0, mesh_dirty = 0;   // capacities (floats / cells); 64-bit words the previous update dirtied in its accumulator
     int mesh_parity = 0;
-    std::mutex mesh_mu;
+    std::mutex mesh_mu;                // guards the active indices / events shared with ms_stitch: held only across enqueues, never across a host wait
+    std::mutex mesh_update_mu;         // serialises mesh updates among themselves (shared scratch, staging slots); taken BEFORE mesh_mu
+    hipStream_t last_stream = nullptr; bool last_stream_set = false;
     hipEvent_t last_stitch = nullptr;
-    bool stitch_pending = false;
+    std::atomic<bool> stitch_pending{false};
     // asynchronous recalibration: a mesh update only enqueues work; `mesh_ready[v]` is recorded behind it and the next ms_stitch makes
     // its stream wait for it; `mesh_chain` orders updates among themselves (they share the scratch and the staging buffers)
     hipEvent_t mesh_ready[MAX_VIEWS] = {}, mesh_chain = nullptr;
@@ -1796,11 +1804,7 @@ void ms_destroy(ms_ctx *c)
 {
     if (!c) return;
     (void)hipDeviceSynchronize();
-    c->maps.release(); c->tabs.release(); c->masks.release(); c->weights.release(); c->wm0.release(); c->den.release(); c->result_mask.release();
-    c->view_tab.release(); c->g0.release(); c->gl.release(); c->cl.release(); c->stage.release();
-    c->mesh[0].release(); c->mesh[1].release(); c->mesh_tmp.release();
-    c->warp_tiles.release(); c->stage1_tiles.release();
-    for (int l = 0; l < MAX_LEVELS; ++l) { c->down_tiles[l].release(); c->blend_tiles[l].release(); }
+    // every DevBuf member (tables, per-batch pyramids, work lists, masks_eff, pure_maps, disp_dev, mesh buffers) frees itself in ~ms_ctx
     if (c->last_stitch) (void)hipEventDestroy(c->last_stitch);
     for (int v = 0; v < MAX_VIEWS; ++v) if (c->mesh_ready[v]) (void)hipEventDestroy(c->mesh_ready[v]);
     if (c->mesh_chain) (void)hipEventDestroy(c->mesh_chain);
@@ -2257,6 +2261,20 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     if (int e = c->view_tab.alloc(sizeof(ViewDesc) * N)) return e;
     MS_HIP(hipMemcpy(c->view_tab.p, c->h_views.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice));
     if (int e = build_plan(c)) return e;
+    if (const char *chk = getenv("MS_CHECK_DIVIDE")) if (atoi(chk) != 0) {
+        // the band kernels' shared-reciprocal division against the compiler's IEEE a / d, over every distinct denominator these tables hold
+        // and all int16 numerators (common.hpp, DivBy): the bit-exactness claim rests on this check, not on an argument about the sequence
+        std::vector<float> hd(den_total);
+        MS_HIP(hipMemcpy(hd.data(), c->den.p, den_total * sizeof(float), hipMemcpyDeviceToHost));
+        std::sort(hd.begin(), hd.end());
+        hd.erase(std::unique(hd.begin(), hd.end()), hd.end());
+        for (size_t i = 0; i < hd.size(); i += 65535) {
+            const int n = (int)std::min<size_t>(65535, hd.size() - i);
+            const int bad = ms_selftest_divide(hd.data() + i, n, stream);
+            if (bad < 0) return bad;
+            if (bad > 0) return fail(MS_ERR_INVALID, "ms_init_blender: shared-reciprocal division differs from IEEE division for %d (numerator, denominator) pairs", bad);
+        }
+    }
     c->blender_ready = true;
     return MS_OK;
 }
@@ -2307,9 +2325,12 @@ static ms_image mesh_image(const ms_ctx *c, int buf, int v, int which)
     return ms_image{base, (size_t)c->map_pitch[v] * sizeof(float), ah, aw, MS_32FC1};
 }
 
+// Callers hold mesh_update_mu (one update at a time).  mesh_mu is taken here only around the bookkeeping ms_stitch shares: ms_stitch holds it from
+// picking the active buffers up to recording last_stitch, so `last_stitch` seen here covers every stitch that may still read the inactive buffer.
 static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st)
 {
     if (!c->blender_ready || !c->cfg.enable_cpw) return fail(MS_ERR_STATE, "mesh update needs enable_cpw and ms_init_blender");
+    std::lock_guard<std::mutex> lk(c->mesh_mu);
     *target = c->mesh_set[view] ? 1 - c->mesh_active[view] : c->mesh_active[view];
     if (!c->mesh_ready[view]) MS_HIP(hipEventCreateWithFlags(&c->mesh_ready[view], hipEventDisableTiming));
     if (!c->mesh_chain) MS_HIP(hipEventCreateWithFlags(&c->mesh_chain, hipEventDisableTiming));
@@ -2322,6 +2343,7 @@ static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st)
 static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st, bool measure = true)
 {
     if (measure) if (int e = measure_mesh_disp(c, view, tgt, st)) return e;
+    std::lock_guard<std::mutex> lk(c->mesh_mu);
     MS_HIP(hipEventRecord(c->mesh_ready[view], st));
     MS_HIP(hipEventRecord(c->mesh_chain, st));
     c->mesh_chain_set = true;
@@ -2335,7 +2357,7 @@ int ms_set_mesh_maps(ms_ctx *c, int view, const ms_image *xm, const ms_image *ym
 {
     if (int e = ctx_check_view(c, view)) return e;
     MS_CHECK(xm && ym && xm->data && ym->data, "ms_set_mesh_maps: null image");
-    std::lock_guard<std::mutex> lk(c->mesh_mu);
+    std::lock_guard<std::mutex> lk(c->mesh_update_mu);
     int tgt;
     hipStream_t st = as_stream(stream);
     const int aw = c->roi[view].width, ah = c->roi[view].height;
@@ -2352,7 +2374,7 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
 {
     if (int e = ctx_check_view(c, view)) return e;
     MS_CHECK(mesh_x && mesh_y && N >= 2 && M >= 2, "ms_set_mesh: need an N x M (>= 2x2) vertex mesh");
-    std::lock_guard<std::mutex> lk(c->mesh_mu);
+    std::lock_guard<std::mutex> lk(c->mesh_update_mu);       // (ms_stitch never takes this one: the waits and allocations below cannot stall it)
     int tgt;
     hipStream_t st = as_stream(stream);
     const int aw = c->roi[view].width, ah = c->roi[view].height, hw = aw / 2, hh = ah / 2;
@@ -2386,7 +2408,9 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     unsigned long long *ax = acc, *ay = acc + n_half;
     // the caller's arrays may be freed right after return: stage them in pinned memory (one slot per view; a slot is reused only by
     // the next update of the same view, whose copy of the previous one finished long before -- checked on its event)
-    if (c->mesh_wait[view] || c->mesh_set[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    bool slot_busy;
+    { std::lock_guard<std::mutex> mk(c->mesh_mu); slot_busy = c->mesh_ready[view] && (c->mesh_wait[view] || c->mesh_set[view]); }
+    if (slot_busy) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     float *stg = c->mesh_stage + (size_t)view * c->mesh_stage_floats;
     memcpy(stg, mesh_x, n_small * 4);
     memcpy(stg + n_small, mesh_y, n_small * 4);
@@ -2426,6 +2450,7 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
     if (int e = ctx_check_view(c, view)) return e;
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view]) return fail(MS_ERR_STATE, "ms_update_mask: needs enable_cpw, ms_init_blender and a mesh for view %d", view);
     hipStream_t st = as_stream(stream);
+    std::lock_guard<std::mutex> ulk(c->mesh_update_mu);
     if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
     if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
@@ -2435,7 +2460,9 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
     const int aw = c->roi[view].width, ah = c->roi[view].height;
     ms_image src{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)aw, ah, aw, MS_8UC1};
     ms_image dst{(uint8_t *)c->masks_eff.p + c->mask_off[view], (size_t)aw, ah, aw, MS_8UC1};
-    ms_image mx = mesh_image(c, c->mesh_active[view], view, 0), my = mesh_image(c, c->mesh_active[view], view, 1);
+    int active;
+    { std::lock_guard<std::mutex> mk(c->mesh_mu); active = c->mesh_active[view]; }
+    ms_image mx = mesh_image(c, active, view, 0), my = mesh_image(c, active, view, 1);
     if (int e = launch_remap(src, mx, my, dst, MS_INTER_LINEAR, MS_BORDER_CONSTANT, st)) return e;
     MS_HIP(hipStreamSynchronize(st));
     c->use_eff[view] = true;
@@ -2446,7 +2473,7 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
 {
     if (int e = ctx_check_view(c, view)) return e;
     MS_CHECK(out_px != nullptr, "ms_get_mesh_displacement: null output");
-    std::lock_guard<std::mutex> lk(c->mesh_mu);
+    std::lock_guard<std::mutex> lk(c->mesh_update_mu);       // no update in flight while we look; ms_stitch is not blocked by this lock
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view] || !c->disp_dev.p) return fail(MS_ERR_STATE, "ms_get_mesh_displacement: no mesh set for view %d", view);
     if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     float *h = (float *)pinned_scratch().get(sizeof(float));          // pinned landing zone: see PinnedScratch (common.hpp)
@@ -2521,8 +2548,11 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     const bool cpw = c->cfg.enable_cpw != 0;
     DispTable disp{};
     { const float lim = (float)CPW_DMAX; memcpy(&disp.limit_bits, &lim, 4); }
+    // CPW: mesh_mu is held from here to the hipEventRecord(last_stitch) at the end of the enqueue (RAII): a mesh update that starts meanwhile
+    // sees this stitch in last_stitch before it may touch the buffer this stitch reads.  Only enqueues happen under the lock.
+    std::unique_lock<std::mutex> mesh_lk(c->mesh_mu, std::defer_lock);
     if (cpw) {
-        std::lock_guard<std::mutex> lk(c->mesh_mu);
+        mesh_lk.lock();
         for (int v = 0; v < N; ++v) {
             if (!c->mesh_set[v]) return fail(MS_ERR_STATE, "ms_stitch: enable_cpw is set but view %d has no mesh", v);
             disp.p[v] = (const unsigned *)c->disp_dev.p + 2 * v + c->mesh_active[v];
@@ -2531,6 +2561,11 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             mesh.x[v] = (const float *)mx.data; mesh.y[v] = (const float *)my.data; mesh.pitch[v] = c->map_pitch[v];
         }
     }
+
+    // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
+    // (the reference makes a fresh cuda::Stream per stitch_online call, timed.cpp:64, and relies on the NULL stream for ordering)
+    if (c->last_stream_set && c->last_stream != st && c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
+    c->last_stream = st; c->last_stream_set = true;
 
     const ViewDesc *vt = (const ViewDesc *)c->view_tab.p;
     const uint8_t *g0 = (const uint8_t *)c->g0.p;
