@@ -12,8 +12,9 @@
  * maintainer adds so that timed.cpp-style callers compile unchanged.
  *
  * Conventions
- *   - ms_image is bit-compatible with cv::cuda::PtrStepSz<T> + the OpenCV type code, i.e. it can be
- *     filled from a cv::cuda::GpuMat without copying: {m.data, m.step, m.rows, m.cols, m.type()}.
+ *   - ms_image has the fields of cv::cuda::PtrStepSz<T> in the reference's own order -- {data, step} (PtrStep, cuda_types.hpp:95-107) then
+ *     {cols, rows} (PtrStepSz, :109-120) -- followed by the OpenCV type code: it is filled from a cv::cuda::GpuMat without copying,
+ *     {m.data, m.step, m.cols, m.rows, m.type()}, and the kernels' by-value PtrStepSz arguments map onto its first four fields.
  *     All ms_image pointers are DEVICE pointers unless a parameter says "host".
  *   - ms_stream is a hipStream_t (NULL = the default stream).  Calls only enqueue work.
  *   - Every function returns MS_OK (0) or a negative ms_status; ms_last_error() returns the
@@ -54,10 +55,10 @@ enum { MS_INTER_NEAREST = 0, MS_INTER_LINEAR = 1,
 /* warper kinds: detail::{Plane,Cylindrical,Spherical}WarperGpu (OCV/stitching/include/opencv2/stitching/detail/warpers.hpp:435-550) */
 enum { MS_PROJ_PLANE = 0, MS_PROJ_CYLINDRICAL = 1, MS_PROJ_SPHERICAL = 2 };
 
-typedef struct ms_image {   /* == PtrStepSz<T> (OCV/core/include/opencv2/core/cuda_types.hpp:95-120) + type */
+typedef struct ms_image {   /* PtrStepSz<T> field for field (OCV/core/include/opencv2/core/cuda_types.hpp:95-120), then the type code */
     void *data;
     size_t step;            /* row pitch in bytes */
-    int rows, cols;
+    int cols, rows;         /* PtrStepSz order: cols first */
     int type;
 } ms_image;
 
@@ -182,6 +183,7 @@ MS_API int ms_result_roi(int n, const ms_rect *view_rois, ms_rect *roi);
 typedef struct ms_ctx ms_ctx;
 
 typedef struct ms_config {
+    unsigned struct_size;   /* sizeof(ms_config) of the caller's header: ms_create rejects a mismatch (ABI guard)  */
     int num_views;          /* NUM_IMAGES (APP/defs.h:37)                                             */
     int src_width, src_height;   /* camera frame size (after the optional compose_scale resize)       */
     int projection;         /* MS_PROJ_*: the app ships cylindrical (APP/calibration.cpp:100,156)     */
@@ -190,10 +192,15 @@ typedef struct ms_config {
     int enable_cpw;         /* enable_local (APP/defs.h:27): second remap through the mesh maps       */
     int out_width, out_height;   /* equirect canvas (0,0 = emit the pano ROI only)                     */
     int max_frames;         /* frames batched per ms_stitch call (1 = live; >1 amortises launches)    */
-    int reserved[8];        /* [0] != 0: debug, run the simple one-pixel-per-lane kernels instead of the tiled ones;
-                             * [1] != 0: stage the warp kernel's source tiles through LDS (measured slower);
-                             * [2] != 0: keep the work lists in raster order instead of the XCD-aware order;
-                             * [3], [4]: view sharding (shard count, shard index), see ms_stitch_partial */
+    int view_shards;        /* 0 / 1 = this context composites whole frames; S = 2..4: it owns one shard of the views (ms_stitch_partial) */
+    int view_shard_index;   /* which shard, 0 .. S-1                                                   */
+    int cpu_flavour_remap;  /* != 0: the projection warp uses cv::remap's CPU arithmetic (1/32-px coordinates, 15-bit weights): the
+                             * reference's CPU pipeline of BASELINE configs[0]; needs debug_simple_kernels and no CPW; changes results BY DESIGN */
+    /* developer knobs: none of them changes a result */
+    int debug_simple_kernels;    /* != 0: the one-pixel-per-lane reference kernels instead of the tiled ones      */
+    int warp_lds_stage;          /* 0: direct tap gathers (default); 1: source tiles staged in LDS by LDS-DMA (k_warp_a, measured slower on config 2); 2: never stage */
+    int raster_tile_order;       /* != 0: work lists in raster order instead of the XCD-aware order               */
+    int reserved[4];             /* must be 0 */
 } ms_config;
 
 MS_API int ms_create(const ms_config *cfg, ms_ctx **out);
@@ -273,7 +280,7 @@ MS_API int ms_feed(ms_ctx *ctx, int view, const ms_image *img, ms_stream stream)
 MS_API int ms_blend(ms_ctx *ctx, ms_image *out8u, ms_image *out16s, ms_stream stream);
 
 /* View sharding (BASELINE configs[4]): create every rank's context with the SAME cameras/masks and
- * ms_config.reserved[3] = number of shards S (<= 4), reserved[4] = this rank's shard index; shard k owns the contiguous block
+ * ms_config.view_shards = number of shards S (<= 4), view_shard_index = this rank's shard index; shard k owns the contiguous block
  * of views [k*N/S, (k+1)*N/S).  The weighted accumulation into the dst Laplacian pyramid is a sum of int16 terms
  * (multiband_blend.cu:46-49), so each rank writes the partial sums of its views (ms_stitch_partial; entries of `views` for
  * views it does not own are ignored), the caller moves the partial buffers to the sink rank (RCCL send/recv: int16 has no

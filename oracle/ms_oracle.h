@@ -226,6 +226,14 @@ void orc_feather_blend(int16_t *dst, size_t dstep, const float *dst_w, size_t dw
 
 void orc_set_num_threads(int n);
 
+/* rounding / saturation helpers of the restatement, exported for the execution pin against the reference's header-only
+ * cv::saturate_cast / cvRound (oracle/ref_pin/ref_pin.cpp, tests/test_ref_pin.py) */
+int orc_helper_sat_u8f(float v);
+int orc_helper_sat_s16f(float v);
+int orc_helper_sat_s16i(int v);
+int orc_helper_cv_round_f(float v);
+int orc_helper_f2i_rd(float v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,7 +51,7 @@ static inline int16_t sat_s16i(int v)
 static inline int16_t trunc_s16f(float v)
 {
     if (!(v == v)) return 0;
-    if (v >= 2147483520.f) return (int16_t)0x7fffffff;
+    if (v > 2147483520.f) return (int16_t)0x7fffffff;
     if (v <= -2147483648.f) return (int16_t)0x80000000;
     return (int16_t)(int32_t)v;
 }
@@ -60,14 +60,14 @@ static inline int f2i_rd(float v)
 {
     if (!(v == v)) return 0;
     float f = floorf(v);
-    if (f >= 2147483520.f) return 0x7fffffff;
+    if (f > 2147483520.f) return 0x7fffffff;
     if (f <= -2147483648.f) return (int)0x80000000;
     return (int)f;
 }
 static inline int f2i_rz(float v)
 {
     if (!(v == v)) return 0;
-    if (v >= 2147483520.f) return 0x7fffffff;
+    if (v > 2147483520.f) return 0x7fffffff;
     if (v <= -2147483648.f) return (int)0x80000000;
     return (int)v;
 }
@@ -186,6 +186,14 @@ static inline int cv_round_f(float v)
     const float r = rintf(v);
     return (r >= -2147483648.f && r < 2147483648.f) ? (int)r : INT32_MIN;
 }
+
+/* the rounding / saturation helpers above, exported so that tests/test_ref_pin.py can compare them with the reference's own
+ * header-only cv::saturate_cast / cvRound (oracle/_ref/libref_pin.so) over every float bit pattern */
+int orc_helper_sat_u8f(float v) { return (int)sat_u8f(v); }
+int orc_helper_sat_s16f(float v) { return (int)sat_s16f(v); }
+int orc_helper_sat_s16i(int v) { return (int)sat_s16i(v); }
+int orc_helper_cv_round_f(float v) { return cv_round_f(v); }
+int orc_helper_f2i_rd(float v) { return f2i_rd(v); }
 
 void orc_cv_remap_linear_8u(const uint8_t *src, size_t sstep, int srows, int scols, int cn,
                             const float *mapx, size_t mxstep, const float *mapy, size_t mystep,

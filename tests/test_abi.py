@@ -44,7 +44,7 @@ def test_compute_without_device_fails_loudly(ms):
     lib = ms.load()
     assert lib.ms_device_count() == 0
     ctx = C.c_void_p()
-    cfg = ms.Config(2, 64, 48, ms.PROJ_SPHERICAL, 50.0, 2, 0, 0, 0, 1)
+    cfg = ms.Config(C.sizeof(ms.Config), 2, 64, 48, ms.PROJ_SPHERICAL, 50.0, 2, 0, 0, 0, 1)
     rc = lib.ms_create(C.byref(cfg), C.byref(ctx))
     assert rc == -4 and b"no CPU fallback" in lib.ms_last_error()
     buf = (C.c_uint8 * 64)()
@@ -74,3 +74,27 @@ def test_shim_meshwarper_selection_state_machine(tmp_path):
                            "-L" + pkg, "-lmsstitch", "-Wl,-rpath," + pkg, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def test_ms_image_layout_matches_the_references_ptrstepsz():
+    """ms_image = PtrStepSz<T> {data, step, cols, rows} + type: checked against the reference's own header where it is present."""
+    import subprocess
+    inc = "/root/reference/sources/modules/core/include"
+    if not os.path.isfile(os.path.join(inc, "opencv2", "core", "cuda_types.hpp")):
+        pytest.skip("the reference is not on this machine")
+    exe = os.path.join(ROOT, "video-stitcher_amd", "build", "abi_layout_check")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++11", "-I" + inc, os.path.join(ROOT, "video-stitcher_amd", "shim", "abi_layout_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "layout ok" in out.stdout, out.stdout
+
+
+def test_config_struct_size_is_checked(ms):
+    """ms_create refuses a config whose struct_size is not this library's sizeof(ms_config) (before it looks for a device)."""
+    lib = ms.load()
+    cfg = ms.Config(C.sizeof(ms.Config) - 4, 2, 64, 48, ms.PROJ_SPHERICAL, 50.0, 2, 0, 0, 0, 1)
+    ctx = C.c_void_p()
+    rc = lib.ms_create(C.byref(cfg), C.byref(ctx))
+    assert rc != 0 and ctx.value is None
+    if lib.ms_device_count() > 0:
+        assert rc == -1 and b"struct_size" in lib.ms_last_error()

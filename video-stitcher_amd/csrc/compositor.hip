@@ -1625,7 +1625,7 @@ static int build_plan(ms_ctx *c)
                         need0 += (double)std::min(WARP_TW, V.pw - x0) * std::min(WARP_TH, V.ph - y0);
                     }
         }
-        if (c->cfg.reserved[2] == 0) xcd_order(tiles);
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
         c->warp_lds_tiles = 0;
@@ -1680,7 +1680,7 @@ static int build_plan(ms_ctx *c)
         {   // reachable tiles first, each part in XCD order on its own: when the others exit early every XCD still gets an equal share
             std::vector<WarpTile> a, b;
             for (const WarpTile &t : tiles) ((t.flags & 2) ? a : b).push_back(t);
-            if (c->cfg.reserved[2] == 0) { xcd_order(a); xcd_order(b); }
+            if (c->cfg.raster_tile_order == 0) { xcd_order(a); xcd_order(b); }
             tiles = a;
             tiles.insert(tiles.end(), b.begin(), b.end());
         }
@@ -1699,7 +1699,7 @@ static int build_plan(ms_ctx *c)
                     for (int x0 = 0; x0 < Lo.w; x0 += DOWN_TW)
                         if (any_in(Nd[v][l + 1], Lo.w, Lo.h, x0, y0, DOWN_TW, DOWN_TH)) tiles.push_back(DownTile{(short)v, 0, (short)x0, (short)y0});
             }
-        if (c->cfg.reserved[2] == 0) xcd_order(tiles);
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
         c->n_down_tiles[l] = (int)tiles.size();
         if (int e = c->down_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(DownTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->down_tiles[l].p, tiles.data(), tiles.size() * sizeof(DownTile), hipMemcpyHostToDevice));
@@ -1717,7 +1717,7 @@ static int build_plan(ms_ctx *c)
                     }
                     tiles.push_back(BlendTile{(short)x0, (short)y0, m});
                 }
-        if (c->cfg.reserved[2] == 0) xcd_order(tiles);
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
         c->n_blend_tiles[l] = (int)tiles.size();
         if (int e = c->blend_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(BlendTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->blend_tiles[l].p, tiles.data(), tiles.size() * sizeof(BlendTile), hipMemcpyHostToDevice));
@@ -1728,7 +1728,7 @@ static int build_plan(ms_ctx *c)
         size_t off[MAX_LEVELS] = {};
         for (int l = 0; l < nb; ++l) {
             c->pano.pure[l] = nullptr; c->pano.ppitch[l] = 0;
-            if (!c->blend_vec[l] || sharded_ctx(c) || c->cfg.reserved[0] != 0) continue;
+            if (!c->blend_vec[l] || sharded_ctx(c) || c->cfg.debug_simple_kernels != 0) continue;
             const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
             off[l] = all.size() + 1;          // (+1: 0 means "no map")
             c->pano.ppitch[l] = pw_;
@@ -1768,6 +1768,8 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
 {
     if (!cfg || !out) return fail(MS_ERR_INVALID, "ms_create: null argument");
     if (int e = require_device()) return e;
+    MS_CHECK(cfg->struct_size == sizeof(ms_config), "ms_create: ms_config.struct_size is %u, this library expects %zu (header / library mismatch)", cfg->struct_size, sizeof(ms_config));
+    MS_CHECK(cfg->reserved[0] == 0 && cfg->reserved[1] == 0 && cfg->reserved[2] == 0 && cfg->reserved[3] == 0, "ms_create: ms_config.reserved must be zero");
     MS_CHECK(cfg->num_views >= 1 && cfg->num_views <= MAX_VIEWS, "ms_create: num_views %d not in [1,%d]", cfg->num_views, MAX_VIEWS);
     MS_CHECK(cfg->src_width > 1 && cfg->src_height > 1, "ms_create: bad source size %dx%d", cfg->src_width, cfg->src_height);
     MS_CHECK(cfg->projection >= MS_PROJ_PLANE && cfg->projection <= MS_PROJ_SPHERICAL, "ms_create: bad projection %d", cfg->projection);
@@ -1782,14 +1784,14 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     c->N = cfg->num_views;
     for (int i = 0; i < MAX_VIEWS; ++i) c->gain[i] = 1.0;
     {
-        const int S = cfg->reserved[3] > 1 ? cfg->reserved[3] : 1, idx = cfg->reserved[4];
+        const int S = cfg->view_shards > 1 ? cfg->view_shards : 1, idx = cfg->view_shard_index;
         if (S > 4 || idx < 0 || idx >= S || S > c->N) { delete c; return fail(MS_ERR_INVALID, "ms_create: bad view-shard setting %d/%d", idx, S); }
         c->own_mask = 0;
         for (int v = idx * c->N / S; v < (idx + 1) * c->N / S; ++v) c->own_mask |= 1u << v;
     }
-    if (cfg->reserved[5] != 0 && (cfg->reserved[0] == 0 || cfg->enable_cpw)) {
+    if (cfg->cpu_flavour_remap != 0 && (cfg->debug_simple_kernels == 0 || cfg->enable_cpw)) {
         delete c;
-        return fail(MS_ERR_INVALID, "ms_create: the CPU-flavoured remap (reserved[5]) runs in the reference kernels only (reserved[0] = 1) and without CPW");
+        return fail(MS_ERR_INVALID, "ms_create: cpu_flavour_remap runs in the reference kernels only (debug_simple_kernels = 1) and without CPW");
     }
     {
         int dev = 0, cus = 0;
@@ -1941,7 +1943,7 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
     for (int i = 0; i < N; ++i) {
         MS_CHECK(full_imgs[i].data && full_imgs[i].type == MS_8UC3 && full_imgs[i].rows == H && full_imgs[i].cols == W,
                  "ms_calibrate_seam: image %d must be 8UC3 %dx%d", i, W, H);
-        ms_image simg{seam.p, (size_t)ws * 3, hs, ws, MS_8UC3};
+        ms_image simg{seam.p, (size_t)ws * 3, ws, hs, MS_8UC3};
         if (int e = launch_resize_linear(full_imgs[i], simg, prm->seam_scale, prm->seam_scale, st)) return e;        // calibration.cpp:95
         const float *Ks = K_seam + 9 * i;
         Projector P;
@@ -1953,11 +1955,11 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
         if (int e = mapy.alloc(npx * 4)) return e;
         if (int e = wimg.alloc(npx * 3)) return e;
         if (int e = wmask.alloc(npx)) return e;
-        ms_image mx{mapx.p, (size_t)rs[i].width * 4, rs[i].height, rs[i].width, MS_32FC1}, my{mapy.p, (size_t)rs[i].width * 4, rs[i].height, rs[i].width, MS_32FC1};
+        ms_image mx{mapx.p, (size_t)rs[i].width * 4, rs[i].width, rs[i].height, MS_32FC1}, my{mapy.p, (size_t)rs[i].width * 4, rs[i].width, rs[i].height, MS_32FC1};
         float k_rinv[9];
         k_rinv_gemm(Ks, c->R[i], k_rinv);
         if (int e = launch_build_warp_maps(c->cfg.projection, rs[i].x, rs[i].y, mx, my, k_rinv, nullptr, prm->seam_warp_scale, st)) return e;
-        ms_image wi{wimg.p, (size_t)rs[i].width * 3, rs[i].height, rs[i].width, MS_8UC3};
+        ms_image wi{wimg.p, (size_t)rs[i].width * 3, rs[i].width, rs[i].height, MS_8UC3};
         if (int e = launch_remap(simg, mx, my, wi, MS_INTER_LINEAR, MS_BORDER_REFLECT, st)) return e;                   // calibration.cpp:118
         k_valid_mask<<<dim3(div_up(rs[i].width, 64), div_up(rs[i].height, 4)), dim3(64, 4), 0, st>>>(                // calibration.cpp:122
             (const float *)mapx.p, (const float *)mapy.p, rs[i].width, rs[i].height, rs[i].width, hs, ws, (uint8_t *)wmask.p, rs[i].width);
@@ -1985,22 +1987,22 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
         const int aw = c->roi[i].width, ah = c->roi[i].height;
         if (int e = wmask.alloc(npx)) return e;
         MS_HIP(hipMemcpyAsync(wmask.p, hmask[i].data(), npx, hipMemcpyHostToDevice, st));                            // calibration.cpp:229
-        ms_image sm{wmask.p, (size_t)rs[i].width, rs[i].height, rs[i].width, MS_8UC1};
+        ms_image sm{wmask.p, (size_t)rs[i].width, rs[i].width, rs[i].height, MS_8UC1};
         if (prm->dilate) {                                                                                            // calibration.cpp:231-232
             if (int e = dil.alloc(npx)) return e;
-            ms_image dm{dil.p, (size_t)rs[i].width, rs[i].height, rs[i].width, MS_8UC1};
+            ms_image dm{dil.p, (size_t)rs[i].width, rs[i].width, rs[i].height, MS_8UC1};
             if (int e = launch_dilate3(sm, dm, st)) return e;
             sm = dm;
         }
         if (int e = big.alloc((size_t)aw * ah)) return e;
-        ms_image bm{big.p, (size_t)aw, ah, aw, MS_8UC1};
+        ms_image bm{big.p, (size_t)aw, aw, ah, MS_8UC1};
         if (int e = launch_resize_linear(sm, bm, 0, 0, st)) return e;                                                // calibration.cpp:236
         ms_image mx = view_map_image(c, i, 0), my = view_map_image(c, i, 1);
         uint8_t *dstm = (uint8_t *)c->masks.p + c->mask_off[i];
         k_valid_mask<<<dim3(div_up(aw, 64), div_up(ah, 4)), dim3(64, 4), 0, st>>>(                                   // calibration.cpp:224-227
             (const float *)mx.data, (const float *)my.data, c->map_pitch[i], ah, aw, H, W, dstm, aw);
         MS_LAUNCH_CHECK();
-        ms_image vm{dstm, (size_t)aw, ah, aw, MS_8UC1};
+        ms_image vm{dstm, (size_t)aw, aw, ah, MS_8UC1};
         if (int e = launch_and_8u(bm, vm, vm, st)) return e;                                                         // calibration.cpp:237
         MS_HIP(hipStreamSynchronize(st));
     }
@@ -2169,7 +2171,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         while (t < nb && c->blend_vec[t]) ++t;
         auto plan_btail = [&](int tt, int *out_t, int *out_lds, int *out_strips) {
             *out_t = -1; *out_lds = 0; *out_strips = 0;
-            bool ok = tt >= 1 && tt < nb && c->cfg.reserved[0] == 0;
+            bool ok = tt >= 1 && tt < nb && c->cfg.debug_simple_kernels == 0;
             for (int l = tt; ok && l < nb; ++l) {          // quads: even band sizes and even-aligned view rects below the coarsest band
                 ok = P.qw[l] % 2 == 0 && P.qh[l] % 2 == 0;
                 for (int v = 0; ok && v < N; ++v) {
@@ -2199,8 +2201,8 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     if (int e = wm.alloc((size_t)c->max_aw * c->max_ah * sizeof(float))) return e;
     for (int v = 0; v < N; ++v) {
         ViewDesc &V = c->h_views[v];
-        ms_image mask{(void *)blend_mask_ptr(c, v), (size_t)V.aw, V.ah, V.aw, MS_8UC1};
-        ms_image wmap{wm.p, (size_t)V.aw * sizeof(float), V.ah, V.aw, MS_32FC1};
+        ms_image mask{(void *)blend_mask_ptr(c, v), (size_t)V.aw, V.aw, V.ah, MS_8UC1};
+        ms_image wmap{wm.p, (size_t)V.aw * sizeof(float), V.aw, V.ah, MS_32FC1};
         if (c->feather_sharpness >= 0.f) {            // FeatherBlender::feed -> createWeightMap (blenders.cpp:156, 944-951), host side like the reference
             std::vector<uint8_t> hm((size_t)V.aw * V.ah);
             std::vector<float> hw((size_t)V.aw * V.ah);
@@ -2212,7 +2214,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         } else if (int e = launch_convert(mask, wmap, 1. / 255., st)) return e;                // blenders.cpp:412
         auto level_img = [&](int l) {
             const LevelDesc &L = V.lv[l];
-            return ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.h, L.w, MS_32FC1};
+            return ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.w, L.h, MS_32FC1};
         };
         ms_image l0 = level_img(0);
         if (int e = launch_copy_make_border(wmap, l0, V.top, V.left, MS_BORDER_CONSTANT, st)) return e;   // :420
@@ -2268,6 +2270,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         MS_HIP(hipMemcpy(hd.data(), c->den.p, den_total * sizeof(float), hipMemcpyDeviceToHost));
         std::sort(hd.begin(), hd.end());
         hd.erase(std::unique(hd.begin(), hd.end()), hd.end());
+        hd.erase(hd.begin(), std::upper_bound(hd.begin(), hd.end(), 0.f));        // (row padding of the tables: never read)
         for (size_t i = 0; i < hd.size(); i += 65535) {
             const int n = (int)std::min<size_t>(65535, hd.size() - i);
             const int bad = ms_selftest_divide(hd.data() + i, n, stream);
@@ -2322,7 +2325,7 @@ static ms_image mesh_image(const ms_ctx *c, int buf, int v, int which)
 {
     const int ah = c->roi[v].height, aw = c->roi[v].width;
     float *base = (float *)c->mesh[buf].p + c->mesh_off[v] + (which ? (size_t)ah * c->map_pitch[v] : 0);
-    return ms_image{base, (size_t)c->map_pitch[v] * sizeof(float), ah, aw, MS_32FC1};
+    return ms_image{base, (size_t)c->map_pitch[v] * sizeof(float), aw, ah, MS_32FC1};
 }
 
 // Callers hold mesh_update_mu (one update at a time).  mesh_mu is taken here only around the bookkeeping ms_stitch shares: ms_stitch holds it from
@@ -2458,8 +2461,8 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
         MS_HIP(hipMemcpy(c->masks_eff.p, c->masks.p, c->masks.bytes, hipMemcpyDeviceToDevice));
     }
     const int aw = c->roi[view].width, ah = c->roi[view].height;
-    ms_image src{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)aw, ah, aw, MS_8UC1};
-    ms_image dst{(uint8_t *)c->masks_eff.p + c->mask_off[view], (size_t)aw, ah, aw, MS_8UC1};
+    ms_image src{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)aw, aw, ah, MS_8UC1};
+    ms_image dst{(uint8_t *)c->masks_eff.p + c->mask_off[view], (size_t)aw, aw, ah, MS_8UC1};
     int active;
     { std::lock_guard<std::mutex> mk(c->mesh_mu); active = c->mesh_active[view]; }
     ms_image mx = mesh_image(c, active, view, 0), my = mesh_image(c, active, view, 1);
@@ -2541,7 +2544,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         }
     }
     if (out_i420) {
-        if (!(P.nb >= 1 && c->blend_vec[0] && c->cfg.reserved[0] == 0 && S.mode == 0 && (P.out_w & 1) == 0 && P.i_rows > 0))
+        if (!(P.nb >= 1 && c->blend_vec[0] && c->cfg.debug_simple_kernels == 0 && S.mode == 0 && (P.out_w & 1) == 0 && P.i_rows > 0))
             return fail(MS_ERR_UNSUPPORTED, "ms_stitch_i420: needs the tiled level-0 band kernel (>= 1 band, pano width a multiple of 8, no view sharding) and an even canvas width");
     }
     MeshTable mesh{};
@@ -2589,7 +2592,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
-        if (c->cfg.reserved[0] == 0)
+        if (c->cfg.debug_simple_kernels == 0)
             MS_PROJ_LAUNCH(k_stage1_t, (), (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH / 2, 256 / WARP_BX)), 0, st), 
                 (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
         else
@@ -2597,17 +2600,17 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
-        if (c->warp_tiled && c->cfg.reserved[0] == 0)
+        if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
             MS_PROJ_LAUNCH(k_warp_t, (true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
-    } else if (c->warp_tiled && c->cfg.reserved[0] == 0) {
+    } else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0) {
         // opt-in (reserved[1] = 1 or MS_WARP_ASYNC=1): source tiles staged in LDS by asynchronous LDS-DMA, persistent waves (k_warp_a) -- bit-identical,
         // measured slower than the direct gathers on config 2 (353 vs 242 us per 16 frames: at its 1.6-2.1 x minification only 54 % of the tiles' source
         // boxes fit a staging buffer and 10 waves per CU cannot hide what 20 do; profiles/r02_warp_probes.txt)
         static const bool env_on = [] { const char *e = getenv("MS_WARP_ASYNC"); return e && atoi(e) != 0; }();
-        bool staged = c->warp_lds_tiles > 0 && (c->cfg.reserved[1] == 1 || (env_on && c->cfg.reserved[1] != 2));
+        bool staged = c->warp_lds_tiles > 0 && (c->cfg.warp_lds_stage == 1 || (env_on && c->cfg.warp_lds_stage != 2));
         for (int i = 0; i < F * N; ++i) staged = staged && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
         if (staged) {
             const long long items = (long long)c->n_warp_tiles * F;
@@ -2615,7 +2618,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         } else
             MS_PROJ_LAUNCH(k_warp_t, (false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
-    } else if (c->cfg.reserved[5] != 0) {
+    } else if (c->cfg.cpu_flavour_remap != 0) {
         k_warp<false, true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
     } else {
@@ -2627,14 +2630,14 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
 
     const int dt_l0 = c->tail_l0, dt_lds = c->tail_lds, dt_strips = c->tail_strips;     // (starting the reduce tail a level finer was measured slower even for one frame)
     for (int l = 0; l < nb; ++l) {
-        if (l == dt_l0 && c->cfg.reserved[0] == 0) {
+        if (l == dt_l0 && c->cfg.debug_simple_kernels == 0) {
             k_down_tail<<<dim3(F * N * 3 * dt_strips), blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask);
             MS_LAUNCH_CHECK();
             if (int e = mark("k_down_tail")) return e;
             break;
         }
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
-        if (c->down_vec[l] && c->cfg.reserved[0] == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
+        if (c->down_vec[l] && c->cfg.debug_simple_kernels == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
             if (l == 0) k_down_t<uint8_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
             else        k_down_t<int16_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
@@ -2679,7 +2682,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         if (int e = mark(blend_names[nb])) return e;
     }
     for (int l = l_first; l >= 0; --l) {
-        if (c->blend_vec[l] && c->cfg.reserved[0] == 0) {
+        if (c->blend_vec[l] && c->cfg.debug_simple_kernels == 0) {
             const dim3 g(c->n_blend_tiles[l], 1, F), b(32, 8);
             if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else        MS_MODE_LAUNCH2(k_blend8, false, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
@@ -2823,7 +2826,7 @@ int ms_get_mask(const ms_ctx *c, int view, ms_image *m)
     if (int e = ctx_check_view(c, view)) return e;
     if (!c->masks_built) return fail(MS_ERR_STATE, "ms_get_mask: masks not built");
     MS_CHECK(m, "null output");
-    *m = ms_image{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)c->roi[view].width, c->roi[view].height, c->roi[view].width, MS_8UC1};
+    *m = ms_image{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)c->roi[view].width, c->roi[view].width, c->roi[view].height, MS_8UC1};
     return MS_OK;
 }
 
@@ -2833,7 +2836,7 @@ int ms_get_weight_level(const ms_ctx *c, int view, int level, ms_image *w)
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_weight_level: call ms_init_blender first");
     MS_CHECK(w && level >= 0 && level <= c->pano.nb, "ms_get_weight_level: bad level %d", level);
     const LevelDesc &L = c->h_views[view].lv[level];
-    *w = ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.h, L.w, MS_32FC1};
+    *w = ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.w, L.h, MS_32FC1};
     return MS_OK;
 }
 
@@ -2851,7 +2854,7 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
 {
     if (!c || !m) return fail(MS_ERR_INVALID, "null argument");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_result_mask: call ms_init_blender first");
-    *m = ms_image{c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fh, c->pano.fw, MS_8UC1};
+    *m = ms_image{c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
     return MS_OK;
 }
 

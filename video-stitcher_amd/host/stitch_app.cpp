@@ -352,7 +352,7 @@ int main(int argc, char **argv)
             }
             comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
             if (o.i420) {
-                ms_image rows{s->pano8u.data + (size_t)ya * s->pano8u.step, s->pano8u.step, yb - ya, o.out_w, MS_8UC3};
+                ms_image rows{s->pano8u.data + (size_t)ya * s->pano8u.step, s->pano8u.step, o.out_w, yb - ya, MS_8UC3};
                 ms_image dst = msshim::wrap(s->i420);
                 msshim::check(ms_bgr_to_i420(&rows, &dst, (ms_stream)stitch_stream));       // cvtColor(BGR2YUV_I420), timed.cpp:308-316
             }

@@ -25,7 +25,7 @@ class MsError(RuntimeError):
 
 
 class Image(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("step", C.c_size_t), ("rows", C.c_int), ("cols", C.c_int), ("type", C.c_int)]
+    _fields_ = [("data", C.c_void_p), ("step", C.c_size_t), ("cols", C.c_int), ("rows", C.c_int), ("type", C.c_int)]      # PtrStepSz order
 
 
 class Rect(C.Structure):
@@ -36,9 +36,11 @@ class Rect(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [("num_views", C.c_int), ("src_width", C.c_int), ("src_height", C.c_int), ("projection", C.c_int),
+    _fields_ = [("struct_size", C.c_uint), ("num_views", C.c_int), ("src_width", C.c_int), ("src_height", C.c_int), ("projection", C.c_int),
                 ("warp_scale", C.c_float), ("num_bands", C.c_int), ("enable_cpw", C.c_int),
-                ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int), ("reserved", C.c_int * 8)]
+                ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int),
+                ("view_shards", C.c_int), ("view_shard_index", C.c_int), ("cpu_flavour_remap", C.c_int),
+                ("debug_simple_kernels", C.c_int), ("warp_lds_stage", C.c_int), ("raster_tile_order", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class SeamParams(C.Structure):
@@ -121,7 +123,7 @@ def img(t):
         assert t.stride(2) == 1 and t.stride(1) == cn
     else:
         assert t.stride(1) == 1
-    return Image(t.data_ptr(), t.stride(0) * t.element_size(), t.shape[0], t.shape[1], _TYPES[(t.dtype, cn)])
+    return Image(t.data_ptr(), t.stride(0) * t.element_size(), t.shape[1], t.shape[0], _TYPES[(t.dtype, cn)])
 
 
 def tensor_of(image, dtype=None):
@@ -415,12 +417,12 @@ class Compositor:
 
     def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
                  out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=None, shards=1, shard_index=0, cv_remap=False):
-        cfg = Config(num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
+        cfg = Config(C.sizeof(Config), num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
                      out_size[0], out_size[1], max_frames)
-        cfg.reserved[0] = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
-        cfg.reserved[1] = 0 if lds_stage is None else (1 if lds_stage else 2)   # True: warp source tiles staged in LDS by LDS-DMA (opt-in, measured slower); False forces the direct gathers even under MS_WARP_ASYNC=1
-        cfg.reserved[3] = shards; cfg.reserved[4] = shard_index   # view sharding
-        cfg.reserved[5] = 1 if cv_remap else 0         # cv::remap's CPU arithmetic for the projection warp (needs simple_kernels, no CPW)
+        cfg.debug_simple_kernels = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
+        cfg.warp_lds_stage = 0 if lds_stage is None else (1 if lds_stage else 2)   # True: warp source tiles staged in LDS by LDS-DMA (opt-in, measured slower); False forces the direct gathers even under MS_WARP_ASYNC=1
+        cfg.view_shards = shards; cfg.view_shard_index = shard_index   # view sharding
+        cfg.cpu_flavour_remap = 1 if cv_remap else 0   # cv::remap's CPU arithmetic for the projection warp (needs simple_kernels, no CPW)
         self._ctx = C.c_void_p()
         _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
         self.cfg = cfg

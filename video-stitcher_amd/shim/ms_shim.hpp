@@ -20,7 +20,7 @@ inline void check(int rc) { if (rc < 0) throw Error(rc, ms_last_error()); }
 
 template <class Mat> inline ms_image wrap(const Mat &m)
 {
-    return ms_image{(void *)m.data, (size_t)m.step, m.rows, m.cols, m.type()};
+    return ms_image{(void *)m.data, (size_t)m.step, m.cols, m.rows, m.type()};
 }
 
 // ---- cv::cuda:: free functions (dst must be pre-created, as GpuMat::create would) ------------------------
@@ -63,6 +63,7 @@ public:
                int out_w, int out_h, int frames_in_flight = 1)
     {
         ms_config c{};
+        c.struct_size = (unsigned)sizeof(ms_config);
         c.num_views = num_views; c.src_width = src_w; c.src_height = src_h; c.projection = projection; c.warp_scale = warp_scale;
         c.num_bands = num_bands; c.enable_cpw = enable_local; c.out_width = out_w; c.out_height = out_h; c.max_frames = frames_in_flight;
         check(ms_create(&c, &ctx_));
