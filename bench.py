@@ -4,8 +4,9 @@
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" = one pass over a batch of F frames (F = --frames, default 48: 6 views x F frames, inputs already resident in
-HBM), issued as --streams (default 3) ms_stitch calls of F/streams frames on separate HIP streams / contexts.  Weak scaling: every rank stitches its own F frames per step (frame-parallel,
+A "step" = --passes (default 20) passes over a batch of F frames (F = --frames, default 48: 6 views x F frames, inputs already
+resident in HBM; 20 x 48 = 960 frames = 32 s of 30 fps video per step), each pass issued as --streams (default 3) ms_stitch calls of
+F/streams frames on separate HIP streams / contexts.  Weak scaling: every rank stitches its own F frames per step (frame-parallel,
 round-robin ownership); with N>1 the finished pano slabs are gathered on rank 0 over RCCL, overlapped with
 the next step.  value = N*F*K / max-over-ranks wall time.
 
@@ -13,6 +14,10 @@ Also printed on the same JSON line:
   roofline     -- dominant kernel: SURVEY 8(d) algorithmic bytes per launch / mean launch duration
                   (hipEvents on the launch stream, instrumented pass right after the timed region), peak 8 TB/s
   cpu_baseline -- the CPU oracle (a port of the reference's kernel arithmetic) on a bounded sample, rank 0 / N=1
+  verified     -- after the timed region, frames of every batch are re-stitched one at a time on a separate one-frame context and
+                  must equal the batched outputs byte for byte
+  live         -- one frame per ms_stitch call, synchronised after each call: median / p95 latency per frame (the reference's shape)
+  pcie_inclusive_fps -- the C++ host pipeline (video-stitcher_amd/stitch_app: pinned H2D of all six views per frame + stitch + consume)
 """
 import argparse
 import json
@@ -80,16 +85,21 @@ def cpu_baseline(cfg, gains, comp, budget_s=12.0):
         for i in range(cfg["n"]):
             b.stitch_online(i, frames[i], maps[i][0], maps[i][1], gains[i])
         b.blend()
+    def timed(th, reps=3):                  # median of `reps` runs: a single timing per candidate picked a different thread count run to run
+        O.set_num_threads(th)
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter(); one(); ts.append(time.perf_counter() - t1)
+        return sorted(ts)[len(ts) // 2]
     O.set_num_threads(1)
     one()                                   # warm-up (page-in)
-    t1 = time.perf_counter(); one(); one_thread = time.perf_counter() - t1
-    # the port is OpenMP-parallel over rows; pick the thread count that is fastest on this host
+    one_thread = timed(1, 3)
+    # the port is OpenMP-parallel over rows; pick the thread count whose MEDIAN of three runs is fastest on this host
     best, cores = one_thread, 1
     for th in (8, 16, 32, 64):
         if th > ncpu:
             break
-        O.set_num_threads(th)
-        t1 = time.perf_counter(); one(); el = time.perf_counter() - t1
+        el = timed(th, 3)
         if el < best:
             best, cores = el, th
     O.set_num_threads(cores)
@@ -110,7 +120,8 @@ def cpu_baseline(cfg, gains, comp, budget_s=12.0):
         pass
     return {"value": round(fps_all, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": model,
             "sample": "%d config-2 frames (6x1080p -> 3839x627 pano ROI, 5 bands) in %.1f s with %d OpenMP threads "
-                      "(best of 1/8/16/32/64 on a %d-CPU host); 1 thread: %.0f ms/frame" % (n, el, cores, ncpu, one_thread * 1e3)}
+                      "(fastest median-of-3 among 1/8/16/32/64 on a %d-CPU host); 1 thread: %.0f ms/frame" % (n, el, cores, ncpu, one_thread * 1e3),
+            "one_thread_fps": round(1.0 / one_thread, 3)}
 
 
 def run_view_shards(args, cfg, gains, rank, world, dev, share):
@@ -229,8 +240,15 @@ def run_view_shards(args, cfg, gains, rank, world, dev, share):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--passes", type=int, default=None, help="passes over the F-frame batch per step (default 20: a step is 960 frames, so that the driver's "
+                    "short runs still time about a second of GPU work; 1 with --calib / profiling runs)")
+    ap.add_argument("--no-live", action="store_true", help="skip the one-frame-per-call latency measurement")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive run of the C++ host pipeline (stitch_app)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=1, help="N>1: gather the slabs of every k-th pass only (0 = pick k so that a rank sends about "
+                    "30 frames/s: the live rate, at which the sink's links are idle and compute scaling is what is measured)")
     ap.add_argument("--frames", type=int, default=None, help="frames per step, split evenly over --streams contexts (default 48 = 3 x 16; cfg3: 16 on one context; cfg5: 24; 1 = live mode)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,6 +273,8 @@ def main():
         args.streams = 1
         if args.frames is None:
             args.frames = 4 if args.config == "cfg5" else 16
+    if args.passes is None:
+        args.passes = 1 if (args.calib or args.view_shards > 1) else 20
     if args.streams is None:        # cfg3 re-expands the CPW meshes on every context: one context there, three elsewhere
         args.streams = 1 if args.config == "cfg3" else 3
     if args.frames is None:
@@ -377,8 +397,17 @@ def main():
                               for i in range(cfg["n"])])
     recal = {"frames": 0, "count": 0}
 
+    state = {"pass": 0, "gather_every": max(1, args.gather_every), "gather_on": True, "last_b": 0, "gathered": 0}
+
     def step(s):
-        b = s & 1
+        for _ in range(args.passes):
+            one_pass()
+
+    def one_pass():
+        p_idx = state["pass"]; state["pass"] += 1
+        b = p_idx & 1
+        state["last_b"] = b
+        do_gather = gather and state["gather_on"] and (p_idx % state["gather_every"] == 0)
         if pending[b] is not None:
             pending[b].wait(); pending[b] = None
         if mesh_pool:
@@ -398,7 +427,7 @@ def main():
             if not i420:         # (the I420 slabs are written by runs[b] itself)
                 for j in range(F):
                     slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
-            if not gather:
+            if not do_gather:
                 pass
             elif share:
                 if to_i420:
@@ -408,32 +437,48 @@ def main():
                 if to_i420:
                     torch.cuda.current_stream().wait_event(egress_done[b])      # the collective is ordered behind the caller's stream
                 pending[b], _ = df.gather_slabs(slabs[b], rank, world, dst=0, async_op=True, out=gl[b])
+            if do_gather:
+                state["gathered"] += 1
 
     def drain():
         for b in range(2):
             if pending[b] is not None:
                 pending[b].wait(); pending[b] = None
 
-    for s in range(args.warmup):
-        step(s)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(steps, warmup):
+        for s_ in range(warmup):
+            step(s_)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        g0_ = state["gathered"]
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            step(s_)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, state["gathered"] - g0_
+
+    no_gather = None
+    if gather:      # N > 1: first the compute-only rate (no collective), so that a SCALE record separates compute scaling from the sink's links
+        state["gather_on"] = False
+        el_ng, _ = timed_region(max(1, args.steps // 2), args.warmup)
+        no_gather = world * F * args.passes * max(1, args.steps // 2) / el_ng
+        state["gather_on"] = True
+        if args.gather_every == 0:      # live rate: about 30 gathered frames per second and rank
+            per_rank = no_gather / world
+            state["gather_every"] = max(1, int(round(per_rank / 30.0 / F)))
+    elapsed, n_gathered = timed_region(args.steps, args.warmup)
 
     if args.calib:
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255); b = torch.empty_like(a)
@@ -442,20 +487,94 @@ def main():
         torch.cuda.synchronize()
         del a, b
 
+    # ---- verification: frames of every batch of the LAST pass re-stitched one at a time on a one-frame context (live code path:
+    #      other launch configuration, band tail one band finer) must equal what the batched, multi-stream passes left in the outputs
+    verified, verify_note = None, None
+    live_comp = None
+    if not args.no_verify or not args.no_live:
+        live_comp = make_comp(1)
+    if not args.no_verify:
+        b = state["last_b"]
+        picks = sorted({k * Fs + j for k in range(S) for j in (0, Fs // 2, Fs - 1)})
+        ok = True
+        if direct_i420:
+            one = live_comp.new_i420(1)
+            for j in picks:
+                one[0][:(yb - ya)] = 16; one[0][(yb - ya):] = 128
+                live_comp.stitch_i420([frames[j]], one)
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(one[0], slabs[b][j]))
+        else:
+            one = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev)]
+            for j in picks:
+                live_comp.stitch([frames[j]], out8u=one)
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(one[0], outs[b][j]))
+        verified = ok
+        verify_note = "%d of the %d frames of the last pass (first / middle / last of each of the %d batches) re-stitched one frame per call: %s" % (
+            len(picks), F, S, "byte-identical" if ok else "MISMATCH")
+        if mesh_pool:
+            verify_note += " [cfg3: the live context carries the meshes of the last recalibration]"
+
+    # ---- live mode: one frame per ms_stitch call (the reference's shape), synchronised after every call ------------------------
+    live = None
+    if not args.no_live and rank == 0:
+        if mesh_pool:      # same meshes as the batch contexts hold now
+            for i in range(cfg["n"]):
+                live_comp.set_mesh(i, *mesh_pool[(recal["count"] - 1) % 4][i])
+        one = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev)]
+        runs1 = [live_comp.prepared([frames[j % F]], out8u=one) for j in range(8)]
+        st = torch.cuda.current_stream()
+        h = ctypes.c_void_p(st.cuda_stream)
+        for j in range(30):
+            runs1[j % 8](h)
+        torch.cuda.synchronize()
+        lat_us = []
+        for j in range(300):
+            t1 = time.perf_counter()
+            runs1[j % 8](h)
+            torch.cuda.synchronize()
+            lat_us.append((time.perf_counter() - t1) * 1e6)
+        t1 = time.perf_counter()
+        for j in range(300):
+            runs1[j % 8](h)
+        torch.cuda.synchronize()
+        back_to_back = 300 / (time.perf_counter() - t1)
+        live = {"us_per_frame_p50": round(float(np.percentile(lat_us, 50)), 1), "us_per_frame_p95": round(float(np.percentile(lat_us, 95)), 1),
+                "frames": 300, "fps_back_to_back": round(back_to_back, 1),
+                "mode": "one frame per ms_stitch call, inputs resident; latency = host call -> stream idle (host launch + %d dependent kernels)" % len(live_comp.stitch_timed([frames[0]], out8u=one))}
+    if live_comp is not None:
+        live_comp.close()
+
+    # ---- PCIe-inclusive rate: the C++ host pipeline with the reference's thread / queue graph, every source frame uploaded from pinned memory
+    pcie = None
+    app = os.path.join(ROOT, "video-stitcher_amd", "stitch_app")
+    if not args.no_pcie and rank == 0 and world == 1 and os.path.exists(app):
+        import subprocess
+        try:
+            cmd = [app, "--views", str(cfg["n"]), "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
+                   "--hfov", str(cfg["hfov_deg"]), "--bands", str(cfg["num_bands"]), "--frames", "1500"] + (["--cpw"] if cpw else [])
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+            pj = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+            pcie = {"value": pj["frames_per_s"], "unit": "frames/s", "frames": pj["frames"],
+                    "how": "video-stitcher_amd/stitch_app: capture thread -> hipMemcpy2DAsync of all %d views from pinned memory per frame -> ms_stitch (1 frame) -> "
+                           "consume thread; %.1f MB over PCIe per frame" % (cfg["n"], cfg["n"] * cfg["w"] * cfg["h"] * 3 / 1e6)}
+        except Exception as e:      # the number is optional; never fail the bench line on it
+            pcie = {"error": str(e)[:200]}
+
     # ---- instrumented pass: per-kernel hipEvent durations on the launch stream ------------------
     acc = {}
-    reps = max(5, min(50, args.steps))
+    reps = max(5, min(50, args.steps * args.passes))
     for _ in range(reps):
         for name, ms_t in comp.stitch_timed(frames[:Fs], out8u=outs[0][:Fs]):
             acc.setdefault(name, []).append(ms_t)
     kmean = {k: float(np.mean(v)) for k, v in acc.items()}
     per_call = np.sum(np.array([acc[k] for k in acc]), axis=0)        # GPU ms of each instrumented ms_stitch call (sum of its kernels)
-    lat = {"gpu_ms_per_step_p50": round(float(np.percentile(per_call, 50)), 5), "gpu_ms_per_step_p95": round(float(np.percentile(per_call, 95)), 5),
+    lat = {"gpu_ms_per_call_p50": round(float(np.percentile(per_call, 50)), 5), "gpu_ms_per_call_p95": round(float(np.percentile(per_call, 95)), 5),
            "calls": int(per_call.size), "frames_per_call": Fs}
     kb, sumP, Q, A = kernel_bytes(comp, cfg, Fs, cpw)
     dom = max(kmean, key=kmean.get)
     achieved = kb.get(dom, 0.0) / (kmean[dom] * 1e-3) / 1e9          # GB/s
-    b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), [0], 0, (cfg["out_w"], cfg["out_h"]))  # placeholder, replaced below
     P_list = []
     for i in range(cfg["n"]):
         g = comp.view_geom(i)
@@ -463,39 +582,68 @@ def main():
     b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), P_list, Q, (cfg["out_w"], cfg["out_h"]), warped_px=A, cpw=cpw)
     gpu_ms_step = float(sum(kmean.values()))
 
-    traffic = None
+    # PMC-measured HBM bytes (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/profile_traffic.sh on the same workload, calibrated on a 1 GiB
+    # copy): read from the committed summary -- counters cannot be collected inside this run -- and labelled as such
+    traffic, traffic_call, traffic_src = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):       # PMC-measured HBM bytes per launch of the dominant kernel (tools/profile_traffic.sh), same workload only
+    if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get("config") == args.config and tj.get("frames_per_launch") == Fs and dom in tj.get("kernels", {}):
-            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        if tj.get("config") == args.config and tj.get("frames_per_launch") == Fs:
+            if dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_call = tj.get("hbm_bytes_per_call")
+            traffic_src = "profiles/%s_traffic.json: rocprofv3 PMC passes of this workload (tag %s), NOT measured in this run" % (tj.get("tag"), tj.get("tag"))
     if rank == 0:
-        total_frames = world * F * args.steps
+        frames_per_step = F * args.passes
+        total_frames = world * frames_per_step * args.steps
+        par = "frame-parallel x%d" % world
+        if gather:
+            par += ", RCCL gather of the %s pano rows on rank 0 (%.1f MB/frame)%s, overlapped" % (
+                args.gather_format.upper(), slabs[0][0].numel() / 1e6,
+                "" if state["gather_every"] == 1 else " for every %d-th pass (about 30 frames/s per rank: live rate)" % state["gather_every"])
+        if share:
+            par += " [DEBUG: ranks share one GPU, gloo]"
         res = {
             "metric": "stitched frames/sec, 6x1080p->4K equirect (ms/frame = 1000/value*n_gpus)",
             "value": round(total_frames / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "ms_per_frame": round(elapsed / args.steps / F * 1e3, 5),
+            "ms_per_frame": round(elapsed / args.steps / frames_per_step * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 in / int16+fp32 pyramid arithmetic", "data": "synthetic",
-            "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, spherical, %d bands, CPW %s%s; "
-                                   "%d frames per step per GPU on %d HIP stream(s), inputs resident in HBM"
+            "config": {"workload": "%s: %dx%dx%d views -> %dx%d equirect, spherical, %d bands, CPW %s%s; a step = %d passes over a batch of "
+                                   "%d frames per GPU (%d frames), each pass on %d HIP stream(s) / contexts, inputs resident in HBM"
                                    % (args.config, cfg["n"], cfg["w"], cfg["h"], cfg["out_w"], cfg["out_h"],
                                       pg.num_bands, "on (40x40 mesh)" if cpw else "off",
-                                      (", meshes re-expanded every %d frames" % args.recalib_every) if mesh_pool else "", F, S),
-                       "frames_per_step": F, "streams": S, "parallelism": "frame-parallel x%d%s%s" % (world, (", RCCL gather of the %s pano rows on rank 0 (%.1f MB/frame), overlapped" % (args.gather_format.upper(), slabs[0][0].numel() / 1e6)) if gather else "",
-                                                                  " [DEBUG: ranks share one GPU, gloo]" if share else "")},
+                                      (", meshes re-expanded every %d frames" % args.recalib_every) if mesh_pool else "", args.passes, F, frames_per_step, S),
+                       "frames_per_step": frames_per_step, "frames_per_pass": F, "passes_per_step": args.passes, "streams": S, "parallelism": par},
+            "verified": verified, "verified_how": verify_note,
+            # `frac` prices the launch at SURVEY 8(d)'s ALGORITHMIC bytes (the level-materialised model: it credits bytes this design does not
+            # move, and can exceed what a copy reaches); `frac_traffic` prices it at the HBM bytes the PMC counters saw -- the physical fraction
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                         "frac_traffic": (round(traffic / (kmean[dom] * 1e-3) / 8e12, 4) if traffic else None), "traffic_source": traffic_src,
                          "alg_bytes_per_launch": int(kb.get(dom, 0)), "mean_launch_ms": round(kmean[dom], 5)},
             "frame_roofline": {"alg_bytes_per_frame": int(b_alg_frame), "gpu_ms_per_frame": round(gpu_ms_step / Fs, 5),
                                "achieved_GBps": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 1e9, 1),
                                "frac": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),
-                               "wall_frac": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4)},
-            "kernels_ms_per_step": {k: round(v, 5) for k, v in kmean.items()},
+                               "wall_frac": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4),
+                               "hbm_bytes_per_frame": (int(traffic_call / Fs) if traffic_call else None),
+                               "frac_traffic": (round(traffic_call / (gpu_ms_step * 1e-3) / 8e12, 4) if traffic_call else None),
+                               "wall_frac_traffic": (round(traffic_call / Fs * total_frames / world / elapsed / 8e12, 4) if traffic_call else None),
+                               "note": "frac / wall_frac use the algorithmic-byte model and exceed 1 where the design moves fewer bytes than the model "
+                                       "(u8 level 0, no accumulator read-modify-write, skipped tiles); the *_traffic fractions use PMC-measured HBM bytes"},
+            "kernels_ms_per_call": {k: round(v, 5) for k, v in kmean.items()},
             "latency": lat,
         }
+        if no_gather is not None:
+            res["value_no_gather"] = round(no_gather, 2)
+            res["gather"] = {"gathered_passes": n_gathered, "of_passes": args.steps * args.passes, "every": state["gather_every"],
+                             "GBps_into_sink": round(n_gathered * F * (world - 1) * slabs[0][0].numel() / elapsed / 1e9, 2)}
+        if live is not None:
+            res["live"] = live
+        if pcie is not None:
+            res["pcie_inclusive_fps"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, gains, comp)
         print(json.dumps(res), flush=True)

@@ -20,21 +20,28 @@ def last_json(out):
 
 
 def test_single_gpu_line_has_the_contract_keys():
-    p = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     d = last_json(p.stdout)
     for k in KEYS:
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 1000 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 1000 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["verified"] is True, d["verified_how"]          # the benchmarked batches themselves: 9 frames re-stitched one per call, byte-identical
+    assert d["live"]["us_per_frame_p50"] > 0 and d["live"]["us_per_frame_p95"] >= d["live"]["us_per_frame_p50"]
+    assert d["pcie_inclusive_fps"]["value"] > 100
+    assert d["config"]["frames_per_step"] == d["config"]["frames_per_pass"] * d["config"]["passes_per_step"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "workload" in d["config"]
+    if r["traffic"]:      # the physical fraction next to the algorithmic one, with its provenance
+        assert abs(r["frac_traffic"] - r["traffic"] / (r["mean_launch_ms"] * 1e-3) / 8e12) < 1e-3 and "NOT measured in this run" in r["traffic_source"]
 
 
 def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     env = dict(os.environ, MS_BENCH_SHARE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                        "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "gather" in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
+    assert d["value_no_gather"] > 0 and d["gather"]["gathered_passes"] == 4 and d["verified"] is True

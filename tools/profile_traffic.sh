@@ -6,7 +6,7 @@ set -euo pipefail
 TAG=${1:-r01}; CFG=${2:-cfg2}; F=${3:-16}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
-B="python bench.py --steps 12 --warmup 3 --no-cpu-baseline --frames $F --streams 1 --config $CFG --calib"
+B="python bench.py --steps 12 --warmup 3 --no-live --no-pcie --no-verify --no-cpu-baseline --frames $F --streams 1 --config $CFG --calib"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $B > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $B > $OUT/bench_write.log 2>&1

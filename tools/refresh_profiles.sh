@@ -7,7 +7,7 @@ timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 python - "$OUT" "$TAG" <<'PY'
 import json, subprocess, sys
 out, tag = sys.argv[1], sys.argv[2]
-runs = {"cfg2_F1": ["--frames", "1", "--streams", "1", "--steps", "300", "--warmup", "30"],
+runs = {"cfg2_F1": ["--frames", "1", "--streams", "1", "--steps", "30", "--warmup", "3"],
         "cfg2_F4": ["--frames", "4", "--streams", "1"],
         "cfg2_F16_1stream": ["--frames", "16", "--streams", "1"],
         "cfg3": ["--config", "cfg3"],

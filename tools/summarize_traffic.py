@@ -59,6 +59,13 @@ def main(out, tag, cfg, frames):
         if k.startswith("k_down_t<unsigned char>"):
             alias["k_down_l0"] = v
     res["kernels"].update(alias)
+    # HBM bytes of one ms_stitch call (all per-frame kernels): what bench.py's frame_roofline.frac_traffic divides by the GPU time
+    per_frame = ("k_warp_t", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
+                 "k_blend<", "k_blend_top", "k_single_band")
+    steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t", "k_warp_a", "k_warp<"))] or [1])
+    res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()
+                                        if k.startswith(per_frame) and k not in alias))
+    res["calls"] = steps
     path = os.path.join(prof, "%s_traffic.json" % tag)
     json.dump(res, open(path, "w"), indent=1, sort_keys=True)
     shutil.copyfile(path, os.path.join(prof, "traffic_latest.json"))
