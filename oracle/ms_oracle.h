@@ -203,6 +203,8 @@ void orc_blender_destroy(orc_blender *b);
 void orc_blender_init_view(orc_blender *b, int view, const uint8_t *mask, size_t mstep);
 /* feed_online(gpu_img 8UC3 of size w[view] x h[view])  blenders.cpp:700-749 */
 void orc_blender_feed(orc_blender *b, int view, const uint8_t *img, size_t step);
+/* MultiBandBlender::feed, CPU branch, for a 16SC3 image (blenders.cpp:585-696); flavour 1 */
+void orc_blender_feed_cpu(orc_blender *b, int view, const int16_t *img, size_t step);
 /* blend(..., gpuOut, true): out = 16SC3 dst_roi_final-sized, out_mask 8UC1 (gpu_dst_mask_);
  * clears the accumulators afterwards (blenders.cpp:758-832). */
 void orc_blender_blend(orc_blender *b, int16_t *out, size_t ostep, uint8_t *out_mask, size_t mstep);
@@ -225,6 +227,18 @@ void orc_feather_feed(const int16_t *img, size_t istep, const float *w, size_t w
 void orc_feather_blend(int16_t *dst, size_t dstep, const float *dst_w, size_t dwstep, int rows, int cols, uint8_t *mask, size_t mstep);
 
 void orc_set_num_threads(int n);
+
+/* ---- the reference's CPU pipeline (a19): cv::pyrDown / cv::pyrUp as the CPU MultiBandBlender::feed / blend use them (ms_oracle_cpu.c) ---- */
+void orc_cv_pyr_down_16s(const int16_t *src, size_t sstep, int srows, int scols, int cn, int16_t *dst, size_t dstep);   /* (x + 128) >> 8 */
+void orc_cv_pyr_down_32f(const float *src, size_t sstep, int srows, int scols, float *dst, size_t dstep);              /* FltCast<float,8>, SSE order */
+void orc_cv_pyr_up_16s(const int16_t *src, size_t sstep, int srows, int scols, int cn, int16_t *dst, size_t dstep);     /* (x + 32) >> 6 */
+/* flavour 0 (default): the fork's GPU branch (init_gpu / feed_online / blend(gpuOut), CUDA kernel arithmetic);
+ * flavour 1: the CPU branch (feed :585-696 incl. the per-call weight pyramid, blend :832-851) with the CPU pyramids above.  Call before init_view. */
+void orc_blender_set_flavour(orc_blender *b, int flavour);
+/* the reference's CPU per-view stage as the surveyor's harness ran it: cv::remap (fixed-point, BORDER_CONSTANT) -> convertTo(gain)
+ * -> convertTo(16S) -> MultiBandBlender::feed; blender must be flavour 1 */
+void orc_stitch_online_cpu(orc_blender *b, int v, const uint8_t *src, size_t sstep, int srows, int scols,
+                           const float *xmap, const float *ymap, double gain);
 
 /* rounding / saturation helpers of the restatement, exported for the execution pin against the reference's header-only
  * cv::saturate_cast / cvRound (oracle/ref_pin/ref_pin.cpp, tests/test_ref_pin.py) */

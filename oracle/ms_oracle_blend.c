@@ -164,7 +164,26 @@ struct orc_blender {
     img_t *dst_w;      /* [nb+1] 32FC1  gpu_dst_band_weights_ */
     img_t **wpyr;      /* [n][nb+1] 32FC1 gpu_weight_pyr_gauss_vec_ */
     img_t **spyr;      /* [n][nb+1] 16SC3 gpu_src_pyr_laplace_vec   */
+    int flavour;       /* 0: GPU branch (CUDA arithmetic); 1: CPU branch (cv::pyrDown / pyrUp rounding, weight pyramid per feed) */
+    img_t *wmap;       /* [n] flavour 1: mask / 255 as feed receives it (the CPU feed rebuilds the weight pyramid on every call) */
 };
+
+static void pd16(const orc_blender *b, const img_t *s, img_t *d)
+{
+    if (b->flavour) orc_cv_pyr_down_16s((const int16_t *)s->data, s->step, s->rows, s->cols, 3, (int16_t *)d->data, d->step);
+    else orc_pyr_down_16s((const int16_t *)s->data, s->step, s->rows, s->cols, 3, (int16_t *)d->data, d->step);
+}
+static void pu16(const orc_blender *b, const img_t *s, img_t *d)
+{
+    if (b->flavour) orc_cv_pyr_up_16s((const int16_t *)s->data, s->step, s->rows, s->cols, 3, (int16_t *)d->data, d->step);
+    else orc_pyr_up_16s((const int16_t *)s->data, s->step, s->rows, s->cols, 3, (int16_t *)d->data, d->step);
+}
+static void pd32(const orc_blender *b, const img_t *s, img_t *d)
+{
+    if (b->flavour) orc_cv_pyr_down_32f((const float *)s->data, s->step, s->rows, s->cols, (float *)d->data, d->step);
+    else orc_pyr_down_32f((const float *)s->data, s->step, s->rows, s->cols, (float *)d->data, d->step);
+}
+void orc_blender_set_flavour(orc_blender *b, int flavour) { b->flavour = flavour; }
 
 static img_t img_alloc(int rows, int cols, int elem)
 {
@@ -197,6 +216,7 @@ orc_blender *orc_blender_create(int n, int num_bands, const int *cx, const int *
     }
     b->wpyr = (img_t **)calloc(n, sizeof(img_t *));
     b->spyr = (img_t **)calloc(n, sizeof(img_t *));
+    b->wmap = (img_t *)calloc(n, sizeof(img_t));
     for (int v = 0; v < n; ++v) {
         b->wpyr[v] = (img_t *)calloc(nb + 1, sizeof(img_t));
         b->spyr[v] = (img_t *)calloc(nb + 1, sizeof(img_t));
@@ -211,8 +231,9 @@ void orc_blender_destroy(orc_blender *b)
     for (int i = 0; i <= nb; ++i) { free(b->dst_lap[i].data); free(b->dst_w[i].data); }
     for (int v = 0; v < b->n; ++v) {
         for (int i = 0; i <= nb; ++i) { free(b->wpyr[v][i].data); free(b->spyr[v][i].data); }
-        free(b->wpyr[v]); free(b->spyr[v]);
+        free(b->wpyr[v]); free(b->spyr[v]); free(b->wmap[v].data);
     }
+    free(b->wmap);
     free(b->wpyr); free(b->spyr); free(b->dst_lap); free(b->dst_w);
     free(b->cx); free(b->cy); free(b->w); free(b->h); free(b->vg);
     free(b);
@@ -237,15 +258,65 @@ void orc_blender_init_view(orc_blender *b, int v, const uint8_t *mask, size_t ms
     orc_copy_make_border_const_32f((const float *)wm.data, wm.step, wm.rows, wm.cols,
                                    (float *)b->wpyr[v][0].data, b->wpyr[v][0].step,
                                    vg->top, vg->bottom, vg->left, vg->right);
-    free(wm.data);
+    free(b->wmap[v].data);
+    b->wmap[v] = wm;
     b->spyr[v][0] = img_alloc(pr, pc, 6);
     for (int i = 0; i < nb; ++i) {
         const img_t *s = &b->wpyr[v][i];
         b->wpyr[v][i + 1] = img_alloc((s->rows + 1) / 2, (s->cols + 1) / 2, 4);
-        orc_pyr_down_32f((const float *)s->data, s->step, s->rows, s->cols,
-                         (float *)b->wpyr[v][i + 1].data, b->wpyr[v][i + 1].step);
+        pd32(b, s, &b->wpyr[v][i + 1]);
         b->spyr[v][i + 1] = img_alloc((s->rows + 1) / 2, (s->cols + 1) / 2, 6);
     }
+}
+
+/* the pyramid part shared by feed_online (8U image) and the CPU feed (16S image): Gaussian chain, Laplacian in place, weighted accumulate */
+static void feed_from_level0(orc_blender *b, int v)
+{
+    const int nb = b->g.num_bands;
+    const orc_view_geom *vg = &b->vg[v];
+    img_t *sp = b->spyr[v];
+    for (int i = 0; i < nb; ++i) pd16(b, &sp[i], &sp[i + 1]);
+    for (int i = 0; i < nb; ++i) {
+        img_t up = img_alloc(sp[i + 1].rows * 2, sp[i + 1].cols * 2, 6);
+        pu16(b, &sp[i + 1], &up);
+        orc_sub_16s((const int16_t *)sp[i].data, sp[i].step, (const int16_t *)up.data, up.step,
+                    (int16_t *)sp[i].data, sp[i].step, sp[i].rows, sp[i].cols * 3);
+        free(up.data);
+    }
+    int y_tl = vg->y_tl, y_br = vg->y_br, x_tl = vg->x_tl, x_br = vg->x_br;
+    for (int i = 0; i <= nb; ++i) {
+        img_t *dl = &b->dst_lap[i], *dw = &b->dst_w[i];
+        orc_add_src_weight_32f((const int16_t *)sp[i].data, sp[i].step,
+                               (const float *)b->wpyr[v][i].data, b->wpyr[v][i].step,
+                               (int16_t *)((char *)dl->data + (size_t)y_tl * dl->step) + 3 * x_tl, dl->step,
+                               (float *)((char *)dw->data + (size_t)y_tl * dw->step) + x_tl, dw->step,
+                               y_br - y_tl, x_br - x_tl);
+        x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
+    }
+}
+
+/* MultiBandBlender::feed, CPU branch (blenders.cpp:585-696) for a 16SC3 image: copyMakeBorder(REFLECT) :587, createLaplacePyr :595
+ * (16S branch :997-1008), the weight map's Gaussian pyramid REBUILT on every call :603-624, accumulate :633-690 */
+void orc_blender_feed_cpu(orc_blender *b, int v, const int16_t *img, size_t step)
+{
+    const int nb = b->g.num_bands;
+    const orc_view_geom *vg = &b->vg[v];
+    img_t *sp = b->spyr[v];
+    for (int y = 0; y < sp[0].rows; ++y) {          /* BORDER_REFLECT on 16SC3: same index map as the 8U version */
+        int sy = y - vg->top;
+        sy = sy < 0 ? -sy - 1 : (sy >= b->h[v] ? 2 * b->h[v] - sy - 1 : sy);
+        const int16_t *s = (const int16_t *)((const char *)img + (size_t)sy * step);
+        int16_t *d = (int16_t *)((char *)sp[0].data + (size_t)y * sp[0].step);
+        for (int x = 0; x < sp[0].cols; ++x) {
+            int sx = x - vg->left;
+            sx = sx < 0 ? -sx - 1 : (sx >= b->w[v] ? 2 * b->w[v] - sx - 1 : sx);
+            d[3 * x] = s[3 * sx]; d[3 * x + 1] = s[3 * sx + 1]; d[3 * x + 2] = s[3 * sx + 2];
+        }
+    }
+    orc_copy_make_border_const_32f((const float *)b->wmap[v].data, b->wmap[v].step, b->wmap[v].rows, b->wmap[v].cols,
+                                   (float *)b->wpyr[v][0].data, b->wpyr[v][0].step, vg->top, vg->bottom, vg->left, vg->right);
+    for (int i = 0; i < nb; ++i) pd32(b, &b->wpyr[v][i], &b->wpyr[v][i + 1]);
+    feed_from_level0(b, v);
 }
 
 /* MultiBandBlender::feed_online  blenders.cpp:700-749 */
@@ -261,30 +332,9 @@ void orc_blender_feed(orc_blender *b, int v, const uint8_t *img, size_t step)
     /* convertTo CV_16S :713 */
     orc_convert_8u_16s((const uint8_t *)bord.data, bord.step, (int16_t *)sp[0].data, sp[0].step, sp[0].rows, sp[0].cols * 3);
     free(bord.data);
-    /* pyrDown chain :714-715 */
-    for (int i = 0; i < nb; ++i)
-        orc_pyr_down_16s((const int16_t *)sp[i].data, sp[i].step, sp[i].rows, sp[i].cols, 3,
-                         (int16_t *)sp[i + 1].data, sp[i + 1].step);
-    /* pyrUp + subtract in place :716-720 */
-    for (int i = 0; i < nb; ++i) {
-        img_t up = img_alloc(sp[i + 1].rows * 2, sp[i + 1].cols * 2, 6);
-        orc_pyr_up_16s((const int16_t *)sp[i + 1].data, sp[i + 1].step, sp[i + 1].rows, sp[i + 1].cols, 3,
-                       (int16_t *)up.data, up.step);
-        orc_sub_16s((const int16_t *)sp[i].data, sp[i].step, (const int16_t *)up.data, up.step,
-                    (int16_t *)sp[i].data, sp[i].step, sp[i].rows, sp[i].cols * 3);
-        free(up.data);
-    }
-    /* weighted accumulate :722-746 */
-    int y_tl = vg->y_tl, y_br = vg->y_br, x_tl = vg->x_tl, x_br = vg->x_br;
-    for (int i = 0; i <= nb; ++i) {
-        img_t *dl = &b->dst_lap[i], *dw = &b->dst_w[i];
-        orc_add_src_weight_32f((const int16_t *)sp[i].data, sp[i].step,
-                               (const float *)b->wpyr[v][i].data, b->wpyr[v][i].step,
-                               (int16_t *)((char *)dl->data + (size_t)y_tl * dl->step) + 3 * x_tl, dl->step,
-                               (float *)((char *)dw->data + (size_t)y_tl * dw->step) + x_tl, dw->step,
-                               y_br - y_tl, x_br - x_tl);
-        x_tl /= 2; y_tl /= 2; x_br /= 2; y_br /= 2;
-    }
+    /* pyrDown chain :714-715, pyrUp + subtract in place :716-720, weighted accumulate :722-746 */
+    (void)nb; (void)vg;
+    feed_from_level0(b, v);
 }
 
 /* MultiBandBlender::blend(dst, dst_mask, gpuOut, true)  blenders.cpp:758-832 */
@@ -300,7 +350,7 @@ void orc_blender_blend(orc_blender *b, int16_t *out, size_t ostep, uint8_t *out_
     for (int i = nb; i > 0; --i) {
         img_t *s = &b->dst_lap[i], *d = &b->dst_lap[i - 1];
         img_t up = img_alloc(s->rows * 2, s->cols * 2, 6);
-        orc_pyr_up_16s((const int16_t *)s->data, s->step, s->rows, s->cols, 3, (int16_t *)up.data, up.step);
+        pu16(b, s, &up);
         orc_add_16s((const int16_t *)up.data, up.step, (const int16_t *)d->data, d->step,
                     (int16_t *)d->data, d->step, d->rows, d->cols * 3);
         free(up.data);
@@ -334,6 +384,22 @@ const int16_t *orc_blender_src_level(const orc_blender *b, int view, int level, 
     const img_t *m = &b->spyr[view][level];
     *rows = m->rows; *cols = m->cols; *step = m->step;
     return (const int16_t *)m->data;
+}
+
+/* The reference's CPU per-view stage (the surveyor's harness, SURVEY App. D: remap + gain + convert 79 ms, prepare + feed 95 ms per frame):
+ * cv::remap(INTER_LINEAR, BORDER_CONSTANT) in its fixed-point CPU arithmetic -> convertTo(same type, gain) -> convertTo(CV_16S) -> feed */
+void orc_stitch_online_cpu(orc_blender *b, int v, const uint8_t *src, size_t sstep, int srows, int scols,
+                           const float *xmap, const float *ymap, double gain)
+{
+    const int w = b->w[v], h = b->h[v];
+    const size_t step3 = (size_t)w * 3, stepf = sizeof(float) * (size_t)w;
+    uint8_t *img = (uint8_t *)malloc(step3 * (size_t)h);
+    orc_cv_remap_linear_8u(src, sstep, srows, scols, 3, xmap, stepf, ymap, stepf, img, step3, h, w);
+    orc_convert_scale_8u(img, step3, img, step3, h, w * 3, gain);
+    int16_t *img16 = (int16_t *)malloc(step3 * 2 * (size_t)h);
+    orc_convert_8u_16s(img, step3, img16, step3 * 2, h, w * 3);
+    orc_blender_feed_cpu(b, v, img16, step3 * 2);
+    free(img); free(img16);
 }
 
 /* stitch_online  APP/timed.cpp:56-121 (compose_scale == 1 branch :90, gain :94, CPW :96-104, feed :116) */

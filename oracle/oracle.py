@@ -379,11 +379,38 @@ def feather_blend(corners, imgs8u, masks, sharpness=0.02):
     return dst, mask, roi
 
 
+def cv_pyr_down_16s(src):
+    """cv::pyrDown on 16S (CPU): (sum + 128) >> 8, BORDER_REFLECT_101  pyramids.cpp:851-964"""
+    src = np.ascontiguousarray(src, np.int16)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty(((src.shape[0] + 1) // 2, (src.shape[1] + 1) // 2) + (() if src.ndim == 2 else (cn,)), np.int16)
+    lib().orc_cv_pyr_down_16s(_p(src), _st(src), src.shape[0], src.shape[1], cn, _p(dst), _st(dst))
+    return dst
+
+
+def cv_pyr_down_32f(src):
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.empty(((src.shape[0] + 1) // 2, (src.shape[1] + 1) // 2), np.float32)
+    lib().orc_cv_pyr_down_32f(_p(src), _st(src), src.shape[0], src.shape[1], _p(dst), _st(dst))
+    return dst
+
+
+def cv_pyr_up_16s(src):
+    """cv::pyrUp on 16S (CPU) to twice the size: (sum + 32) >> 6  pyramids.cpp:976-1078"""
+    src = np.ascontiguousarray(src, np.int16)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty((src.shape[0] * 2, src.shape[1] * 2) + (() if src.ndim == 2 else (cn,)), np.int16)
+    lib().orc_cv_pyr_up_16s(_p(src), _st(src), src.shape[0], src.shape[1], cn, _p(dst), _st(dst))
+    return dst
+
+
 class Blender:
     """The fork's GPU MultiBandBlender (prepare / init_gpu / feed_online / blend(gpuOut))."""
 
-    def __init__(self, corners, sizes, num_bands=5):
+    def __init__(self, corners, sizes, num_bands=5, cpu_flavour=False):
+        """cpu_flavour: the reference's CPU branch (cv::pyrDown / pyrUp rounding, weight pyramid rebuilt per feed) instead of the GPU branch."""
         self.n = len(corners)
+        self.cpu_flavour = bool(cpu_flavour)
         self.corners = [tuple(c) for c in corners]
         self.sizes = [tuple(s) for s in sizes]
         self._h = C.c_void_p(lib().orc_blender_create(
@@ -393,6 +420,8 @@ class Blender:
         lib().orc_blender_get_geom(self._h, C.byref(g))
         self.geom = g
         self.num_bands = g.num_bands
+        if cpu_flavour:
+            lib().orc_blender_set_flavour(self._h, 1)
 
     def close(self):
         if self._h:
@@ -424,6 +453,19 @@ class Blender:
         img = np.ascontiguousarray(img, np.uint8)
         assert img.shape == (self.sizes[v][1], self.sizes[v][0], 3)
         lib().orc_blender_feed(self._h, v, _p(img), _st(img))
+
+    def feed_cpu(self, v, img16):
+        """MultiBandBlender::feed, CPU branch (blenders.cpp:585-696), 16SC3 image."""
+        img16 = np.ascontiguousarray(img16, np.int16)
+        assert self.cpu_flavour and img16.shape == (self.sizes[v][1], self.sizes[v][0], 3)
+        lib().orc_blender_feed_cpu(self._h, v, _p(img16), _st(img16))
+
+    def stitch_online_cpu(self, v, src, xmap, ymap, gain):
+        """cv::remap (CPU fixed-point) -> convertTo(gain) -> convertTo(16S) -> CPU feed: the reference's CPU per-view stage."""
+        w, h = self.sizes[v]
+        xmap = np.ascontiguousarray(xmap, np.float32); ymap = np.ascontiguousarray(ymap, np.float32)
+        assert self.cpu_flavour and xmap.shape == (h, w) and ymap.shape == (h, w)
+        lib().orc_stitch_online_cpu(self._h, v, _p(src), _st(src), src.shape[0], src.shape[1], _p(xmap), _p(ymap), C.c_double(gain))
 
     def stitch_online(self, v, src, xmap, ymap, gain, xmesh=None, ymesh=None, want_warped=False):
         w, h = self.sizes[v]

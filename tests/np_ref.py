@@ -131,3 +131,53 @@ def cv_remap_linear_np(src, mapx, mapy):
         acc += np.where(ok[..., None], px, 0) * wts[t][..., None]
     out = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
     return out[..., 0] if src.ndim == 2 else out
+
+
+# ---- the reference's CPU pyramids (cv::pyrDown / cv::pyrUp, OCV/imgproc/src/pyramids.cpp:851-1078), numpy statements --------------------
+def cv_pyr_down_16s(src):
+    """pyrDown_<FixPtCast<short,8>>: integer 5x5 binomial, BORDER_REFLECT_101, (sum + 128) >> 8 (ties round UP, unlike the CUDA kernel)."""
+    h, w = src.shape[:2]
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    oy, ox = np.arange((h + 1) // 2) * 2, np.arange((w + 1) // 2) * 2
+    s = src.astype(np.int64)
+    acc = 0
+    for a in range(5):
+        rows = s[r101(oy + a - 2, h)]
+        for b in range(5):
+            acc = acc + k[a] * k[b] * rows[:, r101(ox + b - 2, w)]
+    return ((acc + 128) >> 8).astype(np.int16)
+
+
+def cv_pyr_up_16s(src):
+    """pyrUp_<FixPtCast<short,6>> to twice the size: the same taps and source indexing (left / top mirrored, right / bottom replicated:
+    pyramids.cpp:1013-1031 spell out 6a + 2b and b + 7c) as the CUDA kernel, (sum + 32) >> 6."""
+    h, w = src.shape[:2]
+    s = src.astype(np.int64)
+    ys, xs = np.arange(-2, 2 * h + 2), np.arange(-2, 2 * w + 2)
+    full = s[np.minimum(np.abs(ys >> 1), h - 1)][:, np.minimum(np.abs(xs >> 1), w - 1)]
+    m = (ys % 2 == 0)[:, None] & (xs % 2 == 0)[None, :]
+    z = full * (m[..., None] if src.ndim == 3 else m)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    acc = 0
+    for a in range(5):
+        for b in range(5):
+            acc = acc + k[a] * k[b] * z[a:a + 2 * h, b:b + 2 * w]
+    return ((acc + 32) >> 6).astype(np.int16)
+
+
+def cv_pyr_down_32f(src):
+    """pyrDown_<FltCast<float,8>, PyrDownVec_32f> (x86 SSE build): fp32 throughout; horizontal ((6c + 4(b + d)) + a) + e; vertical in the SSE
+    order ((r0 + r4) + (r2 + r2)) + 4((r1 + r3) + r2) for the first (width // 8) * 8 columns and ((6 r2 + 4 (r1 + r3)) + r0) + r4 for the rest;
+    then * (1 / 256)."""
+    f = np.float32
+    h, w = src.shape
+    oy, ox = np.arange((h + 1) // 2) * 2, np.arange((w + 1) // 2) * 2
+    s = src.astype(f)
+    col = [s[:, r101(ox + b - 2, w)] for b in range(5)]
+    hrow = ((col[2] * f(6) + (col[1] + col[3]) * f(4)) + col[0]) + col[4]          # (h, dcols) fp32, evaluated op by op
+    r = [hrow[r101(oy + a - 2, h)] for a in range(5)]
+    vec = ((r[0] + r[4]) + (r[2] + r[2])) + ((r[1] + r[3]) + r[2]) * f(4)
+    tail = ((r[2] * f(6) + (r[1] + r[3]) * f(4)) + r[0]) + r[4]
+    nvec = (len(ox) // 8) * 8
+    out = np.where(np.arange(len(ox))[None, :] < nvec, vec, tail).astype(f)
+    return (out * f(1.0 / 256)).astype(f)
