@@ -176,6 +176,35 @@ MS_API int ms_warp_roi(int projection, const float *K, const float *R, float sca
 /* detail::resultRoi(corners, sizes)  OCV/stitching/src/util.cpp:125-138 */
 MS_API int ms_result_roi(int n, const ms_rect *view_rois, ms_rect *roi);
 
+/* calibrateCameras + the scale bookkeeping of stitch_calib / warpImages (APP/calibration.cpp:28-68, :101-116, :147-181, :269-288; defs.h:51-53):
+ * the fixed rig model -- view i rotated by 2 pi i / N about +y, principal point at the image centre, focal = ppx / tan(hfov / 2), aspect 1 --
+ * and every scale the calibration derives from the three megapixel budgets.  Host arithmetic in the reference's types (double scales,
+ * float rotation angle, K().convertTo(CV_32F)). */
+#define MS_MAX_VIEWS 16
+typedef struct ms_rig_params {
+    int num_views;                 /* NUM_IMAGES (defs.h:37) */
+    int src_width, src_height;     /* full_img_size */
+    double hfov_deg;               /* 90 in the reference (calibration.cpp:31) */
+    double work_megapix;           /* WORK_MEGAPIX 0.6; negative = original size (defs.h:51, calibration.cpp:269-277) */
+    double seam_megapix;           /* SEAM_MEAGPIX 0.01 (defs.h:52, calibration.cpp:280) */
+    double compose_megapix;        /* COMPOSE_MEGAPIX 1.4; not positive = compose at the original resolution (defs.h:53, calibration.cpp:147-150) */
+} ms_rig_params;
+typedef struct ms_rig {
+    double work_scale, seam_scale, seam_work_aspect, compose_scale, compose_work_aspect;
+    float warped_image_scale;      /* static_cast<float>(cameras[0].focal) at work scale (calibration.cpp:288) */
+    float seam_warp_scale;         /* static_cast<float>(warped_image_scale * seam_work_aspect): the seam-scale warper (:101) */
+    float compose_warp_scale;      /* warped_image_scale * static_cast<float>(compose_work_aspect): the compose warper (:156) = ms_config.warp_scale */
+    int resize_input;              /* |compose_scale - 1| > 0.1: every frame goes through cuda::resize before the remap (timed.cpp:75, calibration.cpp:161) */
+    int compose_width, compose_height;   /* cvRound(full * compose_scale) if resize_input, else the full size (:163-164) = ms_config.src_width / height */
+    float K_compose[MS_MAX_VIEWS][9];    /* cameras[i].K() after *= compose_work_aspect, as CV_32F (:171-176) -> ms_set_camera */
+    float K_seam[MS_MAX_VIEWS][9];       /* K at work scale as CV_32F, four entries times (float)seam_work_aspect (:108-116) -> ms_calibrate_seam */
+    float R[MS_MAX_VIEWS][9];            /* Rz * Ry * Rx with only Ry non-trivial (:36-55) */
+} ms_rig;
+MS_API int ms_calibrate_cameras(const ms_rig_params *params, ms_rig *rig);
+/* blend_width = sqrt(area(resultRoi)) * BLEND_STRENGTH / 100 and mb->setNumBands(ceil(log2(blend_width)) - 1) (calibration.cpp:183-194, defs.h:55);
+ * num_bands = 0 where the reference falls back to Blender::NO (blend_width < 1). */
+MS_API int ms_num_bands_rule(int pano_width, int pano_height, float blend_strength, float *blend_width, int *num_bands);
+
 /* =============================================================================================
  * 3. The compositor context: calibration tables once, then one fused launch sequence per frame
  * ============================================================================================= */
@@ -223,7 +252,9 @@ MS_API int ms_build_masks(ms_ctx *ctx, int mode, ms_stream stream);
  * seam_scale, warp image (LINEAR/REFLECT) and a 255-mask (NEAREST/CONSTANT) with the per-view seam intrinsics K_seam (HOST, N x 9,
  * = K at work scale times seam_work_aspect, calibration.cpp:110-116) and seam_warp_scale, estimate the exposure gains
  * (GainCompensator::feed, exposure_compensate.cpp:71-145), cut Voronoi seams, optionally dilate, resize the seam masks to the compose
- * mask size and AND them with warp(255) at compose scale.  Leaves the masks ready for ms_init_blender; gains_out (HOST, N) may be NULL. */
+ * mask size and AND them with warp(255) at compose scale.  Leaves the masks ready for ms_init_blender; gains_out (HOST, N) may be NULL.
+ * The full frames may be larger than the context's source size (compose_scale < 1: the context composites the resized frames, the seam
+ * images are still cut from the full ones, calibration.cpp:95); all N must have one size. */
 typedef struct ms_seam_params {
     double seam_scale;        /* min(1, sqrt(SEAM_MEGAPIX*1e6 / area))  (calibration.cpp:280)            */
     float seam_warp_scale;    /* warped_image_scale * seam_work_aspect  (calibration.cpp:101)             */

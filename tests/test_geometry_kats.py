@@ -73,3 +73,26 @@ def test_plane_and_pole_paths_agree(oracle, ms):
     p = math.radians(80.0)
     up = oracle.warp_roi(2, K, np.array([[1, 0, 0], [0, math.cos(p), -math.sin(p)], [0, math.sin(p), math.cos(p)]], np.float32), 100.0, 320, 240)
     assert up[1] + up[3] - 1 == int(np.float32(math.pi * 100.0)), "the pole fix-up must extend the ROI to v = pi*scale"
+
+
+def test_calibrate_cameras_in_product_code_equals_the_test_side_rig_model(ms):
+    """a17: calibrateCameras + stitch_calib's scale bookkeeping now live behind the ABI (ms_calibrate_cameras, csrc/geometry.cpp; msshim::calibrateCameras /
+    stitch_calib use it).  synth.reference_rig stays as the independent test-side statement of calibration.cpp:28-68, 101-116, 147-181, 269-288:
+    every scale and every fp32 matrix entry must agree exactly, for the shipped budgets (defs.h:51-53) and for the BASELINE full-resolution rig."""
+    import synth
+    for n, w, h, hfov, budgets in [(6, 1920, 1080, 90.0, (0.6, 0.01, 1.4)), (6, 1920, 1080, 90.0, (0.6, 0.01, -1.0)), (6, 1920, 1080, 90.0, (-1.0, 0.01, -1.0)),
+                                   (12, 3840, 2160, 60.0, (0.6, 0.01, 1.4)), (4, 200, 150, 110.0, (0.6, 0.01, -1.0))]:
+        a = ms.calibrate_cameras(n, w, h, hfov, *budgets)
+        b = synth.reference_rig(n, w, h, budgets[0], budgets[1], budgets[2], hfov)
+        for k in ("work_scale", "seam_scale", "seam_work_aspect", "compose_scale", "warped_image_scale", "seam_warp_scale", "compose_warp_scale"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        for i in range(n):
+            for k in ("K_seam", "K_compose", "R"):
+                assert np.array_equal(a[k][i], b[k][i]), (k, i)
+        resized = abs(a["compose_scale"] - 1) > 0.1
+        assert bool(a["resize_input"]) == resized
+        assert (a["compose_width"], a["compose_height"]) == ((int(np.rint(w * a["compose_scale"])), int(np.rint(h * a["compose_scale"]))) if resized else (w, h))
+    # the num_bands rule of calibration.cpp:183-194 on the reference rig's panoramas (SURVEY App. C sizes): 6 bands, as the survey notes
+    assert ms.num_bands_rule(3839, 627)[1] == 6 and ms.num_bands_rule(3839, 687)[1] == 6
+    bw, nb = ms.num_bands_rule(10, 9)
+    assert bw < 1.0 and nb == 0                                     # blend_width < 1: the reference falls back to Blender::NO

@@ -78,3 +78,39 @@ def test_host_app_solves_meshes_while_stitching(ms, cuda, tmp_path):
         assert 1.0 < info["max_mesh_displacement_px"] < 20.0
         got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
         assert (got.max(axis=2) > 0).mean() > 0.25
+
+
+def test_host_app_reference_calibration_matches_the_same_steps_through_the_binding(ms, cuda, tmp_path):
+    """stitch_app --reference-calib = msshim::stitch_calib (calibration.cpp:252-311 in product code): rig and scales from ms_calibrate_cameras, the shipped
+    cylindrical warper, compose-scale ROIs -> num_bands rule, seam-scale gains + Voronoi seams from the first frames, and (COMPOSE_MEGAPIX 1.4 on 1080p:
+    compose_scale 0.82) cuda::resize of every frame before the remap.  The same steps written out through the Python binding must give the same panorama."""
+    n, w, h = 6, 1920, 1080
+    info, dump = run_app(tmp_path, "--reference-calib", "--frames", 6)
+    ow, oh = [int(v) for v in info["out"].split("x")]
+    got = np.fromfile(dump, np.uint8).reshape(oh, ow, 3)
+    rig = ms.calibrate_cameras(n, w, h, 90.0, 0.6, 0.01, 1.4)
+    assert rig["resize_input"] and (rig["compose_width"], rig["compose_height"]) == (1578, 887)
+    cw, ch = rig["compose_width"], rig["compose_height"]
+    rois = [ms.warp_roi(ms.PROJ_CYLINDRICAL, rig["K_compose"][i], rig["R"][i], rig["compose_warp_scale"], cw, ch) for i in range(n)]
+    pano = ms.result_roi(rois)
+    bw, nb = ms.num_bands_rule(pano[2], pano[3], 5.0)
+    assert info["bands"] == min(nb, int(np.ceil(np.log2(max(pano[2], pano[3])))))
+    fit_w = (2 * max(abs(pano[0]), abs(pano[0] + pano[2])) + 1) & ~1
+    fit_h = (2 * max(abs(pano[1]), abs(pano[1] + pano[3])) + 1) & ~1
+    assert (ow, oh) == (fit_w, fit_h)
+    comp = ms.Compositor(n, (cw, ch), ms.PROJ_CYLINDRICAL, rig["compose_warp_scale"], num_bands=nb, out_size=(ow, oh))
+    for i in range(n):
+        comp.set_camera(i, rig["K_compose"][i], rig["R"][i])
+    comp.build_maps()
+    full = [to_dev(synth.frame(w, h, i, 0, noise=False)) for i in range(n)]
+    gains = comp.calibrate_seam(full, np.stack(rig["K_seam"]), rig["seam_scale"], rig["seam_warp_scale"], dilate=False, estimate_gains=True)
+    assert all(0.5 < g < 2.0 for g in gains)
+    comp.init_blender()
+    small = [ms.resize_linear(f, fx=rig["compose_scale"], fy=rig["compose_scale"]) for f in full]
+    assert small[0].shape[:2] == (ch, cw)
+    out8 = torch.zeros((oh, ow, 3), dtype=torch.uint8, device=cuda)
+    comp.stitch([small], out8u=[out8])
+    torch.cuda.synchronize()
+    assert np.array_equal(got, host(out8))
+    assert got.any()
+    comp.close()

@@ -272,4 +272,19 @@ int ms_result_roi(int n, const ms_rect *rois, ms_rect *roi)
     return MS_OK;
 }
 
+int ms_calibrate_cameras(const ms_rig_params *q, ms_rig *rig)
+{
+    MS_CHECK(q && rig, "ms_calibrate_cameras: null argument");
+    MS_CHECK(q->num_views >= 1 && q->num_views <= MS_MAX_VIEWS && q->src_width > 1 && q->src_height > 1, "ms_calibrate_cameras: bad rig (%d views, %dx%d)", q->num_views, q->src_width, q->src_height);
+    MS_CHECK(q->hfov_deg > 0 && q->hfov_deg < 180 && q->seam_megapix > 0 && q->work_megapix != 0, "ms_calibrate_cameras: bad field of view / megapixel budgets");
+    return calibrate_cameras(*q, *rig);
+}
+
+int ms_num_bands_rule(int pano_width, int pano_height, float blend_strength, float *blend_width, int *num_bands)
+{
+    MS_CHECK(pano_width > 0 && pano_height > 0 && blend_width && num_bands, "ms_num_bands_rule: bad argument");
+    num_bands_rule(pano_width, pano_height, blend_strength, blend_width, num_bands);
+    return MS_OK;
+}
+
 }  // extern "C"

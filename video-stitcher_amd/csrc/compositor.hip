@@ -1933,7 +1933,10 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
     MS_CHECK(prm->seam_scale > 0 && prm->seam_scale <= 1.0 && prm->seam_warp_scale > 0, "ms_calibrate_seam: bad scales");
     hipStream_t st = as_stream(stream);
     const int N = c->N, W = c->cfg.src_width, H = c->cfg.src_height;
-    const int ws = (int)__builtin_rint(W * prm->seam_scale), hs = (int)__builtin_rint(H * prm->seam_scale);   // resize.cpp:74
+    // the seam images are cut from the FULL frames (calibration.cpp:95), which are larger than the context's source size when compose_scale < 1
+    const int FW = full_imgs[0].cols, FH = full_imgs[0].rows;
+    MS_CHECK(FW >= W && FH >= H, "ms_calibrate_seam: full frames %dx%d smaller than the context's source size %dx%d", FW, FH, W, H);
+    const int ws = (int)__builtin_rint(FW * prm->seam_scale), hs = (int)__builtin_rint(FH * prm->seam_scale);   // resize.cpp:74
     MS_CHECK(ws >= 2 && hs >= 2, "ms_calibrate_seam: seam image %dx%d too small", ws, hs);
     if (int e = alloc_masks(c)) return e;
     std::vector<ms_rect> rs(N);
@@ -1941,8 +1944,8 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
     DevBuf seam, mapx, mapy, wimg, wmask;
     if (int e = seam.alloc((size_t)ws * hs * 3)) return e;
     for (int i = 0; i < N; ++i) {
-        MS_CHECK(full_imgs[i].data && full_imgs[i].type == MS_8UC3 && full_imgs[i].rows == H && full_imgs[i].cols == W,
-                 "ms_calibrate_seam: image %d must be 8UC3 %dx%d", i, W, H);
+        MS_CHECK(full_imgs[i].data && full_imgs[i].type == MS_8UC3 && full_imgs[i].rows == FH && full_imgs[i].cols == FW,
+                 "ms_calibrate_seam: image %d must be 8UC3 %dx%d like image 0", i, FW, FH);
         ms_image simg{seam.p, (size_t)ws * 3, ws, hs, MS_8UC3};
         if (int e = launch_resize_linear(full_imgs[i], simg, prm->seam_scale, prm->seam_scale, st)) return e;        // calibration.cpp:95
         const float *Ks = K_seam + 9 * i;

@@ -391,4 +391,47 @@ bool estimate_gains(int n, const ms_rect *rois, const uint8_t *const *images, co
     return true;
 }
 
+// calibrateCameras + scale bookkeeping (APP/calibration.cpp:28-68, 101-116, 147-181, 269-288), in the reference's types
+int calibrate_cameras(const ms_rig_params &q, ms_rig &r)
+{
+    memset(&r, 0, sizeof(r));
+    const double area = (double)q.src_width * (double)q.src_height;
+    r.work_scale = q.work_megapix < 0 ? 1.0 : std::min(1.0, std::sqrt(q.work_megapix * 1e6 / area));       // :269-277
+    r.seam_scale = std::min(1.0, std::sqrt(q.seam_megapix * 1e6 / area));                                  // :280
+    r.seam_work_aspect = r.seam_scale / r.work_scale;                                                       // :281
+    r.compose_scale = q.compose_megapix > 0 ? std::min(1.0, std::sqrt(q.compose_megapix * 1e6 / area)) : 1.0;   // :147-150 (compose_scale starts at 1)
+    r.compose_work_aspect = r.compose_scale / r.work_scale;                                                 // :153
+    const double PI = 3.14159265358979323846;
+    const double fov = q.hfov_deg * PI / 180.0, focal_tmp = 1.0 / std::tan(fov * 0.5);                      // :31-32
+    const double ppx = ((double)q.src_width * r.work_scale) / 2.0, ppy = ((double)q.src_height * r.work_scale) / 2.0, focal = focal_tmp * ppx;   // :57-66
+    r.warped_image_scale = (float)focal;                                                                    // :288
+    r.seam_warp_scale = (float)((double)r.warped_image_scale * r.seam_work_aspect);                         // :101 (float * double -> double -> float)
+    r.compose_warp_scale = r.warped_image_scale * (float)r.compose_work_aspect;                             // :156
+    r.resize_input = std::fabs(r.compose_scale - 1) > 1e-1;                                                 // :161
+    r.compose_width = r.resize_input ? (int)std::nearbyint((double)q.src_width * r.compose_scale) : q.src_width;     // cvRound :163-164
+    r.compose_height = r.resize_input ? (int)std::nearbyint((double)q.src_height * r.compose_scale) : q.src_height;
+    const float swa = (float)r.seam_work_aspect;
+    for (int i = 0; i < q.num_views; ++i) {
+        const float rot = (float)(2.0 * PI * (double)(float)i / (double)q.num_views);                       // :35
+        const float c = (float)std::cos((double)rot), s = (float)std::sin((double)rot);
+        const float R[9] = {c, 0.f, s, 0.f, 1.f, 0.f, -s, 0.f, c};                                          // Rz * Ry * Rx, Rx = Rz = I (exact)
+        memcpy(r.R[i], R, sizeof(R));
+        // CameraParams::K(): (focal, 0, ppx; 0, focal * aspect, ppy; 0, 0, 1) in double, then convertTo(CV_32F)
+        const float Kw[9] = {(float)focal, 0.f, (float)ppx, 0.f, (float)focal, (float)ppy, 0.f, 0.f, 1.f};
+        memcpy(r.K_seam[i], Kw, sizeof(Kw));
+        r.K_seam[i][0] *= swa; r.K_seam[i][2] *= swa; r.K_seam[i][4] *= swa; r.K_seam[i][5] *= swa;         // :112-116
+        const double fc = focal * r.compose_work_aspect, px = ppx * r.compose_work_aspect, py = ppy * r.compose_work_aspect;   // :171-173
+        const float Kc[9] = {(float)fc, 0.f, (float)px, 0.f, (float)fc, (float)py, 0.f, 0.f, 1.f};
+        memcpy(r.K_compose[i], Kc, sizeof(Kc));
+    }
+    return MS_OK;
+}
+
+void num_bands_rule(int pano_w, int pano_h, float blend_strength, float *blend_width, int *num_bands)
+{
+    const float bw = std::sqrt((float)((long long)pano_w * pano_h)) * blend_strength / 100.f;               // :183
+    *blend_width = bw;
+    *num_bands = bw < 1.f ? 0 : (int)(std::ceil(std::log((double)bw) / std::log(2.)) - 1.);                 // :185-193
+}
+
 }  // namespace ms

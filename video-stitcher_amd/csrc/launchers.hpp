@@ -35,6 +35,8 @@ void set_camera_params(Projector &p, const float *K, const float *R, const float
 void k_rinv_gemm(const float *K, const float *R, float *k_rinv);   // warpers_cuda.cpp: K * R.t()
 void r_kinv_gemm(const float *K, const float *R, float *r_kinv);
 ms_rect warp_roi(int proj, const Projector &p, int src_w, int src_h);
+int calibrate_cameras(const ms_rig_params &q, ms_rig &r);
+void num_bands_rule(int pano_w, int pano_h, float blend_strength, float *blend_width, int *num_bands);
 ms_rect result_roi(int n, const ms_rect *rois);
 
 struct BlendGeom { int num_bands; ms_rect dst_roi_final, dst_roi; };

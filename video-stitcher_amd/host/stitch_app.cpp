@@ -17,6 +17,9 @@
 //
 // Usage: stitch_app [--views 6] [--size 1920x1080] [--out 3840x1920] [--hfov 90] [--bands 5] [--frames 300] [--cpw]
 //                   [--i420] [--nv12] [--dump pano.bin] [--no-upload] [--solve-mesh]
+//                   [--reference-calib [--work-megapix 0.6] [--seam-megapix 0.01] [--compose-megapix 1.4]]
+// --reference-calib runs msshim::stitch_calib (calibration.cpp:252-311): the reference's rig and scale bookkeeping, cylindrical warper, seam-scale
+// gains + Voronoi seams from the first frames, the num_bands rule, and -- with the default COMPOSE_MEGAPIX -- cuda::resize of every frame.
 // Prints one JSON line: end-to-end frames/s INCLUDING the PCIe upload of every source frame (unlike bench.py).
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -71,6 +74,8 @@ struct Options {
     int views = 6, w = 1920, h = 1080, out_w = 3840, out_h = 1920, bands = 5, frames = 300;
     double hfov = 90.0;
     bool cpw = false, i420 = false, upload = true, nv12 = false, solve_mesh = false;
+    bool reference_calib = false;               // stitch_calib as the reference ships it: cylindrical warper, megapixel budgets of defs.h, seam-scale pipeline
+    double work_mp = 0.6, seam_mp = 0.01, compose_mp = 1.4;      // WORK_MEGAPIX, SEAM_MEAGPIX, COMPOSE_MEGAPIX (defs.h:51-53)
     std::string dump;
 };
 
@@ -107,17 +112,6 @@ static void synth_nv12(unsigned char *dst, int w, int h, int view)
             uv[(size_t)y * w + 2 * x] = (unsigned char)(64 + (3 * x + 5 * view) % 128);
             uv[(size_t)y * w + 2 * x + 1] = (unsigned char)(64 + (2 * y + 7 * view) % 128);
         }
-}
-
-// calibrateCameras (calibration.cpp:28-68): R = R_y(2 pi i / N), principal point at the centre, focal from the field of view
-static void rig_camera(const Options &o, int i, float K[9], float R[9])
-{
-    const float rot = (float)(2.0 * M_PI * (double)(float)i / o.views);
-    const double c = std::cos((double)rot), s = std::sin((double)rot);
-    const float r[9] = {(float)c, 0, (float)s, 0, 1, 0, (float)-s, 0, (float)c};
-    const double f = (o.w / 2.0) / std::tan(o.hfov * M_PI / 180.0 / 2.0);
-    const float k[9] = {(float)f, 0, (float)(o.w / 2.0), 0, (float)f, (float)(o.h / 2.0), 0, 0, 1};
-    memcpy(K, k, sizeof k); memcpy(R, r, sizeof r);
 }
 
 // a smooth synthetic CPW mesh (the optimiser that produces real ones is out of scope): identity + amp sin(2 pi u + phase) sin(pi v)
@@ -157,6 +151,10 @@ int main(int argc, char **argv)
         else if (k == "--no-upload") o.upload = false;
         else if (k == "--nv12") o.nv12 = true;
         else if (k == "--dump") o.dump = next();
+        else if (k == "--reference-calib") o.reference_calib = true;
+        else if (k == "--work-megapix") o.work_mp = atof(next());
+        else if (k == "--seam-megapix") o.seam_mp = atof(next());
+        else if (k == "--compose-megapix") o.compose_mp = atof(next());
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     int ndev = 0;
@@ -164,17 +162,45 @@ int main(int argc, char **argv)
 
     try {
         // ---- stitch_calib ------------------------------------------------------------------------------------
-        const float warp_scale = (float)(o.out_w / (2.0 * M_PI));
-        msshim::Compositor comp(o.views, o.w, o.h, MS_PROJ_SPHERICAL, warp_scale, o.bands, o.cpw, o.out_w, o.out_h, 1);
-        for (int i = 0; i < o.views; ++i) {
-            float K[9], R[9];
-            rig_camera(o, i, K, R);
-            comp.setCamera(i, K, R);
-            comp.setGain(i, 1.0 + 0.02 * (i - (o.views - 1) / 2.0));
+        std::unique_ptr<msshim::Compositor> comp_owner;
+        msshim::Calibration cal;
+        if (o.reference_calib) {
+            // the reference's own calibration from the first frame of every camera (device 8UC3, full size)
+            std::vector<DevMat> first(o.views);
+            std::vector<unsigned char> host((size_t)o.w * o.h * 3);
+            for (int i = 0; i < o.views; ++i) {
+                first[i].create(o.h, o.w, MS_8UC3, 3);
+                synth_frame(host.data(), o.w, o.h, i);
+                HIPCHECK(hipMemcpy2D(first[i].data, first[i].step, host.data(), (size_t)o.w * 3, (size_t)o.w * 3, o.h, hipMemcpyHostToDevice));
+            }
+            comp_owner = msshim::stitch_calib(first, MS_PROJ_CYLINDRICAL, o.cpw, cal, o.hfov, o.work_mp, o.seam_mp, o.compose_mp, 5.f, -1, -1, 1);
+            for (auto &m : first) HIPCHECK(hipFree(m.data));
+            const ms_pano_geom g = comp_owner->panoGeom();
+            o.out_w = (2 * std::max(std::abs(cal.pano_roi.x), std::abs(cal.pano_roi.x + cal.pano_roi.width)) + 1) & ~1;
+            o.out_h = (2 * std::max(std::abs(cal.pano_roi.y), std::abs(cal.pano_roi.y + cal.pano_roi.height)) + 1) & ~1;
+            o.bands = g.num_bands;
+            fprintf(stderr, "stitch_calib: work %.4f seam %.4f compose %.4f, frames %dx%d%s, warper scale %.3f, pano %dx%d, blend width %.1f -> %d bands, gains",
+                    cal.rig.work_scale, cal.rig.seam_scale, cal.rig.compose_scale, cal.rig.compose_width, cal.rig.compose_height,
+                    cal.rig.resize_input ? " (resized per frame)" : "", cal.rig.compose_warp_scale, cal.pano_roi.width, cal.pano_roi.height, cal.blend_width, g.num_bands);
+            for (double gn : cal.gains) fprintf(stderr, " %.3f", gn);
+            fprintf(stderr, "\n");
+        } else {
+            // BASELINE rig: the reference's rig model at full resolution, spherical warper with the full circle on out_w columns
+            cal.rig = msshim::calibrateCameras(o.views, o.w, o.h, o.hfov, -1.0, 0.01, -1.0);
+            comp_owner.reset(new msshim::Compositor(o.views, o.w, o.h, MS_PROJ_SPHERICAL, (float)(o.out_w / (2.0 * M_PI)), o.bands, o.cpw, o.out_w, o.out_h, 1));
+            for (int i = 0; i < o.views; ++i) {
+                comp_owner->setCamera(i, cal.rig.K_compose[i], cal.rig.R[i]);
+                comp_owner->setGain(i, 1.0 + 0.02 * (i - (o.views - 1) / 2.0));
+            }
+            comp_owner->buildMaps();
+            comp_owner->buildMasks(true);
+            comp_owner->init_gpu();
         }
-        comp.buildMaps();
-        comp.buildMasks(true);
-        comp.init_gpu();
+        msshim::Compositor &comp = *comp_owner;
+        if (o.solve_mesh && o.reference_calib && cal.rig.resize_input) { fprintf(stderr, "stitch_app: --solve-mesh with a resized compose scale is not wired up (use --compose-megapix -1)\n"); return 2; }
+        const float warp_scale = o.reference_calib ? cal.rig.compose_warp_scale : (float)(o.out_w / (2.0 * M_PI));
+        const bool resize_in = o.reference_calib && cal.rig.resize_input;
+        const int cw = o.reference_calib ? cal.rig.compose_width : o.w, ch = o.reference_calib ? cal.rig.compose_height : o.h;
         hipStream_t stitch_stream, recal_stream;
         HIPCHECK(hipStreamCreateWithFlags(&stitch_stream, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&recal_stream, hipStreamNonBlocking));
@@ -208,6 +234,8 @@ int main(int argc, char **argv)
         // ---- stitch_one + results queue + consume -----------------------------------------------------------------
         std::vector<DevMat> full_imgs(o.views);
         for (auto &m : full_imgs) m.create(o.h, o.w, MS_8UC3, 3);
+        std::vector<DevMat> small_imgs(resize_in ? o.views : 0);
+        for (auto &m : small_imgs) m.create(ch, cw, MS_8UC3, 3);
         std::vector<DevMat> nv12_imgs(o.nv12 ? o.views : 0);
         for (auto &m : nv12_imgs) m.create(o.h * 3 / 2, o.w, MS_8UC1, 1);
         const int RING = 4;
@@ -350,7 +378,11 @@ int main(int argc, char **argv)
                                                   hipMemcpyHostToDevice, stitch_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
                 }
             }
-            comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
+            if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)
+                for (int i = 0; i < o.views; ++i) msshim::cuda::resize(full_imgs[i], small_imgs[i], cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);
+                comp.stitch_one(small_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
+            } else
+                comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
             if (o.i420) {
                 ms_image rows{s->pano8u.data + (size_t)ya * s->pano8u.step, s->pano8u.step, o.out_w, yb - ya, MS_8UC3};
                 ms_image dst = msshim::wrap(s->i420);

@@ -55,6 +55,18 @@ class PanoGeom(C.Structure):
     _fields_ = [("num_bands", C.c_int), ("dst_roi_final", Rect), ("dst_roi", Rect), ("canvas_x", C.c_int), ("canvas_y", C.c_int)]
 
 
+class RigParams(C.Structure):
+    _fields_ = [("num_views", C.c_int), ("src_width", C.c_int), ("src_height", C.c_int), ("hfov_deg", C.c_double),
+                ("work_megapix", C.c_double), ("seam_megapix", C.c_double), ("compose_megapix", C.c_double)]
+
+
+class Rig(C.Structure):
+    _fields_ = [("work_scale", C.c_double), ("seam_scale", C.c_double), ("seam_work_aspect", C.c_double), ("compose_scale", C.c_double),
+                ("compose_work_aspect", C.c_double), ("warped_image_scale", C.c_float), ("seam_warp_scale", C.c_float),
+                ("compose_warp_scale", C.c_float), ("resize_input", C.c_int), ("compose_width", C.c_int), ("compose_height", C.c_int),
+                ("K_compose", (C.c_float * 9) * 16), ("K_seam", (C.c_float * 9) * 16), ("R", (C.c_float * 9) * 16)]
+
+
 class MeshMatch(C.Structure):
     _fields_ = [("x1", C.c_float), ("y1", C.c_float), ("x2", C.c_float), ("y2", C.c_float), ("dst", C.c_int)]
 
@@ -74,6 +86,7 @@ EXPORTS = [
     "ms_copy_make_border", "ms_pyr_down", "ms_pyr_up", "ms_subtract_16s", "ms_add_16s", "ms_add_src_weight_32f",
     "ms_normalize_using_weight_32f", "ms_compare_gt_32f", "ms_compare_eq_8u", "ms_set_zero_masked_16sc3",
     "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
+    "ms_calibrate_cameras", "ms_num_bands_rule",
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
@@ -410,6 +423,26 @@ def create_mesh(views, matches, params, temporal=None):
     _chk(load().ms_create_mesh(n, ims, marr, mcnt, tarr, tcnt, C.byref(params), mx.ctypes.data_as(fp), my.ctypes.data_as(fp),
                                C.byref(info), _stream()))
     return mx, my, {k: getattr(info, k) for k, _ in MeshInfo._fields_}
+
+
+def calibrate_cameras(num_views, w, h, hfov_deg=90.0, work_megapix=0.6, seam_megapix=0.01, compose_megapix=1.4):
+    """ms_calibrate_cameras: calibrateCameras + stitch_calib's scale bookkeeping (APP/calibration.cpp:28-68, 101-116, 147-181, 269-288).
+    Returns a dict: the scales, and per view K_compose / K_seam / R as fp32 3x3 arrays."""
+    import numpy as np
+    q = RigParams(num_views, w, h, hfov_deg, work_megapix, seam_megapix, compose_megapix)
+    r = Rig()
+    _chk(load().ms_calibrate_cameras(C.byref(q), C.byref(r)))
+    out = {k: getattr(r, k) for k in ("work_scale", "seam_scale", "seam_work_aspect", "compose_scale", "compose_work_aspect", "warped_image_scale",
+                                      "seam_warp_scale", "compose_warp_scale", "resize_input", "compose_width", "compose_height")}
+    for k in ("K_compose", "K_seam", "R"):
+        out[k] = [np.array(list(getattr(r, k)[i]), np.float32).reshape(3, 3) for i in range(num_views)]
+    return out
+
+
+def num_bands_rule(pano_w, pano_h, blend_strength=5.0):
+    bw, nb = C.c_float(), C.c_int()
+    _chk(load().ms_num_bands_rule(pano_w, pano_h, C.c_float(blend_strength), C.byref(bw), C.byref(nb)))
+    return bw.value, nb.value
 
 
 class Compositor:

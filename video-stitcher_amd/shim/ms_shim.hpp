@@ -8,6 +8,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -116,12 +117,76 @@ public:
     ms_pano_geom panoGeom() const { ms_pano_geom g; check(ms_get_pano_geom(ctx_, &g)); return g; }
     ms_view_geom viewGeom(int i) const { ms_view_geom g; check(ms_get_view_geom(ctx_, i, &g)); return g; }
     ms_ctx *raw() { return ctx_; }
+    // warpImages' seam-scale half (calibration.cpp:92-135, 224-237): resize, seam warps, gains, Voronoi seams, dilate, resize up, AND
+    template <class Mat> void calibrateSeam(const std::vector<Mat> &full_imgs, const float *K_seam, const ms_seam_params &prm, double *gains_out = nullptr, ms_stream s = nullptr)
+    {
+        std::vector<ms_image> v;
+        for (const Mat &m : full_imgs) v.push_back(wrap(m));
+        check(ms_calibrate_seam(ctx_, v.data(), K_seam, &prm, gains_out, s));
+    }
 
 private:
     ms_ctx *ctx_ = nullptr;
     int n_ = 0;
 };
 
+
+// ---- calibrateCameras / stitch_calib (360_stitcher/calibration.cpp:28-68, 252-311) ---------------------------------------------------
+// The rig model and every scale of the calibration, in product code: cameras[i].{focal, ppx, ppy, R} at compose and seam scale plus
+// work / seam / compose scales and warper scales (ms_calibrate_cameras restates calibration.cpp:28-68, 101-116, 147-181, 269-288).
+inline ms_rig calibrateCameras(int num_views, int full_w, int full_h, double hfov_deg = 90.0,
+                               double work_megapix = 0.6, double seam_megapix = 0.01, double compose_megapix = 1.4)      // defs.h:51-53
+{
+    ms_rig_params q{num_views, full_w, full_h, hfov_deg, work_megapix, seam_megapix, compose_megapix};
+    ms_rig rig;
+    check(ms_calibrate_cameras(&q, &rig));
+    return rig;
+}
+
+struct Calibration {
+    ms_rig rig;
+    int num_bands = 0;             // mb->setNumBands(...) of calibration.cpp:193
+    float blend_width = 0.f;
+    ms_rect pano_roi{};            // resultRoi(corners, sizes)
+    std::vector<double> gains;     // GainCompensator::gains()
+};
+
+// stitch_calib (calibration.cpp:252-311) up to the blender being ready for stitch_one: rig + scales (calibrateCameras), compose-scale ROIs and the
+// num_bands rule (:163-194), warp maps + blender->prepare (:196-221), the seam-scale pipeline with exposure gains (:92-135, 224-237),
+// init_gpu for every view (:240).  full_imgs: the first frame of every camera, device 8UC3 at full size.  With compose_scale more than 10 %
+// from 1 the returned compositor expects frames already resized to rig.compose_width x compose_height (msshim::cuda::resize, timed.cpp:75-85).
+// projection: the app ships MS_PROJ_CYLINDRICAL (calibration.cpp:100,156); out_w / out_h: canvas for the 8U output, 0 = none.
+template <class Mat>
+std::unique_ptr<Compositor> stitch_calib(const std::vector<Mat> &full_imgs, int projection, bool enable_local, Calibration &cal,
+                                         double hfov_deg = 90.0, double work_megapix = 0.6, double seam_megapix = 0.01, double compose_megapix = 1.4,
+                                         float blend_strength = 5.f, int out_w = 0, int out_h = 0, int frames_in_flight = 1,
+                                         int num_bands_override = -1, ms_stream s = nullptr)
+{
+    const int n = (int)full_imgs.size();
+    if (n < 1) throw Error(MS_ERR_INVALID, "stitch_calib: no images");
+    cal.rig = calibrateCameras(n, full_imgs[0].cols, full_imgs[0].rows, hfov_deg, work_megapix, seam_megapix, compose_megapix);
+    const ms_rig &rig = cal.rig;
+    std::vector<ms_rect> rois(n);
+    for (int i = 0; i < n; ++i)            // warper->warpRoi(sz, K, R) at compose scale :163-181
+        check(ms_warp_roi(projection, rig.K_compose[i], rig.R[i], rig.compose_warp_scale, rig.compose_width, rig.compose_height, &rois[i]));
+    check(ms_result_roi(n, rois.data(), &cal.pano_roi));
+    check(ms_num_bands_rule(cal.pano_roi.width, cal.pano_roi.height, blend_strength, &cal.blend_width, &cal.num_bands));       // :183-194
+    if (num_bands_override >= 0) cal.num_bands = num_bands_override;
+    if (out_w < 0 || out_h < 0) {          // fit the 8U canvas to the panorama ROI (the compositor places pano x = 0 at canvas column out_w / 2)
+        const ms_rect &r = cal.pano_roi;
+        out_w = (2 * std::max(std::abs(r.x), std::abs(r.x + r.width)) + 1) & ~1;
+        out_h = projection == MS_PROJ_SPHERICAL ? ((r.y + r.height + 1) & ~1) : ((2 * std::max(std::abs(r.y), std::abs(r.y + r.height)) + 1) & ~1);
+    }
+    std::unique_ptr<Compositor> comp(new Compositor(n, rig.compose_width, rig.compose_height, projection, rig.compose_warp_scale, cal.num_bands,
+                                                    enable_local, out_w, out_h, frames_in_flight));
+    for (int i = 0; i < n; ++i) comp->setCamera(i, rig.K_compose[i], rig.R[i]);
+    comp->buildMaps(s);                                                                                          // :196, :221
+    ms_seam_params sp{rig.seam_scale, rig.seam_warp_scale, enable_local ? 1 : 0, 1};
+    cal.gains.assign(n, 1.0);
+    comp->calibrateSeam(full_imgs, &rig.K_seam[0][0], sp, cal.gains.data(), s);                                  // :92-135, :224-237
+    comp->init_gpu(s);                                                                                           // :240
+    return comp;
+}
 
 // ---- matchFeatures' descriptor matching (featurefinder.cpp:50-66): dm->knnMatch(f1.descriptors, f2.descriptors, matches, 2) on the device,
 // then the 0.7 ratio test.  query / train: GpuMat-like 8UC1 descriptor matrices (upload of ImageFeatures::descriptors).

@@ -16,6 +16,10 @@ int shim_compile_check()
         msshim::addSrcWeightGpu32F(a, b, c, d, 1, 1);
         msshim::Compositor comp(6, 1920, 1080, MS_PROJ_CYLINDRICAL, 611.f, 5, false, 3840, 1920);
         std::vector<FakeGpuMat> frames(6);
+        const ms_rig rig = msshim::calibrateCameras(6, 1920, 1080);          // calibrateCameras + the scales of stitch_calib
+        msshim::Calibration cal;
+        std::unique_ptr<msshim::Compositor> calibrated = msshim::stitch_calib(frames, MS_PROJ_CYLINDRICAL, true, cal);      // stitch_calib
+        (void)rig; (void)calibrated;
         comp.stitch_one(frames, &a, (FakeGpuMat *)nullptr);
         for (int i = 0; i < 6; ++i) comp.feed_online(frames[i], i);
         comp.blend(&a, (FakeGpuMat *)nullptr);
