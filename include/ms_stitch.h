@@ -388,6 +388,30 @@ MS_API int ms_create_mesh(int n_views, const ms_image *warped_views, const ms_me
  * findHomography stay with the caller (msshim::knnRatioMatches does the former).  Synchronises `stream`. */
 MS_API int ms_knn_match_hamming2(const ms_image *query, const ms_image *train, int *train_idx_host, int *distance_host, ms_stream stream);
 
+/* ---- feature front-end of the recalibration path ----------------------------------------------------------------------------
+ * cuda::ORB::create(nfeatures, scaleFactor, nlevels)->detectAndCompute(gray, mask, keypoints, descriptors) of featurefinder::findFeatures
+ * (360_stitcher/featurefinder.cpp:13-46 -> cudafeatures2d/src/orb.cpp:430-865, cuda/fast.cu, cuda/orb.cu): image / mask pyramids, FAST 9-16 with
+ * score and 3 x 3 non-max suppression, per-level budgets, Harris responses, intensity-centroid angles, rBRIEF descriptors (WTA_K = 2, HARRIS_SCORE,
+ * no blur: the creator's defaults).  gray: DEVICE 8UC1 (ms_bgr_to_gray); mask: DEVICE 8UC1 of the same size or NULL.
+ * keypoints_host: max_keypoints x 6 floats (x, y, response, angle in degrees, octave, size), the rows of cuda::ORB's keypoint matrix;
+ * descriptors: DEVICE 8UC1 max_keypoints x 32 (row i belongs to keypoint i).  Keypoint order: levels in turn, inside a level by descending Harris
+ * response where the level was culled, raster order otherwise (the reference's order is left to atomics and an unstable sort).  Synchronises. */
+typedef struct ms_orb_params {
+    int nfeatures; float scale_factor; int nlevels;      /* ORB::create(2500, 1.2f, 8)  featurefinder.cpp:15 */
+    int edge_threshold, first_level, patch_size, fast_threshold;     /* 31, 0, 31, 20 (cuda::ORB::create defaults) */
+} ms_orb_params;
+MS_API int ms_orb_default_params(ms_orb_params *prm);
+MS_API int ms_orb_detect_and_compute(const ms_image *gray, const ms_image *mask, const ms_orb_params *prm, float *keypoints_host, int max_keypoints,
+                                     ms_image *descriptors, int *n_keypoints, ms_stream stream);
+/* cv::findHomography(src, dst, mask, RANSAC) of featurefinder::matchFeatures (featurefinder.cpp:68-90 -> calib3d/src/fundam.cpp:319-402,
+ * ptsetreg.cpp:53-290, levmarq.cpp:76-214): src_xy / dst_xy HOST, n points (x, y) each.  reproj_threshold <= 0 -> 3, max_iters <= 0 -> 2000,
+ * confidence outside (0, 1) -> 0.995 (the reference's defaults).  Same cv::RNG subset sequence, subset checks, acceptance rule and adaptive
+ * iteration count as the reference; all candidate 4-point models are fitted and scored on the device in one launch, the final N-point fit and the
+ * 10-iteration Levenberg-Marquardt polish of the winner run on the host.  H: 9 doubles row-major (H[8] = 1); inlier_mask: n bytes (may be NULL).
+ * Returns MS_OK, 1 if no model was found (H zeroed; the reference returns an empty Mat), or a negative status. */
+MS_API int ms_find_homography_ransac(const float *src_xy, const float *dst_xy, int n, double reproj_threshold, int max_iters, double confidence,
+                                     double *H, uint8_t *inlier_mask, int *n_inliers, ms_stream stream);
+
 /* device-resident static tables, for parity tests: x_maps[i]/y_maps[i] (32FC1), masks (8UC1),
  * weight pyramid level (32FC1). Borrowed pointers owned by ctx. */
 MS_API int ms_get_maps(const ms_ctx *ctx, int view, ms_image *xmap, ms_image *ymap);

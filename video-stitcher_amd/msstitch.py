@@ -86,7 +86,7 @@ EXPORTS = [
     "ms_copy_make_border", "ms_pyr_down", "ms_pyr_up", "ms_subtract_16s", "ms_add_16s", "ms_add_src_weight_32f",
     "ms_normalize_using_weight_32f", "ms_compare_gt_32f", "ms_compare_eq_8u", "ms_set_zero_masked_16sc3",
     "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
-    "ms_calibrate_cameras", "ms_num_bands_rule",
+    "ms_calibrate_cameras", "ms_num_bands_rule", "ms_orb_default_params", "ms_orb_detect_and_compute", "ms_find_homography_ransac",
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
@@ -363,6 +363,45 @@ def result_roi(rois):
     r = Rect()
     _chk(load().ms_result_roi(len(rois), arr, C.byref(r)))
     return r.tuple()
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int), ("edge_threshold", C.c_int), ("first_level", C.c_int),
+                ("patch_size", C.c_int), ("fast_threshold", C.c_int)]
+
+
+def orb_detect_and_compute(gray, mask=None, nfeatures=2500, scale_factor=1.2, nlevels=8, fast_threshold=20):
+    """cuda::ORB::create(nfeatures, scaleFactor, nlevels)->detectAndCompute (featurefinder.cpp:15-40): gray / mask torch uint8 (H, W) on the device.
+    Returns (keypoints (n, 6) float32 numpy: x, y, response, angle, octave, size; descriptors (n, 32) uint8 torch tensor on the device)."""
+    import numpy as np
+    import torch
+    prm = OrbParams()
+    _chk(load().ms_orb_default_params(C.byref(prm)))
+    prm.nfeatures, prm.scale_factor, prm.nlevels, prm.fast_threshold = nfeatures, scale_factor, nlevels, fast_threshold
+    cap = nfeatures
+    kp = np.zeros((cap, 6), np.float32)
+    desc = torch.zeros((cap, 32), dtype=torch.uint8, device=gray.device)
+    n = C.c_int(0)
+    di = img(desc)
+    _chk(load().ms_orb_detect_and_compute(C.byref(img(gray)), None if mask is None else C.byref(img(mask)), C.byref(prm),
+                                          kp.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(di), C.byref(n), _stream()))
+    return kp[:n.value].copy(), desc[:n.value]
+
+
+def find_homography_ransac(src, dst, reproj_threshold=3.0, max_iters=2000, confidence=0.995):
+    """cv::findHomography(src, dst, mask, RANSAC): src / dst (n, 2) float32.  Returns (H 3x3 float64 or None, inlier mask uint8 (n,))."""
+    import numpy as np
+    src = np.ascontiguousarray(src, np.float32); dst = np.ascontiguousarray(dst, np.float32)
+    n = len(src)
+    H = np.zeros(9, np.float64)
+    m = np.zeros(max(n, 1), np.uint8)
+    cnt = C.c_int(0)
+    rc = load().ms_find_homography_ransac(src.ctypes.data_as(C.POINTER(C.c_float)), dst.ctypes.data_as(C.POINTER(C.c_float)), n, C.c_double(reproj_threshold),
+                                          max_iters, C.c_double(confidence), H.ctypes.data_as(C.POINTER(C.c_double)), m.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                          C.byref(cnt), _stream())
+    if rc < 0:
+        _chk(rc)
+    return (None if rc == 1 else H.reshape(3, 3)), m[:n]
 
 
 # ------------------------------------------------------------------ compositor context
