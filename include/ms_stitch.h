@@ -403,6 +403,10 @@ typedef struct ms_orb_params {
 MS_API int ms_orb_default_params(ms_orb_params *prm);
 MS_API int ms_orb_detect_and_compute(const ms_image *gray, const ms_image *mask, const ms_orb_params *prm, float *keypoints_host, int max_keypoints,
                                      ms_image *descriptors, int *n_keypoints, ms_stream stream);
+/* The feature mask createMesh builds for findFeatures (360_stitcher/meshwarper.cpp:82-115): 255 inside the two column bands where neighbouring
+ * views overlap (rect_a / rect_b: x0, width -- cv::rectangle clips them to the image) AND where the warped view is not black (inRange(0, 0) negated:
+ * the pixels the projection did not fill).  warped_view: DEVICE 8UC3; mask: DEVICE 8UC1 of the same size. */
+MS_API int ms_feature_mask(const ms_image *warped_view, int a_x0, int a_width, int b_x0, int b_width, ms_image *mask, ms_stream stream);
 /* cv::findHomography(src, dst, mask, RANSAC) of featurefinder::matchFeatures (featurefinder.cpp:68-90 -> calib3d/src/fundam.cpp:319-402,
  * ptsetreg.cpp:53-290, levmarq.cpp:76-214): src_xy / dst_xy HOST, n points (x, y) each.  reproj_threshold <= 0 -> 3, max_iters <= 0 -> 2000,
  * confidence outside (0, 1) -> 0.995 (the reference's defaults).  Same cv::RNG subset sequence, subset checks, acceptance rule and adaptive

@@ -102,3 +102,21 @@ def test_find_homography_degenerate_inputs(ms, cuda):
     line = np.c_[np.arange(20, dtype=np.float32), np.arange(20, dtype=np.float32) * 2]          # collinear: no valid subset
     H, m = ms.find_homography_ransac(line, line)
     assert H is None and m.sum() == 0
+
+
+def test_front_end_recovers_the_offset_between_two_views_of_one_scene(ms, cuda):
+    """findFeatures + matchFeatures in miniature: two overlapping crops of one texture -> ORB on both, Hamming 2-NN + 0.7 ratio test on the device,
+    RANSAC homography on the centred points (featurefinder.cpp:68-90).  The homography must be the translation between the crops."""
+    scene = textured(1100, 420, 11)
+    off = 310
+    a, b = scene[:, :760].copy(), scene[:, off:off + 760].copy()
+    ka, da = ms.orb_detect_and_compute(torch.from_numpy(a).to(cuda), nfeatures=1500)
+    kb, db = ms.orb_detect_and_compute(torch.from_numpy(b).to(cuda), nfeatures=1500)
+    idx, dist = ms.knn_match_hamming2(da, db)
+    keep = (idx[:, 1] >= 0) & (dist[:, 0].astype(np.float32) < 0.7 * dist[:, 1].astype(np.float32))
+    q = np.nonzero(keep)[0]
+    assert len(q) > 80
+    src = ka[q, :2] - np.float32([760 * 0.5, 420 * 0.5]); dst = kb[idx[q, 0], :2] - np.float32([760 * 0.5, 420 * 0.5])
+    H, mask = ms.find_homography_ransac(src, dst)
+    assert H is not None and mask.sum() > 0.8 * len(q)
+    assert np.allclose(H, [[1, 0, -off], [0, 1, 0], [0, 0, 1]], atol=0.05), H

@@ -66,8 +66,10 @@ def test_host_app_cpw_with_concurrent_recalibration(ms, cuda, tmp_path):
 
 
 def test_host_app_solves_meshes_while_stitching(ms, cuda, tmp_path):
-    """--solve-mesh: the recalibration thread uploads the current frames, remaps them, runs msshim::MeshWarper::calibrateMeshWarp
-    (ms_create_mesh: triangle statistics + least-squares CG on its own stream) and swaps the meshes in, while the stitcher thread runs."""
+    """--solve-mesh: the recalibration thread uploads the current frames, remaps them, runs the device feature front-end (overlap masks, ORB, Hamming 2-NN +
+    ratio test, RANSAC homographies: msshim::featurefinder) and msshim::MeshWarper::calibrateMeshWarp (ms_create_mesh: triangle statistics + least-squares CG
+    on its own stream), and swaps the meshes in -- while the stitcher thread runs.  Small rig: the views are too small for ORB's 31-px border, so the solve
+    sees no matches (global + smoothness terms only); it must still do real work every round."""
     cfg = synth.CONFIGS["mini6"]
     for attempt in range(4):       # the scenario that exposed the stream-ordered allocator losing a solve's upload about once in 30 solves
         info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
@@ -75,9 +77,23 @@ def test_host_app_solves_meshes_while_stitching(ms, cuda, tmp_path):
         assert info["frames"] == 6000 and info["cpw"] is True
         # every solve must do real work: a lost upload shows as a solve that "converges" in 0 iterations (and a black panorama)
         assert info["recalibrations"] >= 1 and info["mesh_solver_iterations"] > info["recalibrations"] * 300, info
-        assert 1.0 < info["max_mesh_displacement_px"] < 20.0
+        assert info["max_mesh_displacement_px"] < 20.0
         got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
         assert (got.max(axis=2) > 0).mean() > 0.25
+
+
+def test_host_app_recalibrates_from_real_features_at_full_size(ms, cuda, tmp_path):
+    """SURVEY 8 f4 end to end, no external feature code: config-2 cameras looking at one synthetic scene (a texture fixed on the viewing sphere, odd and
+    even cameras seeing it +-3 panorama pixels apart); every recalibration round finds ORB keypoints in the six warped 1080p views, matches neighbours,
+    fits RANSAC homographies and lets the mesh optimiser absorb the disparity."""
+    cfg = synth.CONFIGS["cfg2"]
+    info, dump = run_app(tmp_path, "--frames", 1500, "--solve-mesh")
+    r = info["recalibrations"]
+    assert r >= 1 and info["orb_keypoints"] >= r * 6 * 1000, info                 # thousands of corners per view
+    assert info["ratio_matches"] >= r * 500 and info["ransac_inliers"] >= r * 200 and info["ransac_inliers"] <= info["ratio_matches"], info
+    assert info["mesh_solver_iterations"] > r * 300 and 2.0 < info["max_mesh_displacement_px"] < 32.0, info
+    got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
+    assert (got.max(axis=2) > 0).mean() > 0.25
 
 
 def test_host_app_reference_calibration_matches_the_same_steps_through_the_binding(ms, cuda, tmp_path):

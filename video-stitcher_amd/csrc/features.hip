@@ -137,6 +137,17 @@ __global__ void __launch_bounds__(64) k_row_write(const uint8_t *__restrict__ sc
     }
 }
 
+// createMesh's feature mask (meshwarper.cpp:82-115): overlap bands AND not-black
+__global__ void __launch_bounds__(256) k_feature_mask(const uint8_t *__restrict__ img, size_t step, int rows, int cols, int ax0, int ax1, int bx0, int bx1,
+                                                      uint8_t *__restrict__ mask, size_t mstep)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const uint8_t *p = img + (size_t)y * step + 3 * (size_t)x;
+    const bool band = (x >= ax0 && x < ax1) || (x >= bx0 && x < bx1);
+    mask[(size_t)y * mstep + x] = (band && (p[0] | p[1] | p[2])) ? 255 : 0;
+}
+
 // HarrisResponses (orb.cu:93-138): 7 x 7 block, integer gradient sums, float formula evaluated operation by operation
 __global__ void __launch_bounds__(64) k_harris(const uint8_t *__restrict__ img, size_t step, const short2 *__restrict__ loc, float *__restrict__ resp, int n, int block, float k)
 {
@@ -582,6 +593,17 @@ int ms_orb_detect_and_compute(const ms_image *gray, const ms_image *mask, const 
     }
     MS_HIP(hipStreamSynchronize(st));
     *n_out = total;
+    return MS_OK;
+}
+
+int ms_feature_mask(const ms_image *img, int a_x0, int a_w, int b_x0, int b_w, ms_image *mask, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(img && mask && img->data && mask->data && img->type == MS_8UC3 && mask->type == MS_8UC1 && img->rows == mask->rows && img->cols == mask->cols,
+             "ms_feature_mask: need an 8UC3 image and an 8UC1 mask of the same size");
+    k_feature_mask<<<dim3(div_up(img->cols, 64), div_up(img->rows, 4)), dim3(64, 4), 0, as_stream(stream)>>>(
+        (const uint8_t *)img->data, img->step, img->rows, img->cols, a_x0, a_x0 + a_w, b_x0, b_x0 + b_w, (uint8_t *)mask->data, mask->step);
+    MS_LAUNCH_CHECK();
     return MS_OK;
 }
 

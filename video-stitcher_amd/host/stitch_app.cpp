@@ -58,6 +58,7 @@ struct DevMat {
     size_t step = 0;
     unsigned char *data = nullptr;
     int type() const { return flags; }
+    void create(int r, int c, int t) { create(r, c, t, t == MS_8UC3 ? 3 : (t == MS_32FC1 ? 4 : (t == MS_16SC3 ? 6 : (t == MS_16SC1 ? 2 : 1)))); }    // GpuMat::create(rows, cols, type)
     void create(int r, int c, int t, int elem, bool contiguous = false)
     {
         if (data && r == rows && c == cols && t == flags) return;       // GpuMat::create is a no-op when nothing changes
@@ -91,6 +92,34 @@ static void synth_frame(unsigned char *dst, int w, int h, int view)
                 double v = 128.0 + 60.0 * std::sin(two_pi * (phase + c / 3.0)) + chk;
                 v = std::nearbyint(v);
                 dst[((size_t)y * w + x) * 3 + c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+}
+
+// A scene-consistent synthetic camera frame for --solve-mesh: a texture fixed on the viewing sphere (blocks of random grey levels: corners for FAST,
+// structure for the descriptors) seen through the pinhole camera `view` of the rig, so that neighbouring warped views show the SAME content where they
+// overlap and the device front-end finds real correspondences.  `shift_px` moves this camera's view of the scene by that many panorama pixels
+// (a stand-in for parallax): it is what the mesh optimiser then has to absorb.
+static void synth_scene_frame(unsigned char *dst, int w, int h, int view, int n_views, double hfov_deg, double pano_scale, double shift_px)
+{
+    const float rot = (float)(2.0 * M_PI * (double)(float)view / n_views);
+    const double c = std::cos((double)rot), s = std::sin((double)rot);
+    const double f = (w / 2.0) / std::tan(hfov_deg * M_PI / 180.0 / 2.0);
+    const double cell = 32.0 / pano_scale;                          // blocks of 32 panorama pixels
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const double dx = (x - w / 2.0) / f, dy = (y - h / 2.0) / f, dz = 1.0;
+            const double X = c * dx + s * dz, Y = dy, Z = -s * dx + c * dz;           // world = R_y(rot) * camera
+            const double u = std::atan2(X, Z) + shift_px / pano_scale, v = M_PI - std::acos(Y / std::sqrt(X * X + Y * Y + Z * Z));
+            const long long cu = (long long)std::floor(u / cell), cv = (long long)std::floor(v / cell);
+            const double fu = u / cell - cu, fv = v / cell - cv;
+            for (int ch = 0; ch < 3; ++ch) {
+                unsigned hsh = (unsigned)(cu * 73856093ll) ^ (unsigned)(cv * 19349663ll) ^ (unsigned)(ch * 83492791);
+                hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+                double val = 40.0 + (double)((hsh >> 8) & 0xff) * 175.0 / 255.0;
+                val += 18.0 * std::sin(2.0 * M_PI * (fu + 0.3 * ch)) * std::sin(2.0 * M_PI * fv);      // some texture inside a block
+                val = std::nearbyint(val);
+                dst[((size_t)y * w + x) * 3 + ch] = (unsigned char)(val < 1 ? 1 : (val > 255 ? 255 : val));    // never 0: black marks "outside the view" in createMesh's masks
             }
         }
 }
@@ -220,6 +249,7 @@ int main(int argc, char **argv)
             f.w = o.w; f.h = o.h;
             HIPCHECK(hipHostMalloc((void **)&f.p, (size_t)o.w * o.h * 3, hipHostMallocDefault));
             if (o.nv12) synth_nv12(f.p, o.w, o.h, i);          // (h * 3/2 rows of w bytes)
+            else if (o.solve_mesh) synth_scene_frame(f.p, o.w, o.h, i, o.views, o.hfov, warp_scale, (i % 2 ? 1.0 : -1.0) * std::max(1.5, warp_scale / 200.0));   // odd / even cameras see the scene +-3 px apart
             else synth_frame(f.p, o.w, o.h, i);
             f.seq = 0;
         }
@@ -270,6 +300,7 @@ int main(int argc, char **argv)
         std::thread recalibrater;
         std::atomic<int> recalibrations{0};
         std::atomic<int> solver_iterations{0};
+        std::atomic<long long> total_keypoints{0}, total_matches{0}, total_inliers{0};
         std::atomic<float> max_disp{0.f};
         std::string recal_failure;
         if (o.solve_mesh)
@@ -278,10 +309,7 @@ int main(int argc, char **argv)
             // runs.  The feature front-end is not part of this build: the matches are synthetic (a parallax that drifts from round to round).
             recalibrater = std::thread([&] {
                 try {
-                    struct Pt { float x, y; }; struct KeyPoint { Pt pt; }; struct Size { int width, height; };
-                    struct Features { Size img_size; std::vector<KeyPoint> keypoints; };
-                    struct DMatch { int queryIdx, trainIdx; };
-                    struct Matches { int src_img_idx, dst_img_idx; std::vector<DMatch> matches; std::vector<unsigned char> inliers_mask; int num_inliers; };
+                    namespace ff = msshim::featurefinder;
                     msshim::MeshWarper mw(o.views, 10, 10, warp_scale, 1.0, 1.0);
                     mw.params().theta_rule = 1;
                     mw.params().global_dist = std::max(4, std::min(30, o.out_w / 128));    // GLOBAL_DIST = 30 is tuned to 1080p views; scaled for small rigs
@@ -303,33 +331,23 @@ int main(int argc, char **argv)
                                                               hipMemcpyHostToDevice, recal_stream));
                             HIPCHECK(hipStreamSynchronize(recal_stream));
                         }
-                        std::vector<Features> feats(o.views);
-                        std::vector<Matches> pairwise;
                         for (int i = 0; i < o.views; ++i) {
                             ms_image xm, ym;
                             msshim::check(ms_get_maps(comp.raw(), i, &xm, &ym));
                             ms_image src = msshim::wrap(recal_full[i]), dst = msshim::wrap(images[i]);
                             msshim::check(ms_remap(&src, &xm, &ym, &dst, MS_INTER_LINEAR_FIXPT, MS_BORDER_CONSTANT, (ms_stream)recal_stream));   // cv::remap, meshwarper.cpp:72
-                            feats[i].img_size = {g[i].roi.width, g[i].roi.height};
                         }
-                        for (int src = 0; src < o.views; ++src) {             // the kept pairs are (src, src - 1) and the wrap-around seam (0, n - 1)
-                            const int dst = src == 0 ? o.views - 1 : src - 1;
-                            if (g[src].roi.width > o.out_w / 2 || g[dst].roi.width > o.out_w / 2) continue;      // the view straddling +-pi
-                            const int off = ((g[src].roi.x - g[dst].roi.x) % o.out_w + o.out_w) % o.out_w;        // x1 - x2 of a true correspondence = -off
-                            Matches m{src, dst, {}, {}, 0};
-                            for (int k = 0; k < 60; ++k) {
-                                const float x1 = 4.f + (float)((k * 37) % std::max(1, g[dst].roi.width - off - 8));
-                                const float y1 = 8.f + (float)((k * 53) % std::max(1, g[src].roi.height - 16));
-                                const float x2 = x1 + off + 3.f * std::sin(0.7f * round + 0.01f * y1), y2 = y1 + 1.5f * std::cos(0.4f * round);
-                                if (x2 < 0 || x2 >= g[dst].roi.width) continue;
-                                feats[src].keypoints.push_back({{x1, y1}});
-                                feats[dst].keypoints.push_back({{x2, y2}});
-                                m.matches.push_back({(int)feats[src].keypoints.size() - 1, (int)feats[dst].keypoints.size() - 1});
-                                m.inliers_mask.push_back(1);
-                                ++m.num_inliers;
-                            }
-                            pairwise.push_back(m);
-                        }
+                        // createMesh's front-end (meshwarper.cpp:82-119), all on the device: overlap masks, ORB, Hamming 2-NN + ratio test, RANSAC homographies
+                        std::vector<DevMat> fmasks;
+                        ff::featureMasks(images, fmasks, std::min(400, std::max(16, o.out_w / 10)), (ms_stream)recal_stream);
+                        std::vector<ff::ImageFeatures<DevMat>> feats;
+                        ff::findFeatures(images, fmasks, feats, (ms_stream)recal_stream);
+                        std::vector<ff::MatchesInfo> pairwise(o.views);                      // NUM_IMAGES - 1 + wrapAround (calibration.cpp:284)
+                        ff::matchFeatures(feats, pairwise, (ms_stream)recal_stream);
+                        for (auto &m : fmasks) if (m.data) HIPCHECK(hipFree(m.data));
+                        for (auto &f : feats) if (f.descriptors.data) HIPCHECK(hipFree(f.descriptors.data));
+                        { size_t nk = 0, nm = 0, ni = 0; for (auto &f : feats) nk += f.keypoints.size(); for (auto &pm : pairwise) { nm += pm.matches.size(); ni += pm.num_inliers; }
+                          total_keypoints += (long long)nk; total_matches += (long long)nm; total_inliers += (long long)ni; }
                         const ms_mesh_info info = mw.calibrateMeshWarp(comp, images, feats, pairwise, (ms_stream)recal_stream);
                         solver_iterations += info.iterations;
                         if (getenv("STITCH_APP_TRACE")) {
@@ -410,9 +428,11 @@ int main(int argc, char **argv)
             fclose(f);
         }
         printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"upload\": %s, "
-               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"max_mesh_displacement_px\": %.2f, \"checksum\": \"%016llx\"}\n",
+               "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"max_mesh_displacement_px\": %.2f, "
+               "\"orb_keypoints\": %lld, \"ratio_matches\": %lld, \"ransac_inliers\": %lld, \"checksum\": \"%016llx\"}\n",
                o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.upload ? "true" : "false",
-               consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), (double)max_disp.load(), checksum);
+               consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), (double)max_disp.load(),
+               total_keypoints.load(), total_matches.load(), total_inliers.load(), checksum);
     } catch (const msshim::Error &e) {
         fprintf(stderr, "stitch_app: msstitch error %d: %s\n", e.code, e.what());
         return 1;

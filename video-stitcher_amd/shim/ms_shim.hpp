@@ -200,9 +200,123 @@ template <class Mat, class Emit> void knnRatioMatches(const Mat &query, const Ma
         if (idx[2 * i + 1] >= 0 && (float)dist[2 * i] < 0.7 * (float)dist[2 * i + 1]) emit(i, idx[2 * i], (float)dist[2 * i]);
 }
 
+// ---- featurefinder (360_stitcher/featurefinder.cpp, featurefinder.h:7-13) over the device front-end ----------------------------------------
+// Mat = a GpuMat-like device image type with create(rows, cols, type) (cv::cuda::GpuMat qualifies).  ImageFeatures / MatchesInfo have the fields
+// of cv::detail::ImageFeatures / MatchesInfo that the application reads; descriptors stay on the device (the reference downloads them and matches
+// on the CPU; here matching runs on the device too).
+namespace featurefinder {
+struct Point2f { float x, y; };
+struct KeyPoint { Point2f pt; float size, angle, response; int octave; };
+struct Size { int width, height; };
+struct DMatch { int queryIdx, trainIdx; float distance; };
+template <class Mat> struct ImageFeatures { int img_idx = 0; Size img_size{0, 0}; std::vector<KeyPoint> keypoints; Mat descriptors; };
+struct MatchesInfo {
+    int src_img_idx = -1, dst_img_idx = -1;
+    std::vector<DMatch> matches;
+    std::vector<unsigned char> inliers_mask;
+    int num_inliers = 0;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // empty Mat in the reference when no model was found: have_H = false
+    bool have_H = false;
+    double confidence = 0;
+};
+
+// createMesh's feature masks (meshwarper.cpp:82-115): overlap bands of 400 px on both sides (the hard-coded split of view 3 when the rig has 6 views), minus black pixels
+template <class Mat> void featureMasks(const std::vector<Mat> &images, std::vector<Mat> &masks, int overlap = 400, ms_stream s = nullptr)
+{
+    masks.resize(images.size());
+    for (size_t idx = 0; idx < images.size(); ++idx) {
+        const int cols = images[idx].cols, rows = images[idx].rows;
+        masks[idx].create(rows, cols, MS_8UC1);
+        int ax0 = 0, bx0 = cols - overlap;
+        if (idx == 3 && images.size() == 6) {        // "Opencv splits the third video (idx == 3) in the middle"
+            const float split_l = images[0].cols * 0.25f * 2.0f, split_r = -images[0].cols * 0.25f * 2.0f;
+            ax0 = (int)split_l - overlap; bx0 = cols + (int)split_r;
+        }
+        ms_image im = wrap(images[idx]), mk = wrap(masks[idx]);
+        check(ms_feature_mask(&im, ax0, overlap, bx0, overlap, &mk, s));
+    }
+}
+
+// findFeatures (featurefinder.cpp:13-46) with work_scale < 0 (what createMesh passes): BGR2GRAY, cuda::ORB::create(2500, 1.2f, 8)->detectAndCompute
+template <class Mat> void findFeatures(const std::vector<Mat> &images, const std::vector<Mat> &masks, std::vector<ImageFeatures<Mat>> &features, ms_stream s = nullptr,
+                                       int nfeatures = 2500, float scale_factor = 1.2f, int nlevels = 8)
+{
+    features.resize(images.size());
+    ms_orb_params prm;
+    check(ms_orb_default_params(&prm));
+    prm.nfeatures = nfeatures; prm.scale_factor = scale_factor; prm.nlevels = nlevels;
+    Mat gray;
+    std::vector<float> kp((size_t)6 * nfeatures);
+    for (size_t i = 0; i < images.size(); ++i) {
+        gray.create(images[i].rows, images[i].cols, MS_8UC1);
+        ms_image im = wrap(images[i]), g = wrap(gray);
+        check(ms_bgr_to_gray(&im, &g, s));                                             // cuda::cvtColor(gpu_img, gpu_img, CV_BGR2GRAY)
+        features[i].descriptors.create(nfeatures, 32, MS_8UC1);
+        ms_image d = wrap(features[i].descriptors), mk{};
+        const bool have_mask = i < masks.size() && masks[i].data;
+        if (have_mask) mk = wrap(masks[i]);
+        int n = 0;
+        check(ms_orb_detect_and_compute(&g, have_mask ? &mk : nullptr, &prm, kp.data(), nfeatures, &d, &n, s));
+        features[i].img_idx = (int)i;
+        features[i].img_size = Size{images[i].cols, images[i].rows};
+        features[i].keypoints.resize(n);
+        for (int k = 0; k < n; ++k) {
+            const float *r = &kp[6 * (size_t)k];
+            features[i].keypoints[k] = KeyPoint{{r[0], r[1]}, r[5], r[3], r[2], (int)r[4]};
+        }
+    }
+}
+
+// the body shared by matchFeatures (featurefinder.cpp:48-108) and matchFeaturesTemporal (:110-170): knnMatch(k = 2) + 0.7 ratio, centred points,
+// findHomography(RANSAC), inlier count; confidence ends as 1 in both
+template <class Mat> void matchPair(const ImageFeatures<Mat> &f1, const ImageFeatures<Mat> &f2, MatchesInfo &pm, ms_stream s = nullptr)
+{
+    pm.matches.clear(); pm.inliers_mask.clear(); pm.num_inliers = 0; pm.have_H = false;
+    const int n1 = (int)f1.keypoints.size(), n2 = (int)f2.keypoints.size();
+    if (n1 > 0 && n2 > 0) {
+        ms_image q = wrap(f1.descriptors), t = wrap(f2.descriptors);
+        q.rows = n1; t.rows = n2;
+        std::vector<int> idx((size_t)2 * n1), dist((size_t)2 * n1);
+        check(ms_knn_match_hamming2(&q, &t, idx.data(), dist.data(), s));
+        for (int j = 0; j < n1; ++j)
+            if (idx[2 * j + 1] >= 0 && (float)dist[2 * j] < 0.7 * (float)dist[2 * j + 1]) pm.matches.push_back(DMatch{j, idx[2 * j], (float)dist[2 * j]});
+    }
+    if (!pm.matches.empty()) {
+        std::vector<float> src(2 * pm.matches.size()), dst(2 * pm.matches.size());
+        for (size_t j = 0; j < pm.matches.size(); ++j) {
+            const DMatch &m = pm.matches[j];
+            src[2 * j] = f1.keypoints[m.queryIdx].pt.x - f1.img_size.width * 0.5f; src[2 * j + 1] = f1.keypoints[m.queryIdx].pt.y - f1.img_size.height * 0.5f;
+            dst[2 * j] = f2.keypoints[m.trainIdx].pt.x - f2.img_size.width * 0.5f; dst[2 * j + 1] = f2.keypoints[m.trainIdx].pt.y - f2.img_size.height * 0.5f;
+        }
+        pm.inliers_mask.assign(pm.matches.size(), 0);
+        const int rc = ms_find_homography_ransac(src.data(), dst.data(), (int)pm.matches.size(), 0, 0, 0, pm.H, pm.inliers_mask.data(), &pm.num_inliers, s);
+        check(rc);
+        pm.have_H = rc == 0;
+    }
+    pm.confidence = 1;
+}
+template <class Mat> void matchFeatures(const std::vector<ImageFeatures<Mat>> &features, std::vector<MatchesInfo> &pairwise_matches, ms_stream s = nullptr)
+{
+    const int n = (int)features.size();
+    for (size_t i = 0; i < pairwise_matches.size(); ++i) {
+        const int idx1 = (int)i, idx2 = i == 0 ? n - 1 : (int)i - 1;
+        pairwise_matches[i].src_img_idx = idx1; pairwise_matches[i].dst_img_idx = idx2;
+        matchPair(features[idx1], features[idx2], pairwise_matches[i], s);
+    }
+}
+template <class Mat> void matchFeaturesTemporal(const std::vector<ImageFeatures<Mat>> &features, const std::vector<ImageFeatures<Mat>> &prev_features,
+                                                std::vector<MatchesInfo> &pairwise_matches, ms_stream s = nullptr)
+{
+    for (size_t i = 0; i < pairwise_matches.size(); ++i) {
+        pairwise_matches[i].src_img_idx = pairwise_matches[i].dst_img_idx = (int)i;
+        matchPair(features[i], prev_features[i], pairwise_matches[i], s);
+    }
+}
+}  // namespace featurefinder
+
 // ---- MeshWarper: createMesh's host logic around ms_create_mesh (360_stitcher/meshwarper.cpp:158-335) --------------------------
 // Works on anything shaped like cv::detail::ImageFeatures (.img_size, .keypoints[i].pt) and cv::detail::MatchesInfo (.src_img_idx,
-// .dst_img_idx, .matches[i].queryIdx/.trainIdx, .inliers_mask, .num_inliers): the feature front-end (featurefinder.cpp) stays the caller's.
+// .dst_img_idx, .matches[i].queryIdx/.trainIdx, .inliers_mask, .num_inliers): msshim::featurefinder's types above, or the caller's own.
 // Differences from the reference, all stated: NUM_IMAGES is the run-time view count (the literal 5 of filterMatches is num_images - 1);
 // prev_avg starts at 0 (an uninitialised member in the reference); old matches are kept as resolved positions instead of indices into a
 // copy of the old ImageFeatures.

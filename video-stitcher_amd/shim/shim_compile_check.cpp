@@ -5,6 +5,7 @@ struct FakeGpuMat {                       // field names/types of cv::cuda::GpuM
     size_t step = 0;
     unsigned char *data = nullptr;
     int type() const { return flags; }
+    void create(int r, int c, int t) { rows = r; cols = c; flags = t; }      // GpuMat::create(rows, cols, type)
 };
 int shim_compile_check()
 {
@@ -33,7 +34,16 @@ int shim_compile_check()
         std::vector<Features> feats(6);
         std::vector<Matches> pairwise(6);
         msshim::knnRatioMatches(a, b, [&](int q, int t, float d) { pairwise[0].matches.push_back({q, t}); (void)d; });
+        // featurefinder::findFeatures / matchFeatures (featurefinder.h:7-13) on the device front-end, feeding the mesh warper
+        std::vector<FakeGpuMat> fmasks;
+        msshim::featurefinder::featureMasks(frames, fmasks);
+        std::vector<msshim::featurefinder::ImageFeatures<FakeGpuMat>> ffeats, fprev;
+        msshim::featurefinder::findFeatures(frames, fmasks, ffeats);
+        std::vector<msshim::featurefinder::MatchesInfo> fpair(6);
+        msshim::featurefinder::matchFeatures(ffeats, fpair);
+        msshim::featurefinder::matchFeaturesTemporal(ffeats, ffeats, fpair);
         msshim::MeshWarper mw(6, 10, 10, 600.f, 1.0, 0.5);
+        mw.calibrateMeshWarp(comp, frames, ffeats, fpair);
         mw.calibrateMeshWarp(comp, frames, feats, pairwise);
     } catch (const msshim::Error &e) {
         return e.code;
