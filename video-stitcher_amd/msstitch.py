@@ -86,7 +86,7 @@ EXPORTS = [
     "ms_copy_make_border", "ms_pyr_down", "ms_pyr_up", "ms_subtract_16s", "ms_add_16s", "ms_add_src_weight_32f",
     "ms_normalize_using_weight_32f", "ms_compare_gt_32f", "ms_compare_eq_8u", "ms_set_zero_masked_16sc3",
     "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
-    "ms_calibrate_cameras", "ms_num_bands_rule", "ms_orb_default_params", "ms_orb_detect_and_compute", "ms_find_homography_ransac",
+    "ms_calibrate_cameras", "ms_num_bands_rule", "ms_orb_default_params", "ms_orb_detect_and_compute", "ms_find_homography_ransac", "ms_feature_mask",
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
