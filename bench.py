@@ -217,12 +217,19 @@ def run_view_shards(args, cfg, gains, rank, world, dev, share):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ok = None
-    if local:        # same frames through an unsharded context: the split must not change a single byte
+    if is_sink:      # same frames through an unsharded context on the sink: the split (and the transfer) must not change a single byte
         full = make(1, 0)
+        all_pool = [[torch.from_numpy(synth.frame(cfg["w"], cfg["h"], i, t)).to(dev) for i in range(N)] for t in range(4)]
+        all_frames = [all_pool[(group + j) % 4] for j in range(F)]
         want = [torch.zeros_like(o) for o in outs]
-        full.stitch(frames, out8u=want)
+        full.stitch(all_frames, out8u=want)
         torch.cuda.synchronize()
         ok = all(torch.equal(a, b) for a, b in zip(outs, want))
+        full.close()
+    if world > 1:    # every group's sink must agree
+        flag = torch.tensor([1 if (ok is None or ok) else 0], dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
     if rank == 0:
         groups = 1 if local else world // V
         total = groups * F * args.steps

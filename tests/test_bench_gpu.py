@@ -45,3 +45,19 @@ def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "gather" in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
     assert d["value_no_gather"] > 0 and d["gather"]["gathered_passes"] == 4 and d["verified"] is True
+
+
+def test_view_sharded_ranks_exchange_partials_and_match_the_unsharded_frame():
+    """BASELINE configs[4]'s mechanism across two RANKS: each owns half of the views, builds the partial dst pyramid (ms_stitch_partial), the partial of
+    rank 1 travels to rank 0 (send / recv), which adds, normalises, collapses (ms_stitch_finish); the sink re-stitches the same frames unsharded and
+    compares.  With two GPUs: RCCL over xGMI; on a one-GPU box the two ranks share the GPU and the partials go through gloo (MS_BENCH_SHARE_GPU=1)."""
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ) if two else dict(os.environ, MS_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29537",
+                        "bench.py", "--gpus", "2", "--view-shards", "2", "--frames", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["equals_unsharded"] is True and d["value"] > 0
+    assert ("RCCL" in d["config"]["workload"]) == two

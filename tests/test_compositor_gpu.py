@@ -245,7 +245,7 @@ def test_lds_staged_warp_equals_direct(ms, cuda, rig):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("rig,shards", [("mini6", 2), ("mini6", 3), ("cfg2", 2)])
+@pytest.mark.parametrize("rig,shards", [("mini6", 2), ("mini6", 3), ("cfg2", 2), ("cfg5", 2)])       # cfg5 = BASELINE configs[4]: 12 x 4K, views 6 + 6
 def test_view_sharding_equals_single_context(ms, cuda, rig, shards):
     """BASELINE configs[4] mechanism on one GPU: S contexts, each owning a block of views, write partial int16 sums;
     the sink context adds them (wrap-around) and finishes.  Must equal the single-context frame bit for bit."""
