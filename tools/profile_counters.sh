@@ -44,3 +44,4 @@ with open("gpurun_out/counters_%s.txt" % tag, "w") as fo:
             fo.write("    %-40s %18.1f   (mean launch %.1f us)\n" % (c, v, dur / 1e3))
 print(open("gpurun_out/counters_%s.txt" % tag).read()[:200])
 PY
+rm -rf $OUT/p[0-9]*/ 2>/dev/null; find $OUT -name "*.db" -delete      # keep the per-pass text summaries only (gpurun merges <= 64 MiB)

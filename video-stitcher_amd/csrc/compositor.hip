@@ -1905,17 +1905,10 @@ int ms_build_masks(ms_ctx *c, int mode, ms_stream stream)
         MS_LAUNCH_CHECK();
     }
     MS_HIP(hipStreamSynchronize(st));
-    if (mode == 1) {   // seams on the host, exactly where the reference runs VoronoiSeamFinder
-        std::vector<std::vector<uint8_t>> hm(c->N);
+    if (mode == 1) {   // VoronoiSeamFinder on the device (calib.hip): the masks never leave it
         std::vector<uint8_t *> ptr(c->N);
-        for (int i = 0; i < c->N; ++i) {
-            hm[i].resize((size_t)c->roi[i].width * c->roi[i].height);
-            MS_HIP(hipMemcpy(hm[i].data(), (uint8_t *)c->masks.p + c->mask_off[i], hm[i].size(), hipMemcpyDeviceToHost));
-            ptr[i] = hm[i].data();
-        }
-        voronoi_seams(c->N, c->roi, ptr.data());
-        for (int i = 0; i < c->N; ++i)
-            MS_HIP(hipMemcpy((uint8_t *)c->masks.p + c->mask_off[i], hm[i].data(), hm[i].size(), hipMemcpyHostToDevice));
+        for (int i = 0; i < c->N; ++i) ptr[i] = (uint8_t *)c->masks.p + c->mask_off[i];
+        if (int e = voronoi_seams_device(c->N, c->roi, ptr.data(), st)) return e;
     }
     c->masks_built = true;
     c->blender_ready = false;
@@ -1924,7 +1917,7 @@ int ms_build_masks(ms_ctx *c, int mode, ms_stream stream)
 
 // Seam-scale calibration, the reference's own pipeline (APP/calibration.cpp:92-135 and 224-237):
 //   resize(full, seam_scale) -> warp(image: LINEAR/REFLECT, mask 255: NEAREST/CONSTANT) at seam scale -> download ->
-//   GainCompensator::feed (host) -> VoronoiSeamFinder (host) -> upload -> [dilate] -> resize to the compose mask size
+//   GainCompensator::feed -> VoronoiSeamFinder (both on the device here: calib.hip) -> [dilate] -> resize to the compose mask size
 //   (INTER_LINEAR) -> bitwise_and with warp(255) at compose scale  => the masks init_gpu receives.
 int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam, const ms_seam_params *prm, double *gains_out, ms_stream stream)
 {
@@ -1940,8 +1933,8 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
     MS_CHECK(ws >= 2 && hs >= 2, "ms_calibrate_seam: seam image %dx%d too small", ws, hs);
     if (int e = alloc_masks(c)) return e;
     std::vector<ms_rect> rs(N);
-    std::vector<std::vector<uint8_t>> himg(N), hmask(N);
-    DevBuf seam, mapx, mapy, wimg, wmask;
+    std::vector<DevBuf> wimg(N), wmask(N);          // the warped seam images and masks of all views stay on the device
+    DevBuf seam, mapx, mapy;
     if (int e = seam.alloc((size_t)ws * hs * 3)) return e;
     for (int i = 0; i < N; ++i) {
         MS_CHECK(full_imgs[i].data && full_imgs[i].type == MS_8UC3 && full_imgs[i].rows == FH && full_imgs[i].cols == FW,
@@ -1956,41 +1949,36 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
         const size_t npx = (size_t)rs[i].width * rs[i].height;
         if (int e = mapx.alloc(npx * 4)) return e;
         if (int e = mapy.alloc(npx * 4)) return e;
-        if (int e = wimg.alloc(npx * 3)) return e;
-        if (int e = wmask.alloc(npx)) return e;
+        if (int e = wimg[i].alloc(npx * 3)) return e;
+        if (int e = wmask[i].alloc(npx)) return e;
         ms_image mx{mapx.p, (size_t)rs[i].width * 4, rs[i].width, rs[i].height, MS_32FC1}, my{mapy.p, (size_t)rs[i].width * 4, rs[i].width, rs[i].height, MS_32FC1};
         float k_rinv[9];
         k_rinv_gemm(Ks, c->R[i], k_rinv);
         if (int e = launch_build_warp_maps(c->cfg.projection, rs[i].x, rs[i].y, mx, my, k_rinv, nullptr, prm->seam_warp_scale, st)) return e;
-        ms_image wi{wimg.p, (size_t)rs[i].width * 3, rs[i].width, rs[i].height, MS_8UC3};
+        ms_image wi{wimg[i].p, (size_t)rs[i].width * 3, rs[i].width, rs[i].height, MS_8UC3};
         if (int e = launch_remap(simg, mx, my, wi, MS_INTER_LINEAR, MS_BORDER_REFLECT, st)) return e;                   // calibration.cpp:118
         k_valid_mask<<<dim3(div_up(rs[i].width, 64), div_up(rs[i].height, 4)), dim3(64, 4), 0, st>>>(                // calibration.cpp:122
-            (const float *)mapx.p, (const float *)mapy.p, rs[i].width, rs[i].height, rs[i].width, hs, ws, (uint8_t *)wmask.p, rs[i].width);
+            (const float *)mapx.p, (const float *)mapy.p, rs[i].width, rs[i].height, rs[i].width, hs, ws, (uint8_t *)wmask[i].p, rs[i].width);
         MS_LAUNCH_CHECK();
-        himg[i].resize(npx * 3); hmask[i].resize(npx);
-        MS_HIP(hipMemcpyAsync(himg[i].data(), wimg.p, npx * 3, hipMemcpyDeviceToHost, st));
-        MS_HIP(hipMemcpyAsync(hmask[i].data(), wmask.p, npx, hipMemcpyDeviceToHost, st));
-        MS_HIP(hipStreamSynchronize(st));
+        MS_HIP(hipStreamSynchronize(st));            // (mapx / mapy / seam are reused by the next view)
     }
     std::vector<const uint8_t *> ip(N), mp(N);
     std::vector<uint8_t *> mpw(N);
-    for (int i = 0; i < N; ++i) { ip[i] = himg[i].data(); mp[i] = hmask[i].data(); mpw[i] = hmask[i].data(); }
+    for (int i = 0; i < N; ++i) { ip[i] = (const uint8_t *)wimg[i].p; mp[i] = (const uint8_t *)wmask[i].p; mpw[i] = (uint8_t *)wmask[i].p; }
     if (prm->estimate_gains || gains_out) {                                                                          // calibration.cpp:131
         std::vector<double> g(N, 1.0);
-        if (!estimate_gains(N, rs.data(), ip.data(), mp.data(), g.data())) return fail(MS_ERR_INVALID, "ms_calibrate_seam: singular gain system");
+        if (int e = estimate_gains_device(N, rs.data(), ip.data(), mp.data(), g.data(), st)) return e;               // GainCompensator::feed on the device; N doubles come back
         for (int i = 0; i < N; ++i) {
             if (gains_out) gains_out[i] = g[i];
             if (prm->estimate_gains) if (int e = ms_set_gain(c, i, g[i])) return e;
         }
     }
-    voronoi_seams(N, rs.data(), mpw.data());                                                                          // calibration.cpp:134-135
+    if (int e = voronoi_seams_device(N, rs.data(), mpw.data(), st)) return e;                                         // calibration.cpp:134-135, on the device
     DevBuf dil, big;
     for (int i = 0; i < N; ++i) {
-        const size_t npx = hmask[i].size();
+        const size_t npx = (size_t)rs[i].width * rs[i].height;
         const int aw = c->roi[i].width, ah = c->roi[i].height;
-        if (int e = wmask.alloc(npx)) return e;
-        MS_HIP(hipMemcpyAsync(wmask.p, hmask[i].data(), npx, hipMemcpyHostToDevice, st));                            // calibration.cpp:229
-        ms_image sm{wmask.p, (size_t)rs[i].width, rs[i].width, rs[i].height, MS_8UC1};
+        ms_image sm{wmask[i].p, (size_t)rs[i].width, rs[i].width, rs[i].height, MS_8UC1};
         if (prm->dilate) {                                                                                            // calibration.cpp:231-232
             if (int e = dil.alloc(npx)) return e;
             ms_image dm{dil.p, (size_t)rs[i].width, rs[i].width, rs[i].height, MS_8UC1};
@@ -2009,7 +1997,6 @@ int ms_calibrate_seam(ms_ctx *c, const ms_image *full_imgs, const float *K_seam,
         if (int e = launch_and_8u(bm, vm, vm, st)) return e;                                                         // calibration.cpp:237
         MS_HIP(hipStreamSynchronize(st));
     }
-    seam.release(); mapx.release(); mapy.release(); wimg.release(); wmask.release(); dil.release(); big.release();
     c->masks_built = true;
     c->blender_ready = false;
     return MS_OK;

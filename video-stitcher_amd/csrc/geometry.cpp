@@ -206,7 +206,7 @@ ViewPad blender_view_pad(const BlendGeom &g, int tl_x, int tl_y, int mc, int mr)
     return v;
 }
 
-// ---- Voronoi seams -------------------------------------------------------------------------------
+// ---- L1 distance transform (FeatherBlender's createWeightMap; the Voronoi seams use the device version in calib.hip) ------
 namespace {
 
 // cv::distanceTransform(DIST_L1, 3): two-pass chamfer, fixed point 16.16 (distransform.cpp:70-137)
@@ -244,34 +244,6 @@ void dist_l1(const std::vector<uint8_t> &src, int rows, int cols, std::vector<fl
     }
 }
 
-void seam_pair(uint8_t *m1, const ms_rect &r1, uint8_t *m2, const ms_rect &r2, const ms_rect &roi)
-{
-    constexpr int gap = 10;
-    const int R = roi.height + 2 * gap, C = roi.width + 2 * gap;
-    std::vector<uint8_t> z1((size_t)R * C), z2((size_t)R * C);
-    auto at = [](const uint8_t *m, const ms_rect &r, int y, int x) -> uint8_t {
-        return (y >= 0 && x >= 0 && y < r.height && x < r.width) ? m[(size_t)y * r.width + x] : 0;
-    };
-    for (int y = -gap; y < roi.height + gap; ++y)
-        for (int x = -gap; x < roi.width + gap; ++x) {
-            const uint8_t a = at(m1, r1, roi.y - r1.y + y, roi.x - r1.x + x);
-            const uint8_t b = at(m2, r2, roi.y - r2.y + y, roi.x - r2.x + x);
-            const bool both = a && b;
-            // distanceTransform(unique == 0): the transform's zero set is where the unique mask is set
-            z1[(size_t)(y + gap) * C + x + gap] = (!both && a) ? 0 : 255;
-            z2[(size_t)(y + gap) * C + x + gap] = (!both && b) ? 0 : 255;
-        }
-    std::vector<float> d1, d2;
-    dist_l1(z1, R, C, d1);
-    dist_l1(z2, R, C, d2);
-    for (int y = 0; y < roi.height; ++y)
-        for (int x = 0; x < roi.width; ++x) {
-            const size_t i = (size_t)(y + gap) * C + x + gap;
-            if (d1[i] < d2[i]) m2[(size_t)(roi.y - r2.y + y) * r2.width + (roi.x - r2.x + x)] = 0;
-            else m1[(size_t)(roi.y - r1.y + y) * r1.width + (roi.x - r1.x + x)] = 0;
-        }
-}
-
 }  // namespace
 
 // createWeightMap (blenders.cpp:944-951): distanceTransform(mask, DIST_L1, 3) * sharpness, threshold(.., 1, THRESH_TRUNC); fp32
@@ -286,110 +258,7 @@ void feather_weight_map(const uint8_t *mask, int rows, int cols, float sharpness
     }
 }
 
-void voronoi_seams(int n, const ms_rect *rois, uint8_t **masks)
-{
-    for (int i = 0; i + 1 < n; ++i)
-        for (int j = i + 1; j < n; ++j) {
-            const int x0 = std::max(rois[i].x, rois[j].x), y0 = std::max(rois[i].y, rois[j].y);
-            const int x1 = std::min(rois[i].x + rois[i].width, rois[j].x + rois[j].width);
-            const int y1 = std::min(rois[i].y + rois[i].height, rois[j].y + rois[j].height);
-            if (x0 < x1 && y0 < y1) seam_pair(masks[i], rois[i], masks[j], rois[j], ms_rect{x0, y0, x1 - x0, y1 - y0});
-        }
-}
-
-
-// ---- exposure gains: GainCompensator::feed (exposure_compensate.cpp:71-145) + cv::solve DECOMP_LU ---------------
-namespace {
-
-// cv::solve for CV_64F: closed forms up to 3x3 (lapack.cpp:1107-1237), LUImpl with partial pivoting otherwise
-// (matrix_decomp.cpp:52-112), same operation order as the reference
-bool solve_lu(std::vector<double> &A, std::vector<double> &b, int n)
-{
-    auto a = [&](int i, int j) -> double & { return A[(size_t)i * n + j]; };
-    if (n == 1) { if (a(0, 0) == 0.) return false; b[0] = b[0] / a(0, 0); return true; }
-    if (n == 2) {
-        double d = a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
-        if (d == 0.) return false;
-        d = 1. / d;
-        const double t = (b[0] * a(1, 1) - b[1] * a(0, 1)) * d;
-        b[1] = (b[1] * a(0, 0) - b[0] * a(1, 0)) * d;
-        b[0] = t;
-        return true;
-    }
-    if (n == 3) {
-        double d = a(0, 0) * (a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1)) - a(0, 1) * (a(1, 0) * a(2, 2) - a(1, 2) * a(2, 0)) +
-                   a(0, 2) * (a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0));
-        if (d == 0.) return false;
-        d = 1. / d;
-        const double t0 = ((a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1)) * b[0] + (a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2)) * b[1] + (a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1)) * b[2]) * d;
-        const double t1 = ((a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2)) * b[0] + (a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0)) * b[1] + (a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2)) * b[2]) * d;
-        const double t2 = ((a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0)) * b[0] + (a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1)) * b[1] + (a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0)) * b[2]) * d;
-        b[0] = t0; b[1] = t1; b[2] = t2;
-        return true;
-    }
-    const double eps = DBL_EPSILON * 100;
-    for (int i = 0; i < n; ++i) {
-        int k = i;
-        for (int j = i + 1; j < n; ++j) if (std::abs(a(j, i)) > std::abs(a(k, i))) k = j;
-        if (std::abs(a(k, i)) < eps) return false;
-        if (k != i) { for (int j = i; j < n; ++j) std::swap(a(i, j), a(k, j)); std::swap(b[i], b[k]); }
-        const double d = -1 / a(i, i);
-        for (int j = i + 1; j < n; ++j) {
-            const double alpha = a(j, i) * d;
-            for (int q = i + 1; q < n; ++q) a(j, q) += alpha * a(i, q);
-            b[j] += alpha * b[i];
-        }
-    }
-    for (int i = n - 1; i >= 0; --i) {
-        double sv = b[i];
-        for (int q = i + 1; q < n; ++q) sv -= a(i, q) * b[q];
-        b[i] = sv / a(i, i);
-    }
-    return true;
-}
-
-}  // namespace
-
-bool estimate_gains(int n, const ms_rect *rois, const uint8_t *const *images, const uint8_t *const *masks, double *gains)
-{
-    std::vector<int> N((size_t)n * n, 0);
-    std::vector<double> I((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i)
-        for (int j = i; j < n; ++j) {
-            const int x0 = std::max(rois[i].x, rois[j].x), y0 = std::max(rois[i].y, rois[j].y);
-            const int x1 = std::min(rois[i].x + rois[i].width, rois[j].x + rois[j].width);
-            const int y1 = std::min(rois[i].y + rois[i].height, rois[j].y + rois[j].height);
-            if (!(x0 < x1 && y0 < y1)) continue;
-            int cnt = 0;
-            double s1 = 0, s2 = 0;
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) {
-                    const size_t p1 = (size_t)(y - rois[i].y) * rois[i].width + (x - rois[i].x);
-                    const size_t p2 = (size_t)(y - rois[j].y) * rois[j].width + (x - rois[j].x);
-                    if (masks[i][p1] != 255 || masks[j][p2] != 255) continue;
-                    ++cnt;
-                    const uint8_t *a = images[i] + 3 * p1, *b = images[j] + 3 * p2;
-                    s1 += std::sqrt(static_cast<double>(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]));
-                    s2 += std::sqrt(static_cast<double>(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]));
-                }
-            N[(size_t)i * n + j] = N[(size_t)j * n + i] = std::max(1, cnt);
-            I[(size_t)i * n + j] = s1 / N[(size_t)i * n + j];
-            I[(size_t)j * n + i] = s2 / N[(size_t)i * n + j];
-        }
-    const double alpha = 0.01, beta = 100;
-    std::vector<double> A((size_t)n * n, 0.0), b(n, 0.0);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            b[i] += beta * N[(size_t)i * n + j];
-            A[(size_t)i * n + i] += beta * N[(size_t)i * n + j];
-            if (j == i) continue;
-            A[(size_t)i * n + i] += 2 * alpha * I[(size_t)i * n + j] * I[(size_t)i * n + j] * N[(size_t)i * n + j];
-            A[(size_t)i * n + j] -= 2 * alpha * I[(size_t)i * n + j] * I[(size_t)j * n + i] * N[(size_t)i * n + j];
-        }
-    if (!solve_lu(A, b, n)) return false;
-    for (int i = 0; i < n; ++i) gains[i] = b[i];
-    return true;
-}
+// (VoronoiSeamFinder and GainCompensator::feed run on the device: calib.hip)
 
 // calibrateCameras + scale bookkeeping (APP/calibration.cpp:28-68, 101-116, 147-181, 269-288), in the reference's types
 int calibrate_cameras(const ms_rig_params &q, ms_rig &r)

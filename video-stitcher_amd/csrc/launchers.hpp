@@ -44,9 +44,9 @@ struct ViewPad { int top, left, bottom, right, x_tl, y_tl, x_br, y_br; };
 BlendGeom blender_prepare(ms_rect dst_roi, int actual_num_bands);
 ViewPad blender_view_pad(const BlendGeom &g, int tl_x, int tl_y, int mask_cols, int mask_rows);
 // VoronoiSeamFinder over host masks (contiguous, h x w each), in place
-void voronoi_seams(int n, const ms_rect *rois, uint8_t **masks);
+// VoronoiSeamFinder over device masks, in place
+int voronoi_seams_device(int n, const ms_rect *rois, uint8_t *const *masks_dev, hipStream_t st);                 // calib.hip
+int estimate_gains_device(int n, const ms_rect *rois, const uint8_t *const *images_dev, const uint8_t *const *masks_dev, double *gains_host, hipStream_t st);
 void feather_weight_map(const uint8_t *mask, int rows, int cols, float sharpness, float *w);
-// GainCompensator::feed over host images (8UC3, contiguous) and masks (8UC1, contiguous); false if the system is singular
-bool estimate_gains(int n, const ms_rect *rois, const uint8_t *const *images, const uint8_t *const *masks, double *gains);
 
 }  // namespace ms
