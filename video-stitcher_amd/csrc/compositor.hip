@@ -105,17 +105,17 @@ __global__ void __launch_bounds__(256) k_warp(const ViewDesc *__restrict__ views
     d[0] = r[0]; d[plane] = r[1]; d[2 * plane] = r[2];
 }
 
-// pyrDown of one plane of one view: level l -> l+1 (pyr_down.cu:55-174 in exact integer form)
-template <typename TIN>
+// pyrDown of one plane of one view: level l -> l+1 (pyr_down.cu:55-174 in exact integer form).  Every Gaussian level of a view is a convex
+// combination of 8-bit pixels (all values in [0, 255]): the view pyramids are stored as bytes, half the traffic of the reference's 16S.
 __global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views, int n_views, int l,
-                                              const TIN *__restrict__ gin, long long in_stride,
-                                              int16_t *__restrict__ gout, long long out_stride)
+                                              const uint8_t *__restrict__ gin, long long in_stride,
+                                              uint8_t *__restrict__ gout, long long out_stride)
 {
     const int z = blockIdx.z, c = z % 3, v = (z / 3) % n_views, f = z / (3 * n_views);
     const LevelDesc &Li = views[v].lv[l], &Lo = views[v].lv[l + 1];
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= Lo.w || y >= Lo.h) return;
-    const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
+    const uint8_t *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
     const int sy = 2 * y, sx = 2 * x;
     int ry[5], cx[5];
     if (Li.h >= 3 && Li.w >= 3) {     // |overshoot| <= 2 < len: BORDER_REFLECT_101 without the integer modulo
@@ -136,11 +136,11 @@ __global__ void __launch_bounds__(256) k_down(const ViewDesc *__restrict__ views
     int acc = 0;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const TIN *r = in + (size_t)ry[j] * Li.pitch;
+        const uint8_t *r = in + (size_t)ry[j] * Li.pitch;
 #pragma unroll
         for (int k = 0; k < 5; ++k) acc += wv[j] * wv[k] * (int)r[cx[k]];
     }
-    gout[(size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + x] = sat_s16(rne_shift(acc, 8));
+    gout[(size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + x] = (uint8_t)rne_shift(acc, 8);       // <= 255
 }
 
 // 16 bytes from a 4-byte aligned address as one global_load_dwordx4
@@ -164,7 +164,7 @@ __host__ __device__ inline void tail_range(const int *w, int l0, int nb, int str
     for (int l = nb - 1; l >= l0; --l) { a[l] = max(2 * a[l + 1] - 2, 0); b[l] = min(2 * b[l + 1] + 2, w[l]); }
 }
 __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ views, int n_views, int l0, int nb, int max_strips,
-                                                   int16_t *__restrict__ gl, long long gl_stride, unsigned own_mask)
+                                                   uint8_t *__restrict__ gl, long long gl_stride, unsigned own_mask)
 {
     extern __shared__ uint8_t s_lv[];
     const int strip = blockIdx.x % max_strips, z = blockIdx.x / max_strips;
@@ -175,31 +175,31 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
     for (int l = l0; l <= nb; ++l) w[l] = V.lv[l].w;
     if (strip * TAIL_STRIP >= w[nb]) return;
     tail_range(w, l0, nb, strip, a, b);
-    int16_t *base = gl + (size_t)f * gl_stride;
+    uint8_t *base = gl + (size_t)f * gl_stride;
     const int tx = threadIdx.x, ty = threadIdx.y;           // block 64 x 4
     uint8_t *cur = s_lv;
     {
         const LevelDesc &La = V.lv[l0];
-        const int16_t *in = base + La.off + (size_t)c * La.h * La.pitch + a[l0];
+        const uint8_t *in = base + La.off + (size_t)c * La.h * La.pitch + a[l0];
         const int wl = b[l0] - a[l0];
-        // 8 columns per 16-byte read (a[l0] is even: dword aligned), four reads in flight per lane before the first LDS write
+        // 8 columns per 8-byte read (a[l0] is even: the address is 2-byte aligned, the hardware takes it), four reads in flight per lane before the first LDS write
         const int nchunk = (wl + 7) >> 3, total = La.h * nchunk, tid = ty * 64 + tx;
         for (int i0 = tid; i0 < total; i0 += 1024) {
-            uint4 q[4];
+            uint2 q[4];
             int yy[4], cc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = min(i0 + 256 * u, total - 1);
                 yy[u] = i / nchunk; cc[u] = i - yy[u] * nchunk;
-                q[u] = load16_a4(in + (size_t)yy[u] * La.pitch + 8 * cc[u]);
+                __builtin_memcpy(&q[u], in + (size_t)yy[u] * La.pitch + 8 * cc[u], 8);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (i0 + 256 * u >= total) continue;
-                const unsigned d[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                const unsigned d[2] = {q[u].x, q[u].y};
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (8 * cc[u] + k < wl) cur[yy[u] * wl + 8 * cc[u] + k] = (uint8_t)((d[k >> 1] >> (16 * (k & 1))) & 0xffu);
+                    if (8 * cc[u] + k < wl) cur[yy[u] * wl + 8 * cc[u] + k] = (uint8_t)((d[k >> 2] >> (8 * (k & 3))) & 0xffu);
             }
         }
     }
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
         const LevelDesc &Li = V.lv[l], &Lo = V.lv[l + 1];
         const int wi = b[l] - a[l], wo = b[l + 1] - a[l + 1];
         uint8_t *nxt = cur + ((wi * Li.h + 15) & ~15);
-        int16_t *out = base + Lo.off + (size_t)c * Lo.h * Lo.pitch;
+        uint8_t *out = base + Lo.off + (size_t)c * Lo.h * Lo.pitch;
         const bool big = Li.h >= 3 && Li.w >= 3;           // |overshoot| <= 2 < len: BORDER_REFLECT_101 without the integer modulo
         const int lr = Li.h - 1, lc = Li.w - 1;
         const int own_a = min((strip * TAIL_STRIP) << (nb - l - 1), Lo.w);
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
             }
             const int o = rne_shift(hs[0] + hs[4] + 4 * (hs[1] + hs[3]) + 6 * hs[2], 8);
             nxt[i] = (uint8_t)o;
-            if (x >= own_a && x < own_b) out[(size_t)y * Lo.pitch + x] = (int16_t)o;
+            if (x >= own_a && x < own_b) out[(size_t)y * Lo.pitch + x] = (uint8_t)o;
         }
         __syncthreads();
         cur = nxt;
@@ -249,104 +249,15 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
 // where the mirrored columns are already inside the body (col -2 -> 2, -1 -> 1, w -> w-2).
 // Raw row fetch for columns [8t-2, 8t+8] of one input row, issued unconditionally (clamped addresses) so that the
 // 7 rows' loads are in flight together; the reflect selection happens after, in registers.
-//   u8:    ONE 16-byte load at byte 8t-4 (dword aligned) covers bytes 8t-4 .. 8t+11
-//   int16: a 16-byte load at element 8t-2 (dword aligned) covers 8t-2 .. 8t+5, an 8-byte load covers 8t+6 .. 8t+9
+//   ONE 16-byte load at byte 8t-4 (dword aligned) covers bytes 8t-4 .. 8t+11
 // (wave-wide gathers cost per instruction, so fewer, wider loads win).  Reads may run a few bytes past the end of
 // the last row of a plane: planes are contiguous and the buffers carry 64 bytes of slack.
 struct Row11u8 { uint4 b; };
-struct Row11s16 { uint4 b; uint2 c; };
 __device__ __forceinline__ Row11u8 fetch_row11(const uint8_t *__restrict__ row, int t, int w)
 {
     Row11u8 o;
     __builtin_memcpy(&o.b, __builtin_assume_aligned(row + max(8 * t - 4, 0), 4), 16);
     return o;
-}
-__device__ __forceinline__ Row11s16 fetch_row11(const int16_t *__restrict__ row, int t, int w)
-{
-    Row11s16 o;
-    const int16_t *p = row + max(8 * t - 2, 0);
-    __builtin_memcpy(&o.b, __builtin_assume_aligned(p, 4), 16);
-    __builtin_memcpy(&o.c, __builtin_assume_aligned(p + 8, 4), 8);
-    return o;
-}
-__device__ __forceinline__ void unpack_row11(const Row11u8 &o, int t, int w, int v[11])
-{
-    const unsigned d[4] = {o.b.x, o.b.y, o.b.z, o.b.w};
-    int e[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) e[i] = (d[i >> 2] >> (8 * (i & 3))) & 0xff;
-    if (t == 0) {            // window starts at column 0: columns -2, -1 mirror to 2, 1
-        v[0] = e[2]; v[1] = e[1];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v[2 + k] = e[k];
-    } else {                 // window starts at column 8t-4
-#pragma unroll
-        for (int k = 0; k < 11; ++k) v[k] = e[2 + k];
-    }
-    if (8 * t + 8 >= w) v[10] = v[8];                                   // col w -> w-2
-}
-__device__ __forceinline__ void unpack_row11(const Row11s16 &o, int t, int w, int v[11])
-{
-    const unsigned d[6] = {o.b.x, o.b.y, o.b.z, o.b.w, o.c.x, o.c.y};
-    int e[12];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { e[2 * i] = (int16_t)(d[i] & 0xffff); e[2 * i + 1] = (int)d[i] >> 16; }
-    if (t == 0) {            // window starts at column 0
-        v[0] = e[2]; v[1] = e[1];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v[2 + k] = e[k];
-    } else {                 // window starts at column 8t-2
-#pragma unroll
-        for (int k = 0; k < 11; ++k) v[k] = e[k];
-    }
-    if (8 * t + 8 >= w) v[10] = v[8];
-}
-template <typename T> struct Row11 { using type = Row11u8; };
-template <> struct Row11<int16_t> { using type = Row11s16; };
-
-template <typename TIN>
-__global__ void __launch_bounds__(256) k_down_vec(const ViewDesc *__restrict__ views, int n_views, int l,
-                                                  const TIN *__restrict__ gin, long long in_stride,
-                                                  int16_t *__restrict__ gout, long long out_stride)
-{
-    const int z = blockIdx.z, c = z % 3, v = (z / 3) % n_views, f = z / (3 * n_views);
-    const LevelDesc &Li = views[v].lv[l], &Lo = views[v].lv[l + 1];
-    const int t = blockIdx.x * 64 + threadIdx.x;            // group of 4 output columns
-    const int y = 2 * (blockIdx.y * 4 + threadIdx.y);       // first of 2 output rows
-    if (4 * t >= Lo.w || y >= Lo.h) return;
-    const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
-    const bool two = (y + 1) < Lo.h;
-    const int sy = 2 * y, h = Li.h, last = h - 1;
-    // BORDER_REFLECT_101 rows (h >= 3: no modulo needed, |overshoot| <= 2)
-    int ridx[7];
-    ridx[0] = abs(sy - 2); ridx[1] = abs(sy - 1); ridx[2] = sy;
-#pragma unroll
-    for (int j = 3; j < 7; ++j) { const int r = sy + j - 2; ridx[j] = r > last ? 2 * last - r : r; }
-    if (!two) { ridx[5] = ridx[4]; ridx[6] = ridx[4]; }      // unused rows: any valid address
-    typename Row11<TIN>::type raw[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) raw[j] = fetch_row11(in + (size_t)ridx[j] * Li.pitch, t, Li.w);
-    int V0[11], V1[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) V0[k] = V1[k] = 0;
-    const int w0[7] = {1, 4, 6, 4, 1, 0, 0}, w1[7] = {0, 0, 1, 4, 6, 4, 1};
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        int r[11];
-        unpack_row11(raw[j], t, Li.w, r);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { V0[k] += w0[j] * r[k]; V1[k] += w1[j] * r[k]; }
-    }
-    int16_t *out = gout + (size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + 4 * t;
-    auto emit = [&](const int *V, int16_t *dst) {
-        unsigned o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            o[i] = (unsigned)(uint16_t)sat_s16(rne_shift(V[2 * i] + 4 * V[2 * i + 1] + 6 * V[2 * i + 2] + 4 * V[2 * i + 3] + V[2 * i + 4], 8));
-        *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-    };
-    emit(V0, out);
-    if (two) emit(V1, out + Lo.pitch);
 }
 
 }  // namespace ms
@@ -354,13 +265,14 @@ __global__ void __launch_bounds__(256) k_down_vec(const ViewDesc *__restrict__ v
 #include "tile_kernels.hpp"
 namespace ms {
 
-// pyrUp of a 2x2 quad whose top-left fine pixel is (2i, 2j), from a planar int16 coarse level
-// (pyr_up.cu:55-145 in exact integer form).  out[0..3] = (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1).
-__device__ __forceinline__ void up_quad(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j, int out[4])
+// pyrUp of a 2x2 quad whose top-left fine pixel is (2i, 2j), from a planar coarse level (T = uint8_t: a view's Gaussian level,
+// int16_t: a collapsed band) (pyr_up.cu:55-145 in exact integer form).  out[0..3] = (2i,2j) (2i,2j+1) (2i+1,2j) (2i+1,2j+1).
+template <typename T>
+__device__ __forceinline__ void up_quad(const T *__restrict__ cs, int cpitch, int ch, int cw, int i, int j, int out[4])
 {
     const int r0 = pu_idx(i - 1, ch), r1 = pu_idx(i, ch), r2 = pu_idx(i + 1, ch);
     const int c0 = pu_idx(j - 1, cw), c1 = pu_idx(j, cw), c2 = pu_idx(j + 1, cw);
-    const int16_t *p0 = cs + (size_t)r0 * cpitch, *p1 = cs + (size_t)r1 * cpitch, *p2 = cs + (size_t)r2 * cpitch;
+    const T *p0 = cs + (size_t)r0 * cpitch, *p1 = cs + (size_t)r1 * cpitch, *p2 = cs + (size_t)r2 * cpitch;
     const int a00 = p0[c0], a01 = p0[c1], a02 = p0[c2];
     const int a10 = p1[c0], a11 = p1[c1], a12 = p1[c2];
     const int a20 = p2[c0], a21 = p2[c1], a22 = p2[c2];
@@ -378,7 +290,7 @@ __device__ __forceinline__ void up_quad(const int16_t *__restrict__ cs, int cpit
 template <int MODE>      // 0 = whole frame, 1 = partial sums of the owned views, 2 = finish from partial sums (view sharding)
 __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ views, PanoDesc P,
                                                    const uint8_t *__restrict__ g0, long long g0_stride,
-                                                   const int16_t *__restrict__ gl, long long gl_stride,
+                                                   const uint8_t *__restrict__ gl, long long gl_stride,
                                                    int16_t *__restrict__ cl, long long cl_stride, ShardArgs S)
 {
     const int l = P.nb, f = blockIdx.z;
@@ -425,7 +337,7 @@ __global__ void __launch_bounds__(256) k_blend_top(const ViewDesc *__restrict__ 
 template <bool L0, int MODE>
 __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                const uint8_t *__restrict__ g0, long long g0_stride,
-                                               const int16_t *__restrict__ gl, long long gl_stride,
+                                               const uint8_t *__restrict__ gl, long long gl_stride,
                                                int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
 {
     const int f = blockIdx.z;
@@ -459,14 +371,8 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
         for (int c = 0; c < 3; ++c) {
             int up[4];
             up_quad(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up);
-            int g[4];
-            if (L0) {
-                const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + c * fplane + fo;
-                g[0] = p[0]; g[1] = p[1]; g[2] = p[L.pitch]; g[3] = p[L.pitch + 1];
-            } else {
-                const int16_t *p = gl + (size_t)f * gl_stride + L.off + c * fplane + fo;
-                g[0] = p[0]; g[1] = p[1]; g[2] = p[L.pitch]; g[3] = p[L.pitch + 1];
-            }
+            const uint8_t *p = (L0 ? g0 + (size_t)f * g0_stride : gl + (size_t)f * gl_stride) + L.off + c * fplane + fo;
+            const int g[4] = {p[0], p[1], p[L.pitch], p[L.pitch + 1]};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int lap = sat_s16(g[k] - (int)sat_s16(up[k]));
@@ -542,7 +448,7 @@ __host__ __device__ inline void btail_range(const int *qw, int t, int nb, int st
     }
 }
 __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__ views, PanoDesc P, int t,
-                                                    const int16_t *__restrict__ gl, long long gl_stride,
+                                                    const uint8_t *__restrict__ gl, long long gl_stride,
                                                     int16_t *__restrict__ cl, long long cl_stride)
 {
     extern __shared__ int16_t s_c[];
@@ -552,7 +458,7 @@ __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
     int16_t *cur = s_c, *prev = nullptr;       // cur: band l being written ((b-a) x qh), prev: band l+1
     int prev_w = 0;
-    const int16_t *glf = gl + (size_t)f * gl_stride;
+    const uint8_t *glf = gl + (size_t)f * gl_stride;
     for (int l = nb; l >= t; --l) {
         const int lw = b[l] - a[l], lh = P.qh[l];
         if (l == nb) {
@@ -587,7 +493,7 @@ __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__
                     if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;     // (short)(L * 0) == 0
                     int up[4];
                     up_quad(glf + C.off + (size_t)c * C.h * C.pitch, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up);
-                    const int16_t *p = glf + L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx;
+                    const uint8_t *p = glf + L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx;
                     const int g[4] = {p[0], p[1], p[L.pitch], p[L.pitch + 1]};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -712,6 +618,25 @@ __device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, un
     }
 }
 
+// A view's Gaussian level is stored as bytes: the 8-column window is ONE 8-byte read per row (2-byte aligned at worst, the hardware takes it),
+// widened to the 16-bit pairs of up_2x8_pk in registers.
+__device__ __forceinline__ void up_rows_load(const uint8_t *__restrict__ cs, int cpitch, int ch, int i, int j0, uint2 raw[3])
+{
+    const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
+    const int jb = max(j0 - 2, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) __builtin_memcpy(&raw[r], cs + (mul24(rr[r], cpitch) + (unsigned)jb), 8);
+}
+__device__ __forceinline__ void up_2x8_pk(const uint2 raw8[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
+{
+    uint4 raw[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        raw[r] = make_uint4(__builtin_amdgcn_perm(0u, raw8[r].x, 0x0c010c00u), __builtin_amdgcn_perm(0u, raw8[r].x, 0x0c030c02u),
+                            __builtin_amdgcn_perm(0u, raw8[r].y, 0x0c010c00u), __builtin_amdgcn_perm(0u, raw8[r].y, 0x0c030c02u));
+    up_2x8_pk(raw, cw, j0, ue, uo);
+}
+
 // The COLLAPSED coarser level has no such bound (it is a saturate_cast<short> of a sum), but in practice it stays near the 8-bit
 // range: add a bias of 384 and use the same packed arithmetic when all 18 taps of the lane are in [-384, 639]
 // (pyrUp's weights sum to 64 and 384 is even, so rne(S + 64*384, 6) == rne(S, 6) + 384 exactly); lanes with a tap outside
@@ -770,7 +695,7 @@ __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, u
 template <bool L0, int MODE>
 __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
-                                                const int16_t *__restrict__ gl, long long gl_stride,
+                                                const uint8_t *__restrict__ gl, long long gl_stride,
                                                 int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
 {
     const BlendTile T = tiles[blockIdx.x];
@@ -843,19 +768,13 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
         const size_t fo = mul24(ly, L.pitch) + (unsigned)lx;
         // the three colour planes are software-pipelined: the reads of plane c+1 (3 coarse rows + 2 fine rows) are issued before
         // plane c is computed, so a view costs about one memory round trip instead of three
-        uint4 craw[2][3];
-        typename std::conditional<L0, uint2, uint4>::type fraw[2][2];
+        uint2 craw[2][3], fraw[2][2];         // byte planes on both sides (level 0 = the warp output, levels >= 1 = the view's Gaussian levels)
+        const uint8_t *fine = (L0 ? g0 + (size_t)f * g0_stride : gl + (size_t)f * gl_stride) + L.off + fo;
         auto issue = [&](int c, int b) {
             up_rows_load(gl + (size_t)f * gl_stride + C.off + c * cplane, C.pitch, C.h, ly >> 1, lx >> 1, craw[b]);
-            if (L0) {
-                const uint8_t *p = g0 + (size_t)f * g0_stride + L.off + c * fplane + fo;
+            const uint8_t *p = fine + c * fplane;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) __builtin_memcpy(&fraw[b][r], __builtin_assume_aligned(p + (size_t)r * L.pitch, 8), sizeof(fraw[b][r]));
-            } else {
-                const int16_t *p = gl + (size_t)f * gl_stride + L.off + c * fplane + fo;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) __builtin_memcpy(&fraw[b][r], __builtin_assume_aligned(p + (size_t)r * L.pitch, 16), sizeof(fraw[b][r]));
-            }
+            for (int r = 0; r < 2; ++r) __builtin_memcpy(&fraw[b][r], __builtin_assume_aligned(p + (size_t)r * L.pitch, 8), 8);
         };
         issue(0, 0);
 #pragma unroll
@@ -867,15 +786,9 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
             unsigned g[2][4];                 // same pixel order as up: (0,2) (1,3) (4,6) (5,7)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                unsigned wds[4];
-                __builtin_memcpy(wds, &fraw[b][r], sizeof(fraw[b][r]));
-                if (L0) {
-                    g[r][0] = wds[0] & 0x00ff00ffu; g[r][1] = (wds[0] >> 8) & 0x00ff00ffu;
-                    g[r][2] = wds[1] & 0x00ff00ffu; g[r][3] = (wds[1] >> 8) & 0x00ff00ffu;
-                } else {
-                    g[r][0] = __builtin_amdgcn_perm(wds[1], wds[0], 0x05040100u); g[r][1] = __builtin_amdgcn_perm(wds[1], wds[0], 0x07060302u);
-                    g[r][2] = __builtin_amdgcn_perm(wds[3], wds[2], 0x05040100u); g[r][3] = __builtin_amdgcn_perm(wds[3], wds[2], 0x07060302u);
-                }
+                const unsigned w0 = fraw[b][r].x, w1 = fraw[b][r].y;
+                g[r][0] = w0 & 0x00ff00ffu; g[r][1] = (w0 >> 8) & 0x00ff00ffu;
+                g[r][2] = w1 & 0x00ff00ffu; g[r][3] = (w1 >> 8) & 0x00ff00ffu;
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -2057,7 +1970,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         for (int l = 0; l <= nb; ++l) {
             LevelDesc &L = V.lv[l];
             L.w = w; L.h = h; L.x_tl = xt; L.y_tl = yt;
-            L.pitch = round_up(w, l == 0 ? 16 : 8);
+            L.pitch = round_up(w, 16);          // byte planes at every level (the Gaussian levels of 8-bit pixels stay in [0, 255])
             L.wpitch = round_up(w, 4);
             c->w_off[v][l] = w_total;
             w_total += (size_t)h * L.wpitch;
@@ -2235,11 +2148,11 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     c->pacc_stride = (pacc_total + 127) / 128 * 128;
     c->stage_stride = (stage_total + 255) / 256 * 256;
     if (int e = c->g0.alloc((size_t)c->g0_stride * F + 64)) return e;
-    if (int e = c->gl.alloc((size_t)c->gl_stride * F * sizeof(int16_t) + 64)) return e;
+    if (int e = c->gl.alloc((size_t)c->gl_stride * F + 64)) return e;
     if (int e = c->cl.alloc((size_t)c->cl_stride * F * sizeof(int16_t) + 64)) return e;
     // invariant the packed band arithmetic relies on: every value in the view pyramids is in [0,255], written or not
     MS_HIP(hipMemsetAsync(c->g0.p, 0, (size_t)c->g0_stride * F + 64, st));
-    MS_HIP(hipMemsetAsync(c->gl.p, 0, (size_t)c->gl_stride * F * sizeof(int16_t) + 64, st));
+    MS_HIP(hipMemsetAsync(c->gl.p, 0, (size_t)c->gl_stride * F + 64, st));
     MS_HIP(hipMemsetAsync(c->cl.p, 0, (size_t)c->cl_stride * F * sizeof(int16_t) + 64, st));
     if (c->cfg.enable_cpw) {
         if (int e = c->stage.alloc((size_t)c->stage_stride * F)) return e;
@@ -2562,7 +2475,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
 
     const ViewDesc *vt = (const ViewDesc *)c->view_tab.p;
     const uint8_t *g0 = (const uint8_t *)c->g0.p;
-    int16_t *gl = (int16_t *)c->gl.p, *cl = (int16_t *)c->cl.p;
+    uint8_t *gl = (uint8_t *)c->gl.p;
+    int16_t *cl = (int16_t *)c->cl.p;
     const dim3 blk(64, 4);
 
     std::vector<hipEvent_t> ev;
@@ -2629,12 +2543,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
         if (c->down_vec[l] && c->cfg.debug_simple_kernels == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
-            if (l == 0) k_down_t<uint8_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
-            else        k_down_t<int16_t><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
+            if (l == 0) k_down_t<<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
+            else        k_down_t<<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
         } else {
             const dim3 g(div_up(ow, 64), div_up(oh, 4), F * N * 3);
-            if (l == 0) k_down<uint8_t><<<g, blk, 0, st>>>(vt, N, l, g0, c->g0_stride, gl, c->gl_stride);
-            else        k_down<int16_t><<<g, blk, 0, st>>>(vt, N, l, gl, c->gl_stride, gl, c->gl_stride);
+            if (l == 0) k_down<<<g, blk, 0, st>>>(vt, N, l, g0, c->g0_stride, gl, c->gl_stride);
+            else        k_down<<<g, blk, 0, st>>>(vt, N, l, gl, c->gl_stride, gl, c->gl_stride);
         }
         MS_LAUNCH_CHECK();
         if (int e = mark(down_names[l])) return e;

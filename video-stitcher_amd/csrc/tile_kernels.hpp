@@ -645,48 +645,26 @@ __device__ __forceinline__ Down7 down_row(const Row11u8 &o, int t, int w)
     if (8 * t + 8 >= w) r.a[3] = r.a[2] >> 16;              // column w mirrors to w-2: E5 = E4
     return r;
 }
-// int16 row, window elements 8t-2 .. 8t+9 in natural pairs: a_i = (v_{2i}, v_{2i+1}) = (E_i, O_i), i = 0..5 (a6 unused)
-__device__ __forceinline__ Down7 down_row(const Row11s16 &o, int t, int w)
-{
-    Down7 r;
-    r.a[0] = o.b.x; r.a[1] = o.b.y; r.a[2] = o.b.z; r.a[3] = o.b.w; r.a[4] = o.c.x; r.a[5] = o.c.y; r.a[6] = 0u;
-    if (t == 0) {                     // window starts at column 0
-        r.a[5] = r.a[4]; r.a[4] = r.a[3]; r.a[3] = r.a[2]; r.a[2] = r.a[1]; r.a[1] = r.a[0];
-        r.a[0] = __builtin_amdgcn_perm(r.a[1], r.a[2], 0x07060100u);      // (col 2, col 1)
-    }
-    if (8 * t + 8 >= w) r.a[5] = r.a[4];                    // E5 = E4
-    return r;
-}
 __device__ __forceinline__ unsigned rne8_pk(unsigned s)
 {
     const unsigned t = (s >> 8) & 0x00010001u;
     return ((s + t + 0x007f007fu) >> 8) & 0x00ff00ffu;
 }
-// horizontal pass on a vertical sum; returns (out0,out1) and (out2,out3) as int16 pairs
-template <typename TIN>
-__device__ __forceinline__ uint2 down_hpass(const Down7 &v)
+// horizontal pass on a vertical sum; returns the four outputs as bytes of one dword (each is <= 255)
+__device__ __forceinline__ unsigned down_hpass(const Down7 &v)
 {
-    unsigned e01, e12, e23, e34, e45, o01, o12, o23, o34;
-    if (sizeof(TIN) == 1) {
-        e01 = __builtin_amdgcn_alignbyte(v.a[1], v.a[0], 2); e12 = v.a[1]; e23 = __builtin_amdgcn_alignbyte(v.a[2], v.a[1], 2);
-        e34 = v.a[2]; e45 = __builtin_amdgcn_alignbyte(v.a[3], v.a[2], 2);
-        o01 = __builtin_amdgcn_alignbyte(v.a[5], v.a[4], 2); o12 = v.a[5]; o23 = __builtin_amdgcn_alignbyte(v.a[6], v.a[5], 2); o34 = v.a[6];
-    } else {
-        e01 = __builtin_amdgcn_perm(v.a[1], v.a[0], 0x05040100u); e12 = __builtin_amdgcn_perm(v.a[2], v.a[1], 0x05040100u);
-        e23 = __builtin_amdgcn_perm(v.a[3], v.a[2], 0x05040100u); e34 = __builtin_amdgcn_perm(v.a[4], v.a[3], 0x05040100u);
-        e45 = __builtin_amdgcn_perm(v.a[5], v.a[4], 0x05040100u);
-        o01 = __builtin_amdgcn_perm(v.a[1], v.a[0], 0x07060302u); o12 = __builtin_amdgcn_perm(v.a[2], v.a[1], 0x07060302u);
-        o23 = __builtin_amdgcn_perm(v.a[3], v.a[2], 0x07060302u); o34 = __builtin_amdgcn_perm(v.a[4], v.a[3], 0x07060302u);
-    }
+    const unsigned e01 = __builtin_amdgcn_alignbyte(v.a[1], v.a[0], 2), e12 = v.a[1], e23 = __builtin_amdgcn_alignbyte(v.a[2], v.a[1], 2);
+    const unsigned e34 = v.a[2], e45 = __builtin_amdgcn_alignbyte(v.a[3], v.a[2], 2);
+    const unsigned o01 = __builtin_amdgcn_alignbyte(v.a[5], v.a[4], 2), o12 = v.a[5], o23 = __builtin_amdgcn_alignbyte(v.a[6], v.a[5], 2), o34 = v.a[6];
     const unsigned s01 = mad6(e12, e01 + e23 + 4u * (o01 + o12));
     const unsigned s23 = mad6(e34, e23 + e45 + 4u * (o23 + o34));
-    return make_uint2(rne8_pk(s01), rne8_pk(s23));
+    return __builtin_amdgcn_perm(rne8_pk(s23), rne8_pk(s01), 0x06040200u);
 }
 
-template <typename TIN>
+// Input and output are both byte planes (level 0 = the gained warp output, levels >= 1 = the view's Gaussian levels: all in [0, 255]).
 __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int l,
-                                                const TIN *__restrict__ gin, long long in_stride,
-                                                int16_t *__restrict__ gout, long long out_stride)
+                                                const uint8_t *__restrict__ gin, long long in_stride,
+                                                uint8_t *__restrict__ gout, long long out_stride)
 {
     const DownTile T = tiles[blockIdx.x];
     const int c = blockIdx.y, f = blockIdx.z, v = T.view;
@@ -695,7 +673,7 @@ __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ til
     const int t = (T.x0 >> 2) + (int)threadIdx.x;
     const int y = T.y0 + RO * (int)threadIdx.y;
     if (4 * t >= Lo.w || y >= Lo.h) return;
-    const TIN *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
+    const uint8_t *in = gin + (size_t)f * in_stride + Li.off + (size_t)c * Li.h * Li.pitch;
     const int nrow = min(RO, Lo.h - y);                     // valid output rows of this lane
     const int sy = 2 * y, last = Li.h - 1;
     int ridx[RI];
@@ -704,19 +682,19 @@ __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ til
     for (int j = 3; j < RI; ++j) { const int r = sy + j - 2; ridx[j] = r > last ? 2 * last - r : r; }
 #pragma unroll
     for (int j = 5; j < RI; ++j) if (j > 2 * nrow + 2) ridx[j] = ridx[4];      // rows only the missing outputs would read: any valid row
-    typename Row11<TIN>::type raw[RI];
+    Row11u8 raw[RI];
 #pragma unroll
     for (int j = 0; j < RI; ++j) raw[j] = fetch_row11(in + (size_t)ridx[j] * Li.pitch, t, Li.w);
     Down7 r[RI];
 #pragma unroll
     for (int j = 0; j < RI; ++j) r[j] = down_row(raw[j], t, Li.w);
-    int16_t *out = gout + (size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + 4 * t;
+    uint8_t *out = gout + (size_t)f * out_stride + Lo.off + (size_t)c * Lo.h * Lo.pitch + (size_t)y * Lo.pitch + 4 * t;
 #pragma unroll
     for (int o = 0; o < RO; ++o) {                          // vertical 1 4 6 4 1 of input rows 2o .. 2o+4
         Down7 vv;
 #pragma unroll
         for (int k = 0; k < 7; ++k) vv.a[k] = mad6(r[2 * o + 2].a[k], (r[2 * o].a[k] + r[2 * o + 4].a[k]) + 4u * (r[2 * o + 1].a[k] + r[2 * o + 3].a[k]));
-        if (o < nrow) *reinterpret_cast<uint2 *>(out + (size_t)o * Lo.pitch) = down_hpass<TIN>(vv);
+        if (o < nrow) *reinterpret_cast<unsigned *>(out + (size_t)o * Lo.pitch) = down_hpass(vv);
     }
 }
 
