@@ -1,0 +1,24 @@
+#!/usr/bin/env bash
+# Run ON THE GPU BOX (through gpurun): everything profiles/<tag>_* is made of, in dependency order.
+#   gpurun --timeout 2400 -- 'bash tools/collect_round.sh r02'
+# 1. bench.py default + the other configurations      -> <tag>_bench.json, <tag>_other_configs.json
+# 2. SQ / TCC / LDS counter passes, cfg2 and cfg3     -> <tag>_counters.txt, <tag>_cfg3_counters.txt
+# 3. kernel trace + FETCH/WRITE PMC passes, cfg3 then cfg2 (traffic_latest.json = cfg2, the bench default) + the per-kernel report
+# 4. live-path timeline (one frame per call)          -> <tag>_live_timeline.json
+# Everything lands in gpurun_out/profiles_out/ (gpurun merges only gpurun_out/ back): copy into profiles/ and commit.
+set -uo pipefail
+TAG=${1:-r02}
+cd "$GRAFT_REPO_ROOT"
+PO=gpurun_out/profiles_out; mkdir -p $PO
+bash tools/refresh_profiles.sh $TAG > $PO/refresh.log 2>&1
+cp gpurun_out/refresh/${TAG}_bench.json gpurun_out/refresh/${TAG}_other_configs.json profiles/ 2>/dev/null
+bash tools/profile_counters.sh $TAG cfg2 16 > $PO/counters.log 2>&1
+cp gpurun_out/counters_$TAG.txt profiles/${TAG}_counters.txt
+bash tools/profile_counters.sh ${TAG}_cfg3 cfg3 16 > $PO/counters_cfg3.log 2>&1
+cp gpurun_out/counters_${TAG}_cfg3.txt profiles/${TAG}_cfg3_counters.txt
+bash tools/profile_traffic.sh ${TAG}_cfg3 cfg3 16 > $PO/traffic_cfg3.log 2>&1
+bash tools/profile_traffic.sh $TAG cfg2 16 > $PO/traffic.log 2>&1
+python tools/report.py $TAG > $PO/report.log 2>&1
+bash tools/live_timeline.sh $TAG > /dev/null 2>&1
+cp profiles/${TAG}_* profiles/traffic_latest.json $PO/ 2>/dev/null
+du -sh gpurun_out; ls $PO

@@ -10,8 +10,9 @@ B="python bench.py --steps 12 --warmup 3 --no-live --no-pcie --no-verify --no-cp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $B > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $B > $OUT/bench_write.log 2>&1
-python bench.py --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err || true
 python tools/summarize_traffic.py $OUT $TAG $CFG $F
+# the plain bench line of this configuration, run AFTER the summary so that its roofline.traffic reads this pass's traffic_latest.json
+python bench.py --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err && cp $OUT/bench_plain.json profiles/${TAG}_bench.json || true
 # gpurun only merges gpurun_out/ back: park the summaries there (copy them into profiles/ and commit)
 python tools/report.py $TAG > /dev/null 2>&1 || true
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/traffic_latest.json gpurun_out/profiles_out/

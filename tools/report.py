@@ -40,7 +40,7 @@ def main(tag):
     clk = 2.33e9
     rows = []
     for k, v in traffic["kernels"].items():
-        if k in ("k_warp", "k_blend_l0", "k_down_l0") or v["launches"] < 20 or "calib" in k or not k.startswith(("k_warp_t", "k_blend", "k_down", "k_stage1", "k_remap", "k_single")):      # (aliases, calibration-time kernels)
+        if k in ("k_warp", "k_blend_l0", "k_down_l0", "k_remap_gain") or v["launches"] < 20 or "calib" in k or not k.startswith(("k_warp_t", "k_blend", "k_down", "k_stage1", "k_remap", "k_single")):      # (aliases, calibration-time kernels)
             continue
         c = next((d for n, d in ctr.items() if short(n) == k), {})
         waves = c.get("SQ_WAVES", 0)

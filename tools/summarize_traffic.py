@@ -44,7 +44,7 @@ def main(out, tag, cfg, frames):
     names = {"k_warp": "k_warp_t<false>", "k_remap_gain": "k_remap_gain"}
     order = sorted(set(fetch) | set(write))
     for k in order:
-        if "ms::" not in k or "calib" in k:
+        if "ms::" not in k or "calib" in k or not short(k):
             continue
         fr = fetch.get(k, (0, 0, 0)); wr = write.get(k, (0, 0, 0))
         res["kernels"][short(k)] = {"fetch_KB_raw": fr[0], "write_KB_raw": wr[0], "launches": fr[1], "mean_ns": fr[2],
@@ -56,7 +56,9 @@ def main(out, tag, cfg, frames):
             alias["k_warp"] = v
         if k.startswith("k_blend8<true, 0>") or k.startswith("k_blend8<true>"):
             alias["k_blend_l0"] = v
-        if k.startswith("k_down_t<unsigned char>"):
+        if k.startswith("k_stage1_t"):
+            alias["k_remap_gain"] = v          # bench.py's name of the first CPW remap (timed.cpp:90-94)
+        if k.startswith("k_down_t<unsigned char>") or k.startswith("k_down_t<true>"):
             alias["k_down_l0"] = v
     res["kernels"].update(alias)
     # HBM bytes of one ms_stitch call (all per-frame kernels): what bench.py's frame_roofline.frac_traffic divides by the GPU time
@@ -64,14 +66,11 @@ def main(out, tag, cfg, frames):
                  "k_blend<", "k_blend_top", "k_single_band")
     steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t", "k_warp_a", "k_warp<"))] or [1])
     res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()
-                                        if k.startswith(per_frame) and k not in alias))
+                                        if (k.startswith(per_frame) or k == "k_down") and k not in alias))
     res["calls"] = steps
     path = os.path.join(prof, "%s_traffic.json" % tag)
     json.dump(res, open(path, "w"), indent=1, sort_keys=True)
     shutil.copyfile(path, os.path.join(prof, "traffic_latest.json"))
-    bp = os.path.join(out, "bench_plain.json")
-    if os.path.exists(bp) and os.path.getsize(bp) > 10:
-        shutil.copyfile(bp, os.path.join(prof, "%s_bench.json" % tag))
     print(json.dumps(res["calibration"]))
     for k in ("k_warp", "k_down_l0", "k_blend_l0"):
         if k in res["kernels"]:

@@ -2543,8 +2543,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
         if (c->down_vec[l] && c->cfg.debug_simple_kernels == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
-            if (l == 0) k_down_t<<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
-            else        k_down_t<<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
+            if (l == 0) k_down_t<true><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
+            else        k_down_t<false><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
         } else {
             const dim3 g(div_up(ow, 64), div_up(oh, 4), F * N * 3);
             if (l == 0) k_down<<<g, blk, 0, st>>>(vt, N, l, g0, c->g0_stride, gl, c->gl_stride);
@@ -2573,7 +2573,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else K<L0, 2><<<G, B, 0, st>>>(__VA_ARGS__);                    \
     } while (0)
     int l_first = nb - 1;
-    const bool bt2 = F <= 2 && c->btail2_t >= 0;      // live mode (1-2 frames per call): launches dominate, the band tail starts one band finer
+    static const bool bt2_off = [] { const char *e = getenv("MS_LIVE_TAIL"); return e && atoi(e) == 0; }();
+    const bool bt2 = F <= 2 && c->btail2_t >= 0 && !bt2_off;      // live mode (1-2 frames per call): launches dominate, the band tail starts one band finer
     const int bt_t = bt2 ? c->btail2_t : c->btail_t, bt_lds = bt2 ? c->btail2_lds : c->btail_lds, bt_strips = bt2 ? c->btail2_strips : c->btail_strips;
     if (S.mode == 0 && bt_t >= 0) {      // bands nb .. bt_t in one launch
         k_blend_tail<<<dim3(bt_strips, 3, F), blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride);

@@ -662,6 +662,8 @@ __device__ __forceinline__ unsigned down_hpass(const Down7 &v)
 }
 
 // Input and output are both byte planes (level 0 = the gained warp output, levels >= 1 = the view's Gaussian levels: all in [0, 255]).
+// L0 only names the launch (level 0 vs the coarser levels) so that kernel traces tell them apart; the code is the same.
+template <bool L0>
 __global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int l,
                                                 const uint8_t *__restrict__ gin, long long in_stride,
                                                 uint8_t *__restrict__ gout, long long out_stride)
