@@ -663,6 +663,13 @@ __device__ __forceinline__ unsigned sub_pk_u16(unsigned a, unsigned b)      // v
     __builtin_memcpy(&a, &x, 4);
     return a;
 }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(unsigned a) { s16x2 x; __builtin_memcpy(&x, &a, 4); return x; }
+__device__ __forceinline__ unsigned as_u32(s16x2 x) { unsigned a; __builtin_memcpy(&a, &x, 4); return a; }
+// v_pk_add_i16 clamp / v_pk_min_i16 / v_pk_max_i16: two int16 per register; the saturating add is add + saturate_cast<short> per half
+__device__ __forceinline__ unsigned addsat_pk_i16(unsigned a, unsigned b) { return as_u32(__builtin_elementwise_add_sat(as_s16x2(a), as_s16x2(b))); }
+__device__ __forceinline__ unsigned min_pk_i16(unsigned a, unsigned b) { return as_u32(__builtin_elementwise_min(as_s16x2(a), as_s16x2(b))); }
+__device__ __forceinline__ unsigned max_pk_i16(unsigned a, unsigned b) { return as_u32(__builtin_elementwise_max(as_s16x2(a), as_s16x2(b))); }
 constexpr int UP_BIAS = 384;
 __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
 {
@@ -838,42 +845,50 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int k = 0; k < 8; ++k) rcp[r][k] = owner == 255 ? DivBy(den[r][k]).r : 1.f;
-    unsigned resp[3][2][4];               // results as int16 pairs, natural pixel order (px 2j, 2j+1): half the registers of 48 ints
+    // Results as int16 pairs in the accumulators' pixel order (register q of a row holds px (0,2) (1,3) (4,6) (5,7)): normalise, collapse and the
+    // output conversion stay packed (v_pk_*_i16), two pixels per instruction.
+    unsigned resq[3][2][4];
     uint4 ccraw[2][3];                    // the three planes of the collapsed coarser level are pipelined like the view planes above
     up_rows_load(cc, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[0]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (c + 1 < 3) up_rows_load(cc + (c + 1) * cplane, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[(c + 1) & 1]);
-        int up[2][8];
-        unsigned upk[2][4];
-        if (up_2x8_pkb(ccraw[c & 1], P.qw[l + 1], x0 >> 1, upk[0], upk[1])) {
+        unsigned upq[2][4];               // pyrUp of the collapsed coarser band (its values fit int16: the reference's saturate_cast<short> is the identity)
+        if (up_2x8_pkb(ccraw[c & 1], P.qw[l + 1], x0 >> 1, upq[0], upq[1])) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {           // pixel order (0,2) (1,3) (4,6) (5,7)
-                    const int k0 = (q >> 1) * 4 + (q & 1);
-                    up[r][k0] = (int)(upk[r][q] & 0xffffu) - UP_BIAS;
-                    up[r][k0 + 2] = (int)(upk[r][q] >> 16) - UP_BIAS;
-                }
+                for (int q = 0; q < 4; ++q) upq[r][q] = sub_pk_u16(upq[r][q], (unsigned)UP_BIAS * 0x00010001u);
         } else {
+            int up[2][8];
             up_2x8(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, up[0], up[1]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = (q >> 1) * 4 + (q & 1);
+                    upq[r][q] = ((unsigned)up[r][k0] & 0xffffu) | ((unsigned)up[r][k0 + 2] << 16);
+                }
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {   // int16 accumulation wraps: (short)(sum) == successive `short +=`
-                DivBy dv(1.f); dv.d = den[r][k]; dv.r = rcp[r][k];
-                const unsigned ap = accp[c][r][(k >> 2) * 2 + (k & 1)];          // pixel k lives in register (k/4)*2 + (k&1), half (k>>1)&1
-                const int a = ((k >> 1) & 1) ? ((int)ap >> 16) : (int)(int16_t)(ap & 0xffffu);
-                // owner cells: a / 1.00001f for an integer |a| <= 255 lies strictly between a - sign(a) and a, further than half an ulp from a,
-                // so the correctly rounded quotient truncates to a - sign(a): the division is an integer subtraction there
-                up[r][k] = owner != 255 ? sat_s16(up[r][k] + (a - min(max(a, -1), 1)))
-                                        : sat_s16(up[r][k] + (int)trunc_s16(dv((float)a)));        // (the result replaces the expanded coarser level)
+            for (int q = 0; q < 4; ++q) {   // int16 accumulation wraps: (short)(sum) == successive `short +=`
+                const unsigned a = accp[c][r][q];
+                unsigned n;
+                if (owner != 255) {
+                    // owner cells: a / 1.00001f for an integer |a| <= 255 lies strictly between a - sign(a) and a, further than half an ulp from a,
+                    // so the correctly rounded quotient truncates to a - sign(a): the division is an integer subtraction there
+                    n = sub_pk_u16(a, min_pk_i16(max_pk_i16(a, 0xffffffffu), 0x00010001u));
+                } else {
+                    const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
+                    DivBy d0(1.f), d1(1.f);
+                    d0.d = den[r][k0]; d0.r = rcp[r][k0]; d1.d = den[r][k1]; d1.r = rcp[r][k1];
+                    const int n0 = trunc_s16(d0((float)(int)(int16_t)(a & 0xffffu))), n1 = trunc_s16(d1((float)((int)a >> 16)));
+                    n = ((unsigned)n0 & 0xffffu) | ((unsigned)n1 << 16);
+                }
+                resq[c][r][q] = addsat_pk_i16(upq[r][q], n);          // add(pyrUp, band) with saturate_cast<short> (the result replaces the expanded coarser level)
             }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) resp[c][r][j] = ((unsigned)up[r][2 * j] & 0xffffu) | ((unsigned)up[r][2 * j + 1] << 16);
     }
 
     if (!L0) {
@@ -883,7 +898,12 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                *reinterpret_cast<uint4 *>(d + c * plane + (size_t)r * P.qpitch[l]) = make_uint4(resp[c][r][0], resp[c][r][1], resp[c][r][2], resp[c][r][3]);
+                uint4 o;                      // back to natural pixel order
+                o.x = __builtin_amdgcn_perm(resq[c][r][1], resq[c][r][0], 0x05040100u);   // px 0, 1
+                o.y = __builtin_amdgcn_perm(resq[c][r][1], resq[c][r][0], 0x07060302u);   // px 2, 3
+                o.z = __builtin_amdgcn_perm(resq[c][r][3], resq[c][r][2], 0x05040100u);   // px 4, 5
+                o.w = __builtin_amdgcn_perm(resq[c][r][3], resq[c][r][2], 0x07060302u);   // px 6, 7
+                *reinterpret_cast<uint4 *>(d + c * plane + (size_t)r * P.qpitch[l]) = o;
             }
     } else {
 #pragma unroll
@@ -891,32 +911,59 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
             const int y = y0 + r;
             if (y >= P.fh) continue;
             const uint8_t *mrow = P.mask + mul24(y, P.mask_pitch);
-            int px[8][3];
             const int nvalid = min(8, P.fw - x0);
-            int mk[8];
-            if (nvalid == 8) unpack8(load8_a1(mrow + x0), mk);
+            uint2 mk8 = make_uint2(0u, 0u);                 // result mask of the 8 pixels: bytes 0 / 255 (k_finish_den)
+            if (nvalid == 8) mk8 = load8_a1(mrow + x0);
             else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) mk[k] = (k < nvalid) ? (int)mrow[x0 + k] : 0;
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned m = (k < nvalid) ? (unsigned)mrow[x0 + k] : 0u;
+                    if (k < 4) mk8.x |= m << (8 * k); else mk8.y |= m << (8 * (k - 4));
+                }
             }
+            // setTo(0, mask == 0) (blenders.cpp:803-810): 0xffff / 0 per half, in the registers' pixel order
+            const unsigned mq[4] = {__builtin_amdgcn_perm(0u, mk8.x, 0x02020000u), __builtin_amdgcn_perm(0u, mk8.x, 0x03030101u),
+                                    __builtin_amdgcn_perm(0u, mk8.y, 0x02020000u), __builtin_amdgcn_perm(0u, mk8.y, 0x03030101u)};
+            unsigned v[3][4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool m = mk[k] != 0;
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) px[k][c] = m ? ((k & 1) ? ((int)resp[c][r][k >> 1] >> 16) : (int)(int16_t)(resp[c][r][k >> 1] & 0xffffu)) : 0;
-            }
+                for (int q = 0; q < 4; ++q) v[c][q] = resq[c][r][q] & mq[q];
+            // pixel k of the row: register (k / 4) * 2 + (k & 1), half (k >> 1) & 1
+            auto val = [&](int k, int c) -> int {
+                const unsigned w = v[c][(k >> 2) * 2 + (k & 1)];
+                return ((k >> 1) & 1) ? ((int)w >> 16) : (int)(int16_t)(w & 0xffffu);
+            };
             if (out.p16[f]) {
                 int16_t *d = (int16_t *)((char *)out.p16[f] + mul24(y, (int)out.step16[f])) + 3 * x0;
                 if (nvalid == 8) {
                     unsigned wds[12];
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        const int e0 = 2 * i, e1 = 2 * i + 1;
-                        wds[i] = (unsigned)(uint16_t)px[e0 / 3][e0 % 3] | ((unsigned)(uint16_t)px[e1 / 3][e1 % 3] << 16);
+                    for (int i = 0; i < 12; ++i) {        // interleaved int16 triplets: elements 2i, 2i+1 of the 24
+                        const int e0 = 2 * i, e1 = 2 * i + 1, ka = e0 / 3, kb = e1 / 3;
+                        const unsigned sel = (((ka >> 1) & 1) ? 0x0302u : 0x0100u) | ((((kb >> 1) & 1) ? 0x0706u : 0x0504u) << 16);
+                        wds[i] = __builtin_amdgcn_perm(v[e1 % 3][(kb >> 2) * 2 + (kb & 1)], v[e0 % 3][(ka >> 2) * 2 + (ka & 1)], sel);
                     }
                     __builtin_memcpy(d, wds, 48);
                 } else {
-                    for (int k = 0; k < nvalid; ++k) { d[3 * k] = (int16_t)px[k][0]; d[3 * k + 1] = (int16_t)px[k][1]; d[3 * k + 2] = (int16_t)px[k][2]; }
+                    for (int k = 0; k < nvalid; ++k) { d[3 * k] = (int16_t)val(k, 0); d[3 * k + 1] = (int16_t)val(k, 1); d[3 * k + 2] = (int16_t)val(k, 2); }
+                }
+            }
+            if (!out.p8[f] && !out.pi[f]) continue;
+            // convertTo(CV_8U) (timed.cpp:251): clamp to [0, 255] per half, then one dword [B, G, R, 0] per pixel
+            unsigned px4[8];
+            {
+                unsigned bg[4], rr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned cb = min_pk_i16(max_pk_i16(v[0][q], 0u), 0x00ff00ffu), cg = min_pk_i16(max_pk_i16(v[1][q], 0u), 0x00ff00ffu);
+                    rr[q] = min_pk_i16(max_pk_i16(v[2][q], 0u), 0x00ff00ffu);
+                    bg[q] = cb | (cg << 8);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = (k >> 2) * 2 + (k & 1);
+                    px4[k] = __builtin_amdgcn_perm(rr[q], bg[q], ((k >> 1) & 1) ? 0x0c060302u : 0x0c040100u);
                 }
             }
             if (out.p8[f]) {
@@ -926,22 +973,17 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                     if (nvalid == 8 && cx0 >= 0 && cx0 + 8 <= P.out_w) {
                         unsigned wds[6];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            unsigned wv = 0;
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int e = 4 * i + b;
-                                wv |= (unsigned)min(max(px[e / 3][e % 3], 0), 255) << (8 * b);
-                            }
-                            wds[i] = wv;
+                        for (int h = 0; h < 2; ++h) {       // 4 pixels -> 12 bytes
+                            wds[3 * h + 0] = __builtin_amdgcn_perm(px4[4 * h + 1], px4[4 * h + 0], 0x04020100u);
+                            wds[3 * h + 1] = __builtin_amdgcn_perm(px4[4 * h + 2], px4[4 * h + 1], 0x05040201u);
+                            wds[3 * h + 2] = __builtin_amdgcn_perm(px4[4 * h + 3], px4[4 * h + 2], 0x06050402u);
                         }
                         __builtin_memcpy(d, wds, 24);
                     } else {
                         for (int k = 0; k < nvalid; ++k) {
                             const int cx = cx0 + k;
                             if (cx < 0 || cx >= P.out_w) continue;
-                            d[3 * k] = (uint8_t)min(max(px[k][0], 0), 255); d[3 * k + 1] = (uint8_t)min(max(px[k][1], 0), 255);
-                            d[3 * k + 2] = (uint8_t)min(max(px[k][2], 0), 255);
+                            d[3 * k] = (uint8_t)(px4[k] & 0xffu); d[3 * k + 1] = (uint8_t)((px4[k] >> 8) & 0xffu); d[3 * k + 2] = (uint8_t)((px4[k] >> 16) & 0xffu);
                         }
                     }
                 }
@@ -957,7 +999,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
                     uint8_t yv[8], uv[8], vv[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const int b = min(max(px[k][0], 0), 255), g = min(max(px[k][1], 0), 255), rr = min(max(px[k][2], 0), 255);
+                        const int b = (int)(px4[k] & 0xffu), g = (int)((px4[k] >> 8) & 0xffu), rr = (int)((px4[k] >> 16) & 0xffu);
                         yv[k] = (uint8_t)min(max((CRY * rr + CGY * g + CBY * b + HALF + (16 << SH)) >> SH, 0), 255);
                         uv[k] = (uint8_t)min(max((CRU * rr + CGU * g + CBU * b + HALF + (128 << SH)) >> SH, 0), 255);
                         vv[k] = (uint8_t)min(max((CBU * rr + CGV * g + CBV * b + HALF + (128 << SH)) >> SH, 0), 255);
