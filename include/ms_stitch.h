@@ -229,7 +229,13 @@ typedef struct ms_config {
     int debug_simple_kernels;    /* != 0: the one-pixel-per-lane reference kernels instead of the tiled ones      */
     int warp_lds_stage;          /* 0: direct tap gathers (default); 1: source tiles staged in LDS by LDS-DMA (k_warp_a, measured slower on config 2); 2: never stage */
     int raster_tile_order;       /* != 0: work lists in raster order instead of the XCD-aware order               */
-    int reserved[4];             /* must be 0 */
+    /* Pano-column sharding (the alternative to view sharding): S = 2..16 contexts -- one per GPU -- each composite the columns
+     * [ms_get_col_window) of the panorama ROI, bit-identical there to an unsharded context.  The work lists are cut down to what those columns depend on
+     * (their own pixels plus <= 3 * 2^num_bands columns of halo on either side, recomputed); views that do not reach the window are never read
+     * (their ms_image may be all-zero).  Output pixels outside the window are unspecified.  0 / 1 = the whole panorama. */
+    int col_shards;
+    int col_shard_index;         /* which shard, 0 .. S-1 */
+    int reserved[2];             /* must be 0 */
 } ms_config;
 
 MS_API int ms_create(const ms_config *cfg, ms_ctx **out);
@@ -431,6 +437,12 @@ MS_API int ms_get_mesh_maps(const ms_ctx *ctx, int view, ms_image *xmesh, ms_ima
  * Needs the tiled band path (>= 1 band, panorama width a multiple of 8, no view sharding); MS_ERR_UNSUPPORTED otherwise. */
 MS_API int ms_stitch_i420(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out_i420, ms_stream stream);
 MS_API int ms_get_i420_rows(const ms_ctx *ctx, int *first_canvas_row, int *rows);
+/* Pano-column sharding: the columns [*begin, *end) of the panorama ROI (= canvas columns [*begin + canvas_x, *end + canvas_x), ms_get_pano_geom) this
+ * context composites; the whole ROI for an unsharded context.  Shard boundaries are multiples of 16 columns.  Valid after ms_init_blender. */
+MS_API int ms_get_col_window(const ms_ctx *ctx, int *begin, int *end);
+/* Bit v set = ms_stitch reads view v (always all views of an unsharded context; a column shard reads only the views that reach its window plus
+ * halo; a view shard only the views it owns): the caller need not upload the others and may pass an all-zero ms_image for them. */
+MS_API int ms_get_needed_views(const ms_ctx *ctx, unsigned *mask);
 
 /* per-kernel GPU time of the last ms_stitch_timed call (hipEvents on `stream`), for bench.py's roofline.
  * names/ms: arrays of `cap` entries; returns the number of kernels recorded. */

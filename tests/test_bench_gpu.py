@@ -61,3 +61,29 @@ def test_view_sharded_ranks_exchange_partials_and_match_the_unsharded_frame():
     d = last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["equals_unsharded"] is True and d["value"] > 0
     assert ("RCCL" in d["config"]["workload"]) == two
+
+
+def test_column_sharded_ranks_exchange_slabs_and_match_the_unsharded_frame():
+    """SURVEY 8(e) pano-column split across two RANKS: each composites one half of the panorama's columns (its work lists and uploads cut down to that
+    window plus halo), rank 1's finished column slab travels to rank 0, which assembles the canvas and compares it with an unsharded stitch of the same
+    frames.  With two GPUs: RCCL; on a one-GPU box the ranks share the GPU and the slabs go through gloo."""
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ) if two else dict(os.environ, MS_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        "bench.py", "--gpus", "2", "--col-shards", "2", "--frames", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["equals_unsharded"] is True and d["value"] > 0
+    assert ("RCCL" in d["config"]["workload"]) == two
+
+
+def test_column_shards_on_one_gpu_config5():
+    """BASELINE configs[4] geometry (12 x 4K -> 7680 x 3840), two column windows on one GPU: equal to the unsharded frame, and each shard reads a strict
+    subset of the views (the ingest is what the split divides)."""
+    p = subprocess.run([sys.executable, "bench.py", "--config", "cfg5", "--col-shards", "2", "--frames", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = last_json(p.stdout)
+    assert d["equals_unsharded"] is True and all(v < d["config"]["views"] for v in d["config"]["views_read_per_shard"]), d

@@ -277,6 +277,66 @@ def test_view_sharding_equals_single_context(ms, cuda, rig, shards):
     full.close()
 
 
+@pytest.mark.parametrize("rig,shards,cpw", [("mini6", 2, False), ("mini6", 3, True), ("mini4", 2, False), ("cfg2", 4, False), ("cfg3", 2, True), ("cfg5", 2, False)])
+def test_column_sharding_equals_single_context(ms, cuda, rig, shards, cpw):
+    """SURVEY 8(e), pano-column split: S contexts, each compositing a window of panorama columns from work lists cut down to that window plus
+    its halo; every window must equal the unsharded frame bit for bit (16S ROI, 8U canvas, I420), the windows must tile the panorama, and a
+    shard must not even look at the views that do not reach its window (they are handed over as None)."""
+    name = "cfg2" if rig == "cfg3" else rig
+    full, cfg, _ = make_rig(ms, name, max_frames=2, enable_cpw=cpw)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(2)]
+    meshes = None
+    if cpw:
+        meshes = [synth.mesh(full.view_geom(i).roi.width, full.view_geom(i).roi.height, 12, 9, phase=0.3 * i, amp=6.0) for i in range(cfg["n"])]
+        for i, (mx, my) in enumerate(meshes):
+            full.set_mesh(i, mx, my)
+    pg = full.pano_geom()
+    fw, fh = pg.dst_roi_final.width, pg.dst_roi_final.height
+    want16 = [torch.zeros((fh, fw, 3), dtype=torch.int16, device=cuda) for _ in range(2)]
+    want8 = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda) for _ in range(2)]
+    full.stitch(frames, out8u=want8, out16s=want16)
+    wanti = full.new_i420(2)
+    full.stitch_i420(frames, wanti)
+    assert full.col_window() == (0, fw) and full.needed_views() == (1 << cfg["n"]) - 1
+    y0, rows = full.i420_rows()
+    W = cfg["out_w"]
+    edges, read = [], 0
+    for k in range(shards):
+        c, _, _ = make_rig(ms, name, max_frames=2, enable_cpw=cpw, col_shards=shards, col_shard_index=k)
+        if cpw:
+            for i, (mx, my) in enumerate(meshes):
+                c.set_mesh(i, mx, my)
+        b, e = c.col_window()
+        edges.append((b, e))
+        need = c.needed_views()
+        read += bin(need).count("1")
+        mine = [[fr[v] if (need >> v) & 1 else None for v in range(cfg["n"])] for fr in frames]
+        got16 = [torch.full((fh, fw, 3), -7, dtype=torch.int16, device=cuda) for _ in range(2)]
+        got8 = [torch.full((cfg["out_h"], cfg["out_w"], 3), 9, dtype=torch.uint8, device=cuda) for _ in range(2)]
+        c.stitch(mine, out8u=got8, out16s=got16)
+        goti = c.new_i420(2)
+        c.stitch_i420(mine, goti)
+        torch.cuda.synchronize()
+        cb, ce = b + pg.canvas_x, e + pg.canvas_x
+        for t in range(2):
+            assert torch.equal(got16[t][:, b:e], want16[t][:, b:e]), "16S window of shard %d" % k
+            r0, r1 = max(pg.canvas_y, 0), min(pg.canvas_y + fh, cfg["out_h"])          # (canvas rows outside the panorama ROI are never written)
+            assert torch.equal(got8[t][r0:r1, max(cb, 0):ce], want8[t][r0:r1, max(cb, 0):ce]), "8U window of shard %d" % k
+            gi, wi = goti[t].view(-1), wanti[t].view(-1)
+            Y = lambda a: a[:W * rows].view(rows, W)
+            U = lambda a: a[W * rows:W * rows + (W // 2) * (rows // 2)].view(rows // 2, W // 2)
+            V = lambda a: a[W * rows + (W // 2) * (rows // 2):].view(rows // 2, W // 2)
+            assert torch.equal(Y(gi)[:, max(cb, 0):ce], Y(wi)[:, max(cb, 0):ce])
+            lo, hi = (max(cb, 0) + 1) // 2, ce // 2            # chroma samples whose 2 x 2 block starts inside the window
+            assert torch.equal(U(gi)[:, lo:hi], U(wi)[:, lo:hi]) and torch.equal(V(gi)[:, lo:hi], V(wi)[:, lo:hi])
+        c.close()
+    assert edges[0][0] == 0 and edges[-1][1] == fw and all(edges[i][1] == edges[i + 1][0] for i in range(shards - 1)), edges
+    assert all(b % 16 == 0 for b, _ in edges)
+    if rig in ("cfg2", "cfg5"):
+        assert read < shards * cfg["n"], "every shard read every view: the window does not cut the work lists"
+    full.close()
+
+
 def test_config1_two_views(ms, cuda, oracle):
     """BASELINE configs[0] geometry (2 views 640x480, yaw -/+25 deg, hfov 90, scale 2000/2pi; SURVEY App. C known ROIs),
     composited with the multiband path on the GPU and compared with the oracle."""

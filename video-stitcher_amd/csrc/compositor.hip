@@ -1420,6 +1420,9 @@ struct ms_ctx {
     int canvas_x = 0, canvas_y = 0;
     // view sharding (ms_config.reserved[3] = shard count S, [4] = this shard's index): contiguous blocks of views per shard
     unsigned own_mask = 0xffffffffu;
+    // pano-column sharding (ms_config.col_shards / col_shard_index): the window of pano-ROI columns this context composites and the views it reads for it
+    int col_begin = 0, col_end = 0;    // 0, 0 = whole panorama
+    unsigned needed_mask = 0xffffffffu;
     long long pacc_stride = 0;         // elements per frame of a partial-accumulator buffer
 };
 
@@ -1535,15 +1538,34 @@ static int build_plan(ms_ctx *c)
             for (int y = 0; y < L.h; ++y)
                 for (int x = 0; x < L.w; ++x) b[(size_t)y * L.w + x] = p[(size_t)y * L.wpitch + x] != 0.f;
         }
+    // Pano-column window: band l is needed on the columns R_l = [ra_l, rb_l) only, R_0 = the window, R_{l+1} = the pyrUp taps of R_l.  The needed
+    // regions below are derived from the weights restricted to R_l (Wn); the band kernels still composite whole tiles, and what a straddling tile
+    // computes outside R_l is computed from pyramid pixels nobody produced: never read by a needed pixel, like every other unplanned pixel.
+    const bool windowed = c->col_end > c->col_begin;
+    int ra[MAX_LEVELS + 1], rb[MAX_LEVELS + 1];
+    std::vector<std::vector<Bits>> Wn_store;
+    if (windowed) {
+        ra[0] = c->col_begin; rb[0] = c->col_end;
+        for (int l = 0; l < nb; ++l) { ra[l + 1] = std::max(ra[l] / 2 - 1, 0); rb[l + 1] = std::min((rb[l] + 1) / 2 + 1, c->pano.qw[l + 1]); }
+        Wn_store = W;
+        for (int v = 0; v < N; ++v)
+            for (int l = 0; l <= nb; ++l) {
+                const LevelDesc &L = c->h_views[v].lv[l];
+                for (int x = 0; x < L.w; ++x)
+                    if (x + L.x_tl < ra[l] || x + L.x_tl >= rb[l])
+                        for (int y = 0; y < L.h; ++y) Wn_store[v][l][(size_t)y * L.w + x] = 0;
+            }
+    }
+    const std::vector<std::vector<Bits>> &Wn = windowed ? Wn_store : W;
     double need0 = 0, tot0 = 0;
     for (int v = 0; v < N; ++v) {
         const ViewDesc &V = c->h_views[v];
         for (int l = nb; l >= 0; --l) {
             const LevelDesc &L = V.lv[l];
-            Bits n = W[v][l];
+            Bits n = Wn[v][l];
             if (l >= 1) {   // pyrUp taps of band l-1
                 const LevelDesc &F = V.lv[l - 1];
-                Bits u = dilate(half(W[v][l - 1], F.w, F.h), L.w, L.h, 1);
+                Bits u = dilate(half(Wn[v][l - 1], F.w, F.h), L.w, L.h, 1);
                 for (size_t i = 0; i < n.size(); ++i) n[i] |= u[i];
             }
             if (l < nb) {   // pyrDown taps of level l+1
@@ -1580,6 +1602,9 @@ static int build_plan(ms_ctx *c)
                         need0 += (double)std::min(WARP_TW, V.pw - x0) * std::min(WARP_TH, V.ph - y0);
                     }
         }
+        c->needed_mask = 0;
+        for (const WarpTile &t : tiles) c->needed_mask |= 1u << t.view;
+        if (!windowed || !c->warp_tiled) c->needed_mask = 0xffffffffu;      // (the full-grid fallback kernels touch every view)
         if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
@@ -1612,7 +1637,7 @@ static int build_plan(ms_ctx *c)
         // within CPW_DMAX + 2 of the level-0 pixels some consumer needs: those tiles carry flag bit 1, the others exit early.
         std::vector<WarpTile> tiles;
         for (int v = 0; v < N; ++v) {
-            if (!((c->own_mask >> v) & 1u)) continue;
+            if (!((c->own_mask >> v) & 1u) || !((c->needed_mask >> v) & 1u)) continue;
             const ViewDesc &V = c->h_views[v];
             Bits a((size_t)V.aw * V.ah, 0);
             for (int y = 0; y < V.ph; ++y)
@@ -1665,6 +1690,7 @@ static int build_plan(ms_ctx *c)
         if (c->blend_vec[l])
             for (int y0 = 0; y0 < c->pano.qh[l]; y0 += BLEND_TH)
                 for (int x0 = 0; x0 < c->pano.qw[l]; x0 += BLEND_TW) {
+                    if (windowed && (x0 + BLEND_TW <= ra[l] || x0 >= rb[l])) continue;       // no needed column of band l in this tile
                     unsigned m = 0;
                     for (int v = 0; v < N; ++v) {
                         const LevelDesc &L = c->h_views[v].lv[l];
@@ -1724,7 +1750,7 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     if (!cfg || !out) return fail(MS_ERR_INVALID, "ms_create: null argument");
     if (int e = require_device()) return e;
     MS_CHECK(cfg->struct_size == sizeof(ms_config), "ms_create: ms_config.struct_size is %u, this library expects %zu (header / library mismatch)", cfg->struct_size, sizeof(ms_config));
-    MS_CHECK(cfg->reserved[0] == 0 && cfg->reserved[1] == 0 && cfg->reserved[2] == 0 && cfg->reserved[3] == 0, "ms_create: ms_config.reserved must be zero");
+    MS_CHECK(cfg->reserved[0] == 0 && cfg->reserved[1] == 0, "ms_create: ms_config.reserved must be zero");
     MS_CHECK(cfg->num_views >= 1 && cfg->num_views <= MAX_VIEWS, "ms_create: num_views %d not in [1,%d]", cfg->num_views, MAX_VIEWS);
     MS_CHECK(cfg->src_width > 1 && cfg->src_height > 1, "ms_create: bad source size %dx%d", cfg->src_width, cfg->src_height);
     MS_CHECK(cfg->projection >= MS_PROJ_PLANE && cfg->projection <= MS_PROJ_SPHERICAL, "ms_create: bad projection %d", cfg->projection);
@@ -1743,6 +1769,12 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
         if (S > 4 || idx < 0 || idx >= S || S > c->N) { delete c; return fail(MS_ERR_INVALID, "ms_create: bad view-shard setting %d/%d", idx, S); }
         c->own_mask = 0;
         for (int v = idx * c->N / S; v < (idx + 1) * c->N / S; ++v) c->own_mask |= 1u << v;
+    }
+    if (cfg->col_shards > 1 && (cfg->col_shards > 16 || cfg->col_shard_index < 0 || cfg->col_shard_index >= cfg->col_shards || cfg->view_shards > 1 ||
+                                cfg->debug_simple_kernels != 0 || cfg->num_bands < 1)) {
+        delete c;
+        return fail(MS_ERR_INVALID, "ms_create: bad column-shard setting %d/%d (2..16 shards, not together with view shards or the reference kernels, num_bands >= 1)",
+                    cfg->col_shard_index, cfg->col_shards);
     }
     if (cfg->cpu_flavour_remap != 0 && (cfg->debug_simple_kernels == 0 || cfg->enable_cpw)) {
         delete c;
@@ -2207,6 +2239,13 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     }
     if (int e = c->view_tab.alloc(sizeof(ViewDesc) * N)) return e;
     MS_HIP(hipMemcpy(c->view_tab.p, c->h_views.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice));
+    c->col_begin = c->col_end = 0;
+    if (c->cfg.col_shards > 1) {      // shard k composites the pano-ROI columns [bound(k), bound(k+1)); boundaries on multiples of 16 columns
+        const int S = c->cfg.col_shards, k = c->cfg.col_shard_index, fw = c->pano.fw;
+        auto bound = [&](int i) { return i <= 0 ? 0 : (i >= S ? fw : (int)((long long)i * fw / S) / 16 * 16); };
+        c->col_begin = bound(k); c->col_end = bound(k + 1);
+        if (c->col_end <= c->col_begin) return fail(MS_ERR_INVALID, "ms_init_blender: a %d-column panorama is too narrow for %d column shards", fw, S);
+    }
     if (int e = build_plan(c)) return e;
     if (const char *chk = getenv("MS_CHECK_DIVIDE")) if (atoi(chk) != 0) {
         // the band kernels' shared-reciprocal division against the compiler's IEEE a / d, over every distinct denominator these tables hold
@@ -2458,6 +2497,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     SrcTable src{};
     for (int i = 0; i < F * N && S.mode != 2; ++i) {
         if (!((c->own_mask >> (i % N)) & 1u)) continue;       // another shard's view: not read
+        if (!((c->needed_mask >> (i % N)) & 1u)) continue;    // column sharding: no pixel of this view reaches the window
         MS_CHECK(views[i].data && views[i].type == MS_8UC3 && views[i].rows == c->cfg.src_height && views[i].cols == c->cfg.src_width,
                  "ms_stitch: view %d must be 8UC3 %dx%d", i, c->cfg.src_width, c->cfg.src_height);
         src.p[i] = (const uint8_t *)views[i].data;
@@ -2667,6 +2707,25 @@ int ms_stitch_i420(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out
 {
     if (!out_i420) return fail(MS_ERR_INVALID, "ms_stitch_i420: null output");
     return stitch_impl(c, n_frames, views, nullptr, nullptr, as_stream(stream), 0, nullptr, nullptr, nullptr, ShardArgs{}, out_i420);
+}
+
+int ms_get_col_window(const ms_ctx *c, int *begin, int *end)
+{
+    if (!c || !begin || !end) return fail(MS_ERR_INVALID, "ms_get_col_window: null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_col_window: call ms_init_blender first");
+    const bool windowed = c->col_end > c->col_begin;
+    *begin = windowed ? c->col_begin : 0;
+    *end = windowed ? c->col_end : c->pano.fw;
+    return MS_OK;
+}
+
+int ms_get_needed_views(const ms_ctx *c, unsigned *mask)
+{
+    if (!c || !mask) return fail(MS_ERR_INVALID, "ms_get_needed_views: null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_needed_views: call ms_init_blender first");
+    const unsigned all = (c->N >= 32) ? 0xffffffffu : ((1u << c->N) - 1u);
+    *mask = c->own_mask & c->needed_mask & all;
+    return MS_OK;
 }
 
 int ms_get_i420_rows(const ms_ctx *c, int *first_canvas_row, int *rows)

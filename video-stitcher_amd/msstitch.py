@@ -40,7 +40,8 @@ class Config(C.Structure):
                 ("warp_scale", C.c_float), ("num_bands", C.c_int), ("enable_cpw", C.c_int),
                 ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int),
                 ("view_shards", C.c_int), ("view_shard_index", C.c_int), ("cpu_flavour_remap", C.c_int),
-                ("debug_simple_kernels", C.c_int), ("warp_lds_stage", C.c_int), ("raster_tile_order", C.c_int), ("reserved", C.c_int * 4)]
+                ("debug_simple_kernels", C.c_int), ("warp_lds_stage", C.c_int), ("raster_tile_order", C.c_int),
+                ("col_shards", C.c_int), ("col_shard_index", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class SeamParams(C.Structure):
@@ -91,7 +92,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views",
 ]
 
 _lib = None
@@ -488,12 +489,14 @@ class Compositor:
     """stitch_calib tables once (build_maps / build_masks / init_blender), then stitch() per frame batch."""
 
     def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
-                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=None, shards=1, shard_index=0, cv_remap=False):
+                 out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=None, shards=1, shard_index=0, cv_remap=False,
+                 col_shards=1, col_shard_index=0):
         cfg = Config(C.sizeof(Config), num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
                      out_size[0], out_size[1], max_frames)
         cfg.debug_simple_kernels = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
         cfg.warp_lds_stage = 0 if lds_stage is None else (1 if lds_stage else 2)   # True: warp source tiles staged in LDS by LDS-DMA (opt-in, measured slower); False forces the direct gathers even under MS_WARP_ASYNC=1
         cfg.view_shards = shards; cfg.view_shard_index = shard_index   # view sharding
+        cfg.col_shards = col_shards; cfg.col_shard_index = col_shard_index   # pano-column sharding
         cfg.cpu_flavour_remap = 1 if cv_remap else 0   # cv::remap's CPU arithmetic for the projection warp (needs simple_kernels, no CPW)
         self._ctx = C.c_void_p()
         _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
@@ -619,7 +622,7 @@ class Compositor:
         for fr in frames:
             assert len(fr) == self.n
             for t in fr:
-                views[k] = img(t); k += 1
+                views[k] = img(t) if t is not None else Image(); k += 1      # None: a view this (column / view) shard never reads
         o8 = o16 = None
         if out8u is not None:
             o8 = (Image * n_frames)(*[img(t) for t in out8u])
@@ -641,6 +644,18 @@ class Compositor:
             _chk(fn(ctx, n, views, o8, o16, stream if stream is not None else _stream()))
         run.keepalive = (frames, out8u, out16s, views, o8, o16)
         return run
+
+    def col_window(self):
+        """(begin, end) pano-ROI columns this context composites (column sharding); the whole ROI otherwise."""
+        a, b = C.c_int(0), C.c_int(0)
+        _chk(load().ms_get_col_window(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def needed_views(self):
+        """Bit mask of the views ms_stitch reads (column / view shards read a subset)."""
+        m = C.c_uint(0)
+        _chk(load().ms_get_needed_views(self._ctx, C.byref(m)))
+        return m.value
 
     def i420_rows(self):
         """(first canvas row, rows) of the even-aligned span the I420 output holds."""
