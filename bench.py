@@ -284,9 +284,10 @@ def run_col_shards(args, cfg, gains, rank, world, dev, share):
     is_sink = local or rank == sink
     # a shard composites whole tiles: what it writes outside its window is unspecified, so every shard has its own canvases and only the
     # window's slab is copied (local) or sent (ranks) into the sink's; the sink's own shard writes into the final canvases directly
-    outs = [torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev) for _ in range(F)]
-    outs_k = {k: (outs if k == mine[0] and is_sink else [torch.zeros_like(o) for o in outs]) for k in mine}
-    run = {k: comps[k].prepared(frames[k], out8u=outs_k[k]) for k in mine}
+    canvas = torch.zeros((F, cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=dev)      # one tensor: a window of all F frames moves in one copy
+    canvas_k = {k: (canvas if k == mine[0] and is_sink else torch.zeros_like(canvas)) for k in mine}
+    outs = [canvas[f] for f in range(F)]
+    run = {k: comps[k].prepared(frames[k], out8u=[canvas_k[k][f] for f in range(F)]) for k in mine}
     # windows of every shard (the sink needs the others' to place their slabs): boundaries are a pure function of the panorama width
     fw = pg.dst_roi_final.width
     bound = lambda i: 0 if i <= 0 else (fw if i >= Cn else (i * fw // Cn) // 16 * 16)
@@ -315,22 +316,19 @@ def run_col_shards(args, cfg, gains, rank, world, dev, share):
             run[k]()
         if local:
             for k in mine[1:]:
-                cb = win[k][0] + pg.canvas_x
-                for f in range(F):
-                    outs[f][r0:r1, cb:cb + win[k][1] - win[k][0]].copy_(outs_k[k][f][r0:r1, cb:cb + win[k][1] - win[k][0]])
+                cb, ce = win[k][0] + pg.canvas_x, win[k][1] + pg.canvas_x
+                canvas[:, r0:r1, cb:ce].copy_(canvas_k[k][:, r0:r1, cb:ce])
             return
         if is_sink:
             ws = [xfer(sbuf[k][b], sink + k, False) for k in range(1, Cn)]
             for k, w in zip(range(1, Cn), ws):
                 if w is not None:
                     w.wait()
-                cb = win[k][0] + pg.canvas_x
-                for f in range(F):
-                    outs[f][r0:r1, cb:cb + win[k][1] - win[k][0]].copy_(sbuf[k][b][f])
+                cb, ce = win[k][0] + pg.canvas_x, win[k][1] + pg.canvas_x
+                canvas[:, r0:r1, cb:ce].copy_(sbuf[k][b])
         else:
-            cb = win[k_own][0] + pg.canvas_x
-            for f in range(F):
-                sbuf[k_own][b][f].copy_(outs_k[k_own][f][r0:r1, cb:cb + win[k_own][1] - win[k_own][0]])
+            cb, ce = win[k_own][0] + pg.canvas_x, win[k_own][1] + pg.canvas_x
+            sbuf[k_own][b].copy_(canvas_k[k_own][:, r0:r1, cb:ce])
             w = xfer(sbuf[k_own][b], sink, True)
             if w is not None:
                 pending[b].append(w)

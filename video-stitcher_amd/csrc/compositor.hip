@@ -449,10 +449,10 @@ __host__ __device__ inline void btail_range(const int *qw, int t, int nb, int st
 }
 __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__ views, PanoDesc P, int t,
                                                     const uint8_t *__restrict__ gl, long long gl_stride,
-                                                    int16_t *__restrict__ cl, long long cl_stride)
+                                                    int16_t *__restrict__ cl, long long cl_stride, int strip0)
 {
     extern __shared__ int16_t s_c[];
-    const int nb = P.nb, f = blockIdx.z, strip = blockIdx.x, c = blockIdx.y;      // one colour plane per workgroup
+    const int nb = P.nb, f = blockIdx.z, strip = blockIdx.x + strip0, c = blockIdx.y;      // one colour plane per workgroup (strip0: first strip of a column window)
     int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
     btail_range(P.qw, t, nb, strip, a, b);
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
@@ -2617,7 +2617,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     const int dt_l0 = c->tail_l0, dt_lds = c->tail_lds, dt_strips = c->tail_strips;     // (starting the reduce tail a level finer was measured slower even for one frame)
     for (int l = 0; l < nb; ++l) {
         if (l == dt_l0 && c->cfg.debug_simple_kernels == 0) {
-            k_down_tail<<<dim3(F * N * 3 * dt_strips), blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask);
+            k_down_tail<<<dim3(F * N * 3 * dt_strips), blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask & c->needed_mask);
             MS_LAUNCH_CHECK();
             if (int e = mark("k_down_tail")) return e;
             break;
@@ -2659,7 +2659,13 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     const bool bt2 = F <= 2 && c->btail2_t >= 0 && !bt2_off;      // live mode (1-2 frames per call): launches dominate, the band tail starts one band finer
     const int bt_t = bt2 ? c->btail2_t : c->btail_t, bt_lds = bt2 ? c->btail2_lds : c->btail_lds, bt_strips = bt2 ? c->btail2_strips : c->btail_strips;
     if (S.mode == 0 && bt_t >= 0) {      // bands nb .. bt_t in one launch
-        k_blend_tail<<<dim3(bt_strips, 3, F), blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride);
+        int s0 = 0, s1 = bt_strips;
+        if (c->col_end > c->col_begin) {      // column sharding: only the strips of band bt_t that hold a column the window depends on
+            int ra = c->col_begin, rb = c->col_end;
+            for (int l = 0; l < bt_t; ++l) { ra = std::max(ra / 2 - 1, 0); rb = std::min((rb + 1) / 2 + 1, P.qw[l + 1]); }
+            s0 = std::min(ra / BTAIL_W, bt_strips - 1); s1 = std::max(std::min(div_up(rb, BTAIL_W), bt_strips), s0 + 1);
+        }
+        k_blend_tail<<<dim3(s1 - s0, 3, F), blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_blend_tail")) return e;
         l_first = bt_t - 1;
