@@ -25,13 +25,14 @@ def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, ban
     for i in range(n):
         comp.set_camera(i, *synth.camera(n, w, h, hfov, i)); comp.set_gain(i, gains[i])
     comp.build_maps(); comp.build_masks(1 if seams else 0); comp.init_blender()
-    meshes = None
+    meshes, vmeshes = None, []
     if cpw:
         meshes = []
         for i in range(n):
             r = comp.view_geom(i).roi
             mesh = synth.mesh(r.width, r.height, int(rng.integers(3, 13)), int(rng.integers(3, 13)), phase=0.4 * i, amp=float(rng.uniform(0.5, 12.0)))
             comp.set_mesh(i, *mesh)
+            vmeshes.append(mesh)
             meshes.append(tuple(host(m) for m in comp.mesh_maps(i)))
             want = oracle.convert_mesh_to_map(mesh[0], mesh[1], r.width, r.height)       # convertMeshesToMap, bit for bit (NaN holes included)
             assert np.array_equal(meshes[-1][0], want[0], equal_nan=True) and np.array_equal(meshes[-1][1], want[1], equal_nan=True)
@@ -50,6 +51,28 @@ def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, ban
     ref, refmask = b.blend()
     assert b.num_bands == pg.num_bands
     assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
+    # a column shard of the same rig (SURVEY 8(e) pano-column split): its window must equal the oracle's frame too, from the views it asks for only
+    S = int(rng.integers(2, 4)); k = int(rng.integers(0, S))
+    shard = ms.Compositor(n, (w, h), proj, synth.warp_scale(out_w), num_bands=bands, enable_cpw=cpw, out_size=(out_w, out_w // 2), col_shards=S, col_shard_index=k)
+    for i in range(n):
+        shard.set_camera(i, *synth.camera(n, w, h, hfov, i)); shard.set_gain(i, gains[i])
+    shard.build_maps(); shard.build_masks(1 if seams else 0)
+    try:
+        shard.init_blender()
+        narrow = False
+    except ms.MsError as e:
+        narrow = "too narrow" in str(e)
+        assert narrow, e
+    if not narrow:
+        for i in range(n if cpw else 0):
+            shard.set_mesh(i, *vmeshes[i])
+        b0, b1 = shard.col_window()
+        need = shard.needed_views()
+        got = torch.full_like(out16, -5)
+        shard.stitch([[to_dev(f) if (need >> i) & 1 else None for i, f in enumerate(frames)]], out16s=[got])
+        torch.cuda.synchronize()
+        assert np.array_equal(host(got)[:, b0:b1], ref[:, b0:b1]), "column shard %d/%d, window [%d, %d)" % (k, S, b0, b1)
+    shard.close()
     # the planar I420 output must equal canvas + cvtColor(BGR2YUV_I420) wherever it is supported (any parity of the canvas offset)
     canvas = torch.zeros((out_w // 2, out_w, 3), dtype=torch.uint8, device=cuda)
     comp.stitch([[to_dev(f) for f in frames]], out8u=[canvas])
