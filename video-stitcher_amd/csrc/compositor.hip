@@ -447,7 +447,7 @@ __host__ __device__ inline void btail_range(const int *qw, int t, int nb, int st
         b[l + 1] = min(((b[l] - 1) / 2 + 2 + 1) & ~1, qw[l + 1]);
     }
 }
-__global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__ views, PanoDesc P, int t,
+__global__ void __launch_bounds__(1024) k_blend_tail(const ViewDesc *__restrict__ views, PanoDesc P, int t,
                                                     const uint8_t *__restrict__ gl, long long gl_stride,
                                                     int16_t *__restrict__ cl, long long cl_stride, int strip0)
 {
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__
     const int nb = P.nb, f = blockIdx.z, strip = blockIdx.x + strip0, c = blockIdx.y;      // one colour plane per workgroup (strip0: first strip of a column window)
     int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
     btail_range(P.qw, t, nb, strip, a, b);
-    const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+    const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x, nthr = (int)(blockDim.x * blockDim.y);      // 256 lanes per workgroup, 1024 in live mode
     int16_t *cur = s_c, *prev = nullptr;       // cur: band l being written ((b-a) x qh), prev: band l+1
     int prev_w = 0;
     const uint8_t *glf = gl + (size_t)f * gl_stride;
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__
         const int lw = b[l] - a[l], lh = P.qh[l];
         if (l == nb) {
             // coarsest band: C = trunc( sum_v trunc(G * w) / den ), per pixel (view rects need not be even-aligned here)
-            for (int i = tid; i < lw * lh; i += 256) {
+            for (int i = tid; i < lw * lh; i += nthr) {
                 const int y = i / lw, x = a[l] + (i - y * lw);
                 int16_t acc = 0;
                 for (int v = 0; v < P.n_views; ++v) {
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256) k_blend_tail(const ViewDesc *__restrict__
         } else {
             // band l < nb: Laplacian of every view formed on the fly, accumulate, normalise, add pyrUp of the collapsed band l+1 (in LDS); 2x2 quads
             const int qwl = lw >> 1, qhl = lh >> 1;
-            for (int i = tid; i < qwl * qhl; i += 256) {
+            for (int i = tid; i < qwl * qhl; i += nthr) {
                 const int qy = i / qwl, qxl = i - qy * qwl;
                 const int x0 = a[l] + 2 * qxl, y0 = 2 * qy;
                 int16_t acc[4] = {0, 0, 0, 0};
@@ -2665,7 +2665,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             for (int l = 0; l < bt_t; ++l) { ra = std::max(ra / 2 - 1, 0); rb = std::min((rb + 1) / 2 + 1, P.qw[l + 1]); }
             s0 = std::min(ra / BTAIL_W, bt_strips - 1); s1 = std::max(std::min(div_up(rb, BTAIL_W), bt_strips), s0 + 1);
         }
-        k_blend_tail<<<dim3(s1 - s0, 3, F), blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0);
+        static const int bt_rows = [] { const char *e = getenv("MS_BTAIL_ROWS"); return e ? atoi(e) : 0; }();      // (A/B: lane rows per workgroup)
+        const dim3 bt_blk(64, bt_rows > 0 ? bt_rows : (F <= 2 ? 16 : 4));      // live mode: a strip's few hundred quads per band on 1024 lanes instead of 256 -- fewer serial rounds
+        k_blend_tail<<<dim3(s1 - s0, 3, F), bt_blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_blend_tail")) return e;
         l_first = bt_t - 1;
