@@ -235,7 +235,11 @@ typedef struct ms_config {
      * (their ms_image may be all-zero).  Output pixels outside the window are unspecified.  0 / 1 = the whole panorama. */
     int col_shards;
     int col_shard_index;         /* which shard, 0 .. S-1 */
-    int reserved[2];             /* must be 0 */
+    /* > 0 (with enable_cpw): ms_update_mask only ENQUEUES work -- the blend tables are double-buffered and the work lists are planned for masks
+     * whose edges move by up to this many pixels, so a re-warped mask needs no new plan.  An update whose mesh displaces further than the margin
+     * (ms_get_mesh_displacement) leaves the tables as they are.  0: ms_update_mask rebuilds tables and work lists synchronously (calibration-time call). */
+    int update_mask_margin;
+    int reserved[1];             /* must be 0 */
 } ms_config;
 
 MS_API int ms_create(const ms_config *cfg, ms_ctx **out);
@@ -290,6 +294,9 @@ MS_API int ms_get_mesh_displacement(ms_ctx *ctx, int view, float *out_px);
  * the mask init_gpu received for `view`, remapped through the view's active CPW mesh (INTER_LINEAR, BORDER_CONSTANT 0), replaces the view's
  * blend-weight pyramid.  Needs enable_cpw, ms_init_blender and a mesh for the view.  The reference re-accumulates the weight sums each frame;
  * here they are frame-invariant tables, so the call rebuilds them (and the work lists) as ms_init_blender does, keeping meshes and gains.
+ * With ms_config.update_mask_margin > 0 the call is asynchronous like ms_set_mesh: it enqueues the re-warp, the view's weight pyramid, the weight
+ * sums, the result mask and the owner maps into the inactive copy of the tables on `stream` and swaps; the next ms_stitch waits for it on the GPU.
+ * Safe from the recalibration thread while another thread stitches (timed.cpp:598-605 calls it right after the mesh swap).
  * ms_get_mask keeps returning the original mask; ms_set_mask / ms_build_masks / ms_calibrate_seam drop the re-warped one. */
 MS_API int ms_update_mask(ms_ctx *ctx, int view, ms_stream stream);
 

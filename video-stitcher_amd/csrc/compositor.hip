@@ -1119,6 +1119,55 @@ __global__ void __launch_bounds__(256) k_acc_weight(const float *__restrict__ w,
     if (x >= cols || y >= rows) return;
     dst[(size_t)y * dpitch + x] = dst[(size_t)y * dpitch + x] + w[(size_t)y * wpitch + x];
 }
+// The same sums for one band in ONE launch (ms_update_mask): dst_w = ((0 + w_0) + w_1) + ... over the views that cover the pixel, in view order --
+// the float additions k_acc_weight performs view after view --, then den = sum + WEIGHT_EPS and (level 0) mask = sum > WEIGHT_EPS.
+__global__ void __launch_bounds__(256) k_den_all(const ViewDesc *__restrict__ views, int n_views, int l, float *den, int dpitch, int rows, int cols,
+                                                 uint8_t *mask, int mpitch, int mrows, int mcols)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    float s = 0.f;
+    for (int v = 0; v < n_views; ++v) {
+        const LevelDesc &L = views[v].lv[l];
+        const int lx = x - L.x_tl, ly = y - L.y_tl;
+        if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
+        s = s + L.wgt[(size_t)ly * L.wpitch + lx];
+    }
+    if (mask && x < mcols && y < mrows) mask[(size_t)y * mpitch + x] = s > 1e-5f ? 255 : 0;
+    den[(size_t)y * dpitch + x] = s + 1e-5f;
+}
+// Owner map of one band: one wave per 64 x 16 cell of the pano level.  The cell is owned by view v when v is the only view with a non-zero weight in it,
+// the cell lies inside the pano level and inside v's rect, and all of v's weights there are exactly 1.0f; 255 otherwise (see PanoDesc::pure).
+__global__ void __launch_bounds__(64) k_owner_map(const ViewDesc *__restrict__ views, int n_views, int l, int qw, int qh, uint8_t *__restrict__ pure, int ppitch)
+{
+    const int cx = blockIdx.x, cy = blockIdx.y, lane = threadIdx.x;
+    const int x0 = cx * 64, y0 = cy * 16;
+    const int px = x0 + 16 * (lane & 3), py = y0 + (lane >> 2);      // 16 pixels of one row per lane
+    int owner = -1, cnt = 0;
+    bool ones = false;
+    for (int v = 0; v < n_views; ++v) {
+        const LevelDesc &L = views[v].lv[l];
+        bool nz = false, one = true;
+        const int ly = py - L.y_tl;
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int lx = px + k - L.x_tl;
+            if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) { one = false; continue; }
+            const float w = L.wgt[(size_t)ly * L.wpitch + lx];
+            nz = nz || w != 0.f;
+            one = one && w == 1.0f;
+        }
+        if (__ballot(nz) != 0ull) { owner = v; ++cnt; ones = __ballot(!one) == 0ull; }
+    }
+    if (lane == 0) pure[(size_t)cy * ppitch + cx] = (cnt == 1 && ones && x0 + 64 <= qw && y0 + 16 <= qh) ? (uint8_t)owner : (uint8_t)255;
+}
+// ms_update_mask: the re-warped mask replaces the view's effective mask only while the mesh displaces by no more than the margin the work lists were
+// planned for (measured on the device by ms_set_mesh); otherwise the effective mask -- and with it every table derived from it -- stays as it was.
+__global__ void __launch_bounds__(256) k_mask_select(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n, const unsigned *__restrict__ disp_bits, unsigned limit_bits)
+{
+    if (*disp_bits > limit_bits) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 // den = sum + WEIGHT_EPS ; mask = sum > WEIGHT_EPS (level 0, unpadded ROI)
 __global__ void __launch_bounds__(256) k_finish_den(float *den, int dpitch, int rows, int cols, uint8_t *mask, int mpitch, int mrows, int mcols)
 {
@@ -1391,6 +1440,14 @@ struct ms_ctx {
     ms_image fed[MAX_VIEWS] = {};      // ms_feed: the views of the frame being assembled (borrowed until ms_blend)
     unsigned fed_mask = 0;
     DevBuf masks_eff;                  // ms_update_mask: masks re-warped through the CPW mesh (same layout as `masks`)
+    // Enqueue-only ms_update_mask (cfg.update_mask_margin > 0): a second copy of every table that depends on the masks.  `tab_active` says which
+    // copy ms_stitch reads (0: the members above / below, 1: alt); an update fills the other one on its own stream and swaps under mesh_mu.
+    struct AltTables { DevBuf weights, wm0, den, result_mask, pure_maps, view_tab; PanoDesc pano; std::vector<ViewDesc> h_views; } alt;
+    int tab_active = 0;
+    hipEvent_t tab_ready = nullptr;
+    bool tab_wait = false;
+    DevBuf mask_tmp, wm_scratch;       // re-warped mask / float weight map of the largest view
+    size_t w_total = 0, wm0_total = 0, den_total = 0, pure_total = 0, pure_off[MAX_LEVELS] = {};
     bool use_eff[MAX_VIEWS] = {};
     DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
@@ -1523,6 +1580,18 @@ static void xcd_order(std::vector<T> &tiles)
 
 static bool sharded_ctx(const ms_ctx *c) { return c->own_mask != ((c->N >= 32) ? 0xffffffffu : ((1u << c->N) - 1u)); }
 
+// k_owner_map for every band that has a map, into `pure` (laid out by build_plan), from the weights `vt` points at
+static int launch_owner_maps(ms_ctx *c, const ViewDesc *vt, uint8_t *pure, hipStream_t st)
+{
+    for (int l = 0; l < c->pano.nb; ++l) {
+        if (!c->pure_off[l]) continue;
+        const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
+        k_owner_map<<<dim3(pw_, ph_), 64, 0, st>>>(vt, c->N, l, c->pano.qw[l], c->pano.qh[l], pure + (c->pure_off[l] - 1), pw_);
+        MS_LAUNCH_CHECK();
+    }
+    return MS_OK;
+}
+
 static int build_plan(ms_ctx *c)
 {
     const int N = c->N, nb = c->pano.nb;
@@ -1538,6 +1607,19 @@ static int build_plan(ms_ctx *c)
             for (int y = 0; y < L.h; ++y)
                 for (int x = 0; x < L.w; ++x) b[(size_t)y * L.w + x] = p[(size_t)y * L.wpitch + x] != 0.f;
         }
+    // Enqueue-only ms_update_mask: the lists are planned for every mask whose support stays within `margin` + 2 px (the bilinear taps) of the
+    // original one -- the support of its level-l weights then stays within d_l of the original support, d_0 = margin + 2, d_{l+1} = ceil(d_l / 2) + 1 (pyrDown).
+    // Zero weights inside the planned region cost work, never correctness; the owner maps are made from the true weights on the device.
+    if (c->cfg.update_mask_margin > 0) {
+        int d = c->cfg.update_mask_margin + 2;
+        for (int l = 0; l <= nb; ++l) {
+            for (int v = 0; v < N; ++v) {
+                const LevelDesc &L = c->h_views[v].lv[l];
+                W[v][l] = dilate(W[v][l], L.w, L.h, d);
+            }
+            d = (d + 1) / 2 + 1;
+        }
+    }
     // Pano-column window: band l is needed on the columns R_l = [ra_l, rb_l) only, R_0 = the window, R_{l+1} = the pyrUp taps of R_l.  The needed
     // regions below are derived from the weights restricted to R_l (Wn); the band kernels still composite whole tiles, and what a straddling tile
     // computes outside R_l is computed from pyramid pixels nobody produced: never read by a needed pixel, like every other unplanned pixel.
@@ -1703,40 +1785,21 @@ static int build_plan(ms_ctx *c)
         if (int e = c->blend_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(BlendTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->blend_tiles[l].p, tiles.data(), tiles.size() * sizeof(BlendTile), hipMemcpyHostToDevice));
     }
-    // owner maps: 64 x 16 cells of a band where exactly one view has non-zero weights, every one of them exactly 1.0f
-    {
-        std::vector<uint8_t> all;
-        size_t off[MAX_LEVELS] = {};
-        for (int l = 0; l < nb; ++l) {
-            c->pano.pure[l] = nullptr; c->pano.ppitch[l] = 0;
-            if (!c->blend_vec[l] || sharded_ctx(c) || c->cfg.debug_simple_kernels != 0) continue;
-            const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
-            off[l] = all.size() + 1;          // (+1: 0 means "no map")
-            c->pano.ppitch[l] = pw_;
-            for (int cy = 0; cy < ph_; ++cy)
-                for (int cx = 0; cx < pw_; ++cx) {
-                    const int x0 = cx * 64, y0 = cy * 16;
-                    int owner = -1, cnt = 0;
-                    for (int v = 0; v < N; ++v) {
-                        const LevelDesc &L = c->h_views[v].lv[l];
-                        if (any_in(W[v][l], L.w, L.h, x0 - L.x_tl, y0 - L.y_tl, 64, 16)) { owner = v; ++cnt; }
-                    }
-                    bool ok = cnt == 1 && x0 + 64 <= c->pano.qw[l] && y0 + 16 <= c->pano.qh[l];
-                    if (ok) {
-                        const LevelDesc &L = c->h_views[owner].lv[l];
-                        const float *wp = hw.data() + c->w_off[owner][l];
-                        ok = x0 - L.x_tl >= 0 && y0 - L.y_tl >= 0 && x0 - L.x_tl + 64 <= L.w && y0 - L.y_tl + 16 <= L.h;
-                        for (int y = 0; ok && y < 16; ++y)
-                            for (int x = 0; ok && x < 64; ++x) ok = wp[(size_t)(y0 - L.y_tl + y) * L.wpitch + (x0 - L.x_tl + x)] == 1.0f;
-                    }
-                    all.push_back(ok ? (uint8_t)owner : (uint8_t)255);
-                }
-        }
-        if (!all.empty()) {
-            if (int e = c->pure_maps.alloc(all.size())) return e;
-            MS_HIP(hipMemcpy(c->pure_maps.p, all.data(), all.size(), hipMemcpyHostToDevice));
-            for (int l = 0; l < nb; ++l) if (off[l]) c->pano.pure[l] = (const uint8_t *)c->pure_maps.p + (off[l] - 1);
-        }
+    // owner maps: 64 x 16 cells of a band where exactly one view has non-zero weights, every one of them exactly 1.0f (k_owner_map, from the weights on the device)
+    c->pure_total = 0;
+    for (int l = 0; l < nb; ++l) {
+        c->pano.pure[l] = nullptr; c->pano.ppitch[l] = 0; c->pure_off[l] = 0;
+        if (!c->blend_vec[l] || sharded_ctx(c) || c->cfg.debug_simple_kernels != 0) continue;
+        const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
+        c->pure_off[l] = c->pure_total + 1;          // (+1: 0 means "no map")
+        c->pano.ppitch[l] = pw_;
+        c->pure_total += (size_t)pw_ * ph_;
+    }
+    if (c->pure_total) {
+        if (int e = c->pure_maps.alloc(c->pure_total)) return e;
+        for (int l = 0; l < nb; ++l) if (c->pure_off[l]) c->pano.pure[l] = (const uint8_t *)c->pure_maps.p + (c->pure_off[l] - 1);
+        if (int e = launch_owner_maps(c, (const ViewDesc *)c->view_tab.p, (uint8_t *)c->pure_maps.p, nullptr)) return e;
+        MS_HIP(hipStreamSynchronize(nullptr));
     }
     return MS_OK;
 }
@@ -1750,7 +1813,9 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     if (!cfg || !out) return fail(MS_ERR_INVALID, "ms_create: null argument");
     if (int e = require_device()) return e;
     MS_CHECK(cfg->struct_size == sizeof(ms_config), "ms_create: ms_config.struct_size is %u, this library expects %zu (header / library mismatch)", cfg->struct_size, sizeof(ms_config));
-    MS_CHECK(cfg->reserved[0] == 0 && cfg->reserved[1] == 0, "ms_create: ms_config.reserved must be zero");
+    MS_CHECK(cfg->reserved[0] == 0, "ms_create: ms_config.reserved must be zero");
+    MS_CHECK(cfg->update_mask_margin >= 0 && cfg->update_mask_margin <= 64 && (cfg->update_mask_margin == 0 || (cfg->enable_cpw && cfg->num_bands >= 1 && cfg->view_shards <= 1)),
+             "ms_create: update_mask_margin %d needs enable_cpw, num_bands >= 1, no view shards, and must be in [0, 64]", cfg->update_mask_margin);
     MS_CHECK(cfg->num_views >= 1 && cfg->num_views <= MAX_VIEWS, "ms_create: num_views %d not in [1,%d]", cfg->num_views, MAX_VIEWS);
     MS_CHECK(cfg->src_width > 1 && cfg->src_height > 1, "ms_create: bad source size %dx%d", cfg->src_width, cfg->src_height);
     MS_CHECK(cfg->projection >= MS_PROJ_PLANE && cfg->projection <= MS_PROJ_SPHERICAL, "ms_create: bad projection %d", cfg->projection);
@@ -1797,6 +1862,7 @@ void ms_destroy(ms_ctx *c)
     if (c->last_stitch) (void)hipEventDestroy(c->last_stitch);
     for (int v = 0; v < MAX_VIEWS; ++v) if (c->mesh_ready[v]) (void)hipEventDestroy(c->mesh_ready[v]);
     if (c->mesh_chain) (void)hipEventDestroy(c->mesh_chain);
+    if (c->tab_ready) (void)hipEventDestroy(c->tab_ready);
     if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
     delete c;
 }

@@ -41,7 +41,7 @@ class Config(C.Structure):
                 ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int),
                 ("view_shards", C.c_int), ("view_shard_index", C.c_int), ("cpu_flavour_remap", C.c_int),
                 ("debug_simple_kernels", C.c_int), ("warp_lds_stage", C.c_int), ("raster_tile_order", C.c_int),
-                ("col_shards", C.c_int), ("col_shard_index", C.c_int), ("reserved", C.c_int * 2)]
+                ("col_shards", C.c_int), ("col_shard_index", C.c_int), ("update_mask_margin", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class SeamParams(C.Structure):
@@ -490,13 +490,14 @@ class Compositor:
 
     def __init__(self, num_views, src_size, projection, warp_scale, num_bands=5, enable_cpw=False,
                  out_size=(0, 0), max_frames=1, simple_kernels=False, lds_stage=None, shards=1, shard_index=0, cv_remap=False,
-                 col_shards=1, col_shard_index=0):
+                 col_shards=1, col_shard_index=0, update_mask_margin=0):
         cfg = Config(C.sizeof(Config), num_views, src_size[0], src_size[1], projection, warp_scale, num_bands, int(enable_cpw),
                      out_size[0], out_size[1], max_frames)
         cfg.debug_simple_kernels = 1 if simple_kernels else 0   # debug: force the one-pixel-per-lane reference kernels
         cfg.warp_lds_stage = 0 if lds_stage is None else (1 if lds_stage else 2)   # True: warp source tiles staged in LDS by LDS-DMA (opt-in, measured slower); False forces the direct gathers even under MS_WARP_ASYNC=1
         cfg.view_shards = shards; cfg.view_shard_index = shard_index   # view sharding
         cfg.col_shards = col_shards; cfg.col_shard_index = col_shard_index   # pano-column sharding
+        cfg.update_mask_margin = update_mask_margin   # > 0: ms_update_mask is enqueue-only (double-buffered tables, work lists planned with this margin)
         cfg.cpu_flavour_remap = 1 if cv_remap else 0   # cv::remap's CPU arithmetic for the projection warp (needs simple_kernels, no CPW)
         self._ctx = C.c_void_p()
         _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
