@@ -25,14 +25,14 @@ def host(t):
 
 
 def make_rig(ms, name, enable_cpw=False, max_frames=1, mask_mode=1, projection=None, simple_kernels=False, lds_stage=None, shards=1, shard_index=0,
-             col_shards=1, col_shard_index=0):
+             col_shards=1, col_shard_index=0, update_mask_margin=0):
     """Compositor for one of synth.CONFIGS, calibrated end to end on the device."""
     cfg = synth.CONFIGS[name]
     proj = ms.PROJ_SPHERICAL if projection is None else projection
     comp = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), proj, synth.warp_scale(cfg["out_w"]),
                          num_bands=cfg["num_bands"], enable_cpw=enable_cpw, out_size=(cfg["out_w"], cfg["out_h"]),
                          max_frames=max_frames, simple_kernels=simple_kernels, lds_stage=lds_stage, shards=shards, shard_index=shard_index,
-                         col_shards=col_shards, col_shard_index=col_shard_index)
+                         col_shards=col_shards, col_shard_index=col_shard_index, update_mask_margin=update_mask_margin)
     g = synth.gains(cfg["n"])
     for i in range(cfg["n"]):
         K, R = synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i)

@@ -75,9 +75,11 @@ def test_stitch_cpw_matches_oracle(ms, cuda, oracle):
     comp.close()
 
 
-def test_update_mask_matches_oracle(ms, cuda, oracle):
-    """MultiBandBlender::update_mask (blenders.cpp:297-315): masks re-warped through the CPW meshes replace the blend weights."""
-    comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
+@pytest.mark.parametrize("margin", [0, 12])
+def test_update_mask_matches_oracle(ms, cuda, oracle, margin):
+    """MultiBandBlender::update_mask (blenders.cpp:297-315): masks re-warped through the CPW meshes replace the blend weights.
+    margin = 0: the synchronous rebuild; margin > 0: the enqueue-only path (double-buffered tables, work lists planned with the margin)."""
+    comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True, update_mask_margin=margin)
     frames_np = [synth.frame(cfg["w"], cfg["h"], i, 5) for i in range(cfg["n"])]
     frames = [[to_dev(f) for f in frames_np]]
     pg = comp.pano_geom()
@@ -110,6 +112,29 @@ def test_update_mask_matches_oracle(ms, cuda, oracle):
     assert np.array_equal(host(comp.result_mask()), refmask)
     assert np.array_equal(host(out16), ref16)
     assert not np.array_equal(before, ref16)
+    if margin:
+        # a mesh that displaces further than the margin leaves the tables as they are (the work lists were not planned for it) ...
+        r = comp.view_geom(1).roi
+        comp.set_mesh(1, *synth.mesh(r.width, r.height, 9, 11, phase=0.9, amp=3.0 * margin))
+        assert comp.mesh_displacement(1) > margin
+        comp.update_mask(1)
+        assert np.array_equal(host(comp.result_mask()), refmask)
+        # ... and the next one within the margin takes effect again; many updates in a row alternate between the two copies of the tables
+        comp.set_mesh(1, *synth.mesh(r.width, r.height, 9, 11, phase=0.4, amp=6.0))
+        for _ in range(5):
+            comp.update_mask(1)
+        out_b = torch.zeros_like(out16)
+        comp.stitch(frames, out16s=[out_b]); torch.cuda.synchronize()
+        b2, _ = oracle_blender_from(oracle, comp, cfg)
+        m1 = tuple(host(m) for m in comp.mesh_maps(1))
+        for i in updated + (1,):
+            b2.update_mask(i, *(m1 if i == 1 else meshes[i]))
+        for i in range(cfg["n"]):
+            xm, ym = [host(t) for t in comp.maps(i)]
+            b2.stitch_online(i, frames_np[i], xm, ym, gains[i], *(m1 if i == 1 else meshes[i]))
+        ref_b, refmask_b = b2.blend()
+        b2.close()
+        assert np.array_equal(host(out_b), ref_b) and np.array_equal(host(comp.result_mask()), refmask_b)
     # fresh masks drop the re-warped ones: back to the first result
     for i in range(cfg["n"]):
         comp.set_mask(i, host(comp.mask(i)))

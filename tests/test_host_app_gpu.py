@@ -65,6 +65,19 @@ def test_host_app_cpw_with_concurrent_recalibration(ms, cuda, tmp_path):
     assert info["recalibrations"] >= 1
 
 
+@pytest.mark.parametrize("rig", ["mini6", "cfg2"])
+def test_host_app_updates_masks_on_the_recalibration_thread(ms, cuda, tmp_path, rig):
+    """timed.cpp:598-605 re-enabled: after every mesh swap the recalibration thread calls mb->update_mask(idx) -- enqueue-only here (update_mask_margin),
+    while the stitcher thread keeps stitching.  The run must complete, and the tables the context ends up with must equal what a fresh context builds from
+    the final meshes with the synchronous update_mask (the app stitches one more frame through both and compares: `update_mask_equals_sync_rebuild`)."""
+    cfg = synth.CONFIGS[rig]
+    info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
+                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 400 if rig == "mini6" else 300, "--update-mask", 12)
+    assert info["cpw"] is True and info["update_mask_margin"] == 12 and info["recalibrations"] >= 2
+    assert info["max_mesh_displacement_px"] <= 12
+    assert info["update_mask_equals_sync_rebuild"] is True
+
+
 def test_host_app_solves_meshes_while_stitching(ms, cuda, tmp_path):
     """--solve-mesh: the recalibration thread uploads the current frames, remaps them, runs the device feature front-end (overlap masks, ORB, Hamming 2-NN +
     ratio test, RANSAC homographies: msshim::featurefinder) and msshim::MeshWarper::calibrateMeshWarp (ms_create_mesh: triangle statistics + least-squares CG

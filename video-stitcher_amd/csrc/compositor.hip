@@ -1885,6 +1885,10 @@ int ms_set_gain(ms_ctx *c, int view, double gain)
     if (c->blender_ready) {   // keep the device table in sync (gains change at recalibration only)
         c->h_views[view].gain = (float)gain;
         MS_HIP(hipMemcpy((ViewDesc *)c->view_tab.p + view, &c->h_views[view], sizeof(ViewDesc), hipMemcpyHostToDevice));
+        if (c->alt.view_tab.p && (int)c->alt.h_views.size() == c->N) {
+            c->alt.h_views[view].gain = (float)gain;
+            MS_HIP(hipMemcpy((ViewDesc *)c->alt.view_tab.p + view, &c->alt.h_views[view], sizeof(ViewDesc), hipMemcpyHostToDevice));
+        }
     }
     return MS_OK;
 }
@@ -2159,6 +2163,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         }
         c->blend_vec[l] = ok;
     }
+    c->w_total = w_total;
     if (int e = c->weights.alloc(w_total * sizeof(float))) return e;
     MS_HIP(hipMemsetAsync(c->weights.p, 0, w_total * sizeof(float), st));
     {
@@ -2169,6 +2174,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             c->wm0_off[v] = m_total;
             m_total += (size_t)V.wm0_pitch * V.ph;
         }
+        c->wm0_total = m_total + 64;
         if (int e = c->wm0.alloc(m_total + 64)) return e;
         MS_HIP(hipMemsetAsync(c->wm0.p, 0, m_total + 64, st));
         for (int v = 0; v < N; ++v) {
@@ -2204,6 +2210,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     P.alpha = (float)(1. / 255.);
     P.canvas_x = c->canvas_x; P.canvas_y = c->canvas_y; P.out_w = c->cfg.out_width; P.out_h = c->cfg.out_height;
     P.i_y0 = std::max(0, c->canvas_y & ~1); P.i_rows = std::max(0, std::min(c->cfg.out_height & ~1, (c->canvas_y + P.fh + 1) & ~1) - P.i_y0);
+    c->den_total = den_total;
     if (int e = c->den.alloc(den_total * sizeof(float))) return e;
     if (int e = c->result_mask.alloc((size_t)P.fw * P.fh)) return e;
     MS_HIP(hipMemsetAsync(c->den.p, 0, den_total * sizeof(float), st));
@@ -2313,6 +2320,43 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         if (c->col_end <= c->col_begin) return fail(MS_ERR_INVALID, "ms_init_blender: a %d-column panorama is too narrow for %d column shards", fw, S);
     }
     if (int e = build_plan(c)) return e;
+    {   // a (re-)initialisation makes the primary tables current; the alternate copy is set up (not filled) for the enqueue-only ms_update_mask
+        std::lock_guard<std::mutex> mk(c->mesh_mu);
+        c->tab_active = 0; c->tab_wait = false;
+    }
+    if (c->cfg.update_mask_margin > 0) {
+        ms_ctx::AltTables &A = c->alt;
+        if (int e = A.weights.alloc(c->w_total * sizeof(float))) return e;
+        if (int e = A.wm0.alloc(c->wm0_total)) return e;
+        if (int e = A.den.alloc(c->den_total * sizeof(float))) return e;
+        if (int e = A.result_mask.alloc((size_t)c->pano.fw * c->pano.fh)) return e;
+        if (int e = A.pure_maps.alloc(std::max<size_t>(1, c->pure_total))) return e;
+        if (int e = A.view_tab.alloc(sizeof(ViewDesc) * N)) return e;
+        A.h_views = c->h_views;
+        for (int v = 0; v < N; ++v) {
+            A.h_views[v].wm0 = (const uint8_t *)A.wm0.p + c->wm0_off[v];
+            for (int l = 0; l <= nb; ++l) A.h_views[v].lv[l].wgt = (const float *)A.weights.p + c->w_off[v][l];
+        }
+        MS_HIP(hipMemcpy(A.view_tab.p, A.h_views.data(), sizeof(ViewDesc) * N, hipMemcpyHostToDevice));
+        A.pano = c->pano;
+        for (int l = 0; l <= nb; ++l) A.pano.den[l] = (const float *)A.den.p + c->den_off[l];
+        A.pano.mask = (const uint8_t *)A.result_mask.p;
+        for (int l = 0; l < nb; ++l) A.pano.pure[l] = c->pure_off[l] ? (const uint8_t *)A.pure_maps.p + (c->pure_off[l] - 1) : nullptr;
+        if (int e = c->mask_tmp.alloc((size_t)c->max_aw * c->max_ah)) return e;
+        if (int e = c->wm_scratch.alloc((size_t)c->max_aw * c->max_ah * sizeof(float))) return e;
+        if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
+            if (int e = c->masks_eff.alloc(c->masks.bytes)) return e;
+            for (int v = 0; v < N; ++v) c->use_eff[v] = false;
+        }
+        for (int v = 0; v < N; ++v)      // the effective mask of a view that has no re-warped one is the mask itself
+            if (!c->use_eff[v])
+                MS_HIP(hipMemcpy((uint8_t *)c->masks_eff.p + c->mask_off[v], (const uint8_t *)c->masks.p + c->mask_off[v], (size_t)c->roi[v].width * c->roi[v].height, hipMemcpyDeviceToDevice));
+        if (!c->tab_ready) MS_HIP(hipEventCreateWithFlags(&c->tab_ready, hipEventDisableTiming));
+        if (!c->disp_dev.p) {
+            if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
+            MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));      // "unbounded" until measured
+        }
+    }
     if (const char *chk = getenv("MS_CHECK_DIVIDE")) if (atoi(chk) != 0) {
         // the band kernels' shared-reciprocal division against the compiler's IEEE a / d, over every distinct denominator these tables hold
         // and all int16 numerators (common.hpp, DivBy): the bit-exactness claim rests on this check, not on an argument about the sequence
@@ -2494,6 +2538,81 @@ int ms_set_mesh_interp(ms_ctx *c, int view, const float *x0, const float *y0, co
     return ms_set_mesh(c, view, mx.data(), my.data(), N, M, stream);
 }
 
+// Enqueue-only update_mask (cfg.update_mask_margin > 0; caller holds mesh_update_mu).  Everything that depends on the masks exists twice; the copy
+// ms_stitch does not read is rebuilt on `st` -- behind the stitches enqueued so far, which may still read it from before the previous swap -- and becomes
+// the active one under mesh_mu; ms_stitch makes its stream wait for `tab_ready`.  No host synchronisation, no allocation, no new work lists: those
+// were planned for any mask within the margin (build_plan), and a mesh that displaces further leaves the effective mask unchanged (k_mask_select).
+static int update_mask_async(ms_ctx *c, int view, hipStream_t st)
+{
+    const int N = c->N, nb = c->pano.nb;
+    ms_ctx::AltTables &A = c->alt;
+    int from, mesh_idx;
+    {
+        std::lock_guard<std::mutex> mk(c->mesh_mu);
+        from = c->tab_active; mesh_idx = c->mesh_active[view];
+        if (c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
+        if (c->mesh_ready[view]) MS_HIP(hipStreamWaitEvent(st, c->mesh_ready[view], 0));
+        if (c->tab_wait) MS_HIP(hipStreamWaitEvent(st, c->tab_ready, 0));
+    }
+    const bool to_alt = from == 0;
+    float *w_to = (float *)(to_alt ? A.weights.p : c->weights.p);
+    const float *w_from = (const float *)(to_alt ? c->weights.p : A.weights.p);
+    uint8_t *m0_to = (uint8_t *)(to_alt ? A.wm0.p : c->wm0.p);
+    const uint8_t *m0_from = (const uint8_t *)(to_alt ? c->wm0.p : A.wm0.p);
+    float *den_to = (float *)(to_alt ? A.den.p : c->den.p);
+    uint8_t *rm_to = (uint8_t *)(to_alt ? A.result_mask.p : c->result_mask.p);
+    uint8_t *pure_to = (uint8_t *)(to_alt ? A.pure_maps.p : c->pure_maps.p);
+    const ViewDesc *vt_to = (const ViewDesc *)(to_alt ? A.view_tab.p : c->view_tab.p);
+    const ViewDesc &V = c->h_views[view];
+    const PanoDesc &P = c->pano;
+    const int aw = V.aw, ah = V.ah;
+    // 1. the mask init_gpu received, through the view's active mesh (blenders.cpp:299-301); kept only if the mesh stays within the planned margin
+    ms_image src{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)aw, aw, ah, MS_8UC1};
+    ms_image tmp{c->mask_tmp.p, (size_t)aw, aw, ah, MS_8UC1};
+    ms_image mx = mesh_image(c, mesh_idx, view, 0), my = mesh_image(c, mesh_idx, view, 1);
+    if (int e = launch_remap(src, mx, my, tmp, MS_INTER_LINEAR, MS_BORDER_CONSTANT, st)) return e;
+    const float lim = (float)c->cfg.update_mask_margin;
+    unsigned lim_bits;
+    memcpy(&lim_bits, &lim, 4);
+    uint8_t *eff = (uint8_t *)c->masks_eff.p + c->mask_off[view];
+    k_mask_select<<<std::min(1024, div_up(aw * ah, 256)), 256, 0, st>>>(eff, (const uint8_t *)c->mask_tmp.p, (size_t)aw * ah, (const unsigned *)c->disp_dev.p + 2 * view + mesh_idx, lim_bits);
+    MS_LAUNCH_CHECK();
+    // 2. the other views' weights are what they are in the active copy; this view's are rebuilt (blenders.cpp:303-314 = init_gpu's chain)
+    MS_HIP(hipMemcpyAsync(w_to, w_from, c->w_total * sizeof(float), hipMemcpyDeviceToDevice, st));
+    MS_HIP(hipMemcpyAsync(m0_to, m0_from, c->wm0_total, hipMemcpyDeviceToDevice, st));
+    MS_HIP(hipMemcpy2DAsync(m0_to + c->wm0_off[view] + (size_t)V.top * V.wm0_pitch + V.left, V.wm0_pitch, eff, aw, aw, ah, hipMemcpyDeviceToDevice, st));
+    {
+        ms_image mask{eff, (size_t)aw, aw, ah, MS_8UC1};
+        ms_image wmap{c->wm_scratch.p, (size_t)aw * sizeof(float), aw, ah, MS_32FC1};
+        if (int e = launch_convert(mask, wmap, 1. / 255., st)) return e;
+        auto level_img = [&](int l) {
+            const LevelDesc &L = V.lv[l];
+            return ms_image{(void *)(w_to + c->w_off[view][l]), (size_t)L.wpitch * sizeof(float), L.w, L.h, MS_32FC1};
+        };
+        ms_image l0 = level_img(0);
+        if (int e = launch_copy_make_border(wmap, l0, V.top, V.left, MS_BORDER_CONSTANT, st)) return e;
+        for (int l = 0; l < nb; ++l) {
+            ms_image a = level_img(l), b = level_img(l + 1);
+            if (int e = launch_pyr_down(a, b, st)) return e;
+        }
+    }
+    // 3. weight sums, result mask, owner maps from the new set of weights
+    for (int l = 0; l <= nb; ++l) {
+        k_den_all<<<dim3(div_up(P.qw[l], 64), div_up(P.qh[l], 4)), dim3(64, 4), 0, st>>>(vt_to, N, l, den_to + c->den_off[l], P.dpitch[l], P.qh[l], P.qw[l],
+                                                                                         l == 0 ? rm_to : nullptr, P.mask_pitch, P.fh, P.fw);
+        MS_LAUNCH_CHECK();
+    }
+    if (c->pure_total)
+        if (int e = launch_owner_maps(c, vt_to, pure_to, st)) return e;
+    {
+        std::lock_guard<std::mutex> mk(c->mesh_mu);
+        MS_HIP(hipEventRecord(c->tab_ready, st));
+        c->tab_active = from ^ 1; c->tab_wait = true;
+    }
+    c->use_eff[view] = true;
+    return MS_OK;
+}
+
 // MultiBandBlender::update_mask (blenders.cpp:297-315): the view's mask re-warped through its CPW mesh (remap LINEAR, BORDER_CONSTANT 0),
 // then weight map, border, pyrDown chain as in init_gpu.  The reference re-accumulates the weight sums every frame, here they are static
 // tables: the sums, the result mask and the work lists are rebuilt too (calibration-time cost; synchronises).  Disabled in the reference's
@@ -2504,6 +2623,7 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view]) return fail(MS_ERR_STATE, "ms_update_mask: needs enable_cpw, ms_init_blender and a mesh for view %d", view);
     hipStream_t st = as_stream(stream);
     std::lock_guard<std::mutex> ulk(c->mesh_update_mu);
+    if (c->cfg.update_mask_margin > 0) return update_mask_async(c, view, st);
     if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
     if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
@@ -2559,7 +2679,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     S.own_mask = c->own_mask;
     S.pstride = c->pacc_stride;
     MS_CHECK(S.mode == 2 || views != nullptr, "ms_stitch: null views");
-    const PanoDesc &P = c->pano;
+    PanoDesc P = c->pano;              // (the pointers of the active copy of the tables are filled in under the lock below)
     SrcTable src{};
     for (int i = 0; i < F * N && S.mode != 2; ++i) {
         if (!((c->own_mask >> (i % N)) & 1u)) continue;       // another shard's view: not read
@@ -2615,13 +2735,23 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             mesh.x[v] = (const float *)mx.data; mesh.y[v] = (const float *)my.data; mesh.pitch[v] = c->map_pitch[v];
         }
     }
+    // which copy of the mask-dependent tables (enqueue-only ms_update_mask; same lock, same hand-over as the meshes)
+    const ViewDesc *vt = (const ViewDesc *)c->view_tab.p;
+    if (cpw && c->cfg.update_mask_margin > 0) {
+        if (c->tab_wait) MS_HIP(hipStreamWaitEvent(st, c->tab_ready, 0));
+        if (c->tab_active == 1) {
+            vt = (const ViewDesc *)c->alt.view_tab.p;
+            for (int l = 0; l <= nb; ++l) P.den[l] = c->alt.pano.den[l];
+            for (int l = 0; l < nb; ++l) P.pure[l] = c->alt.pano.pure[l];
+            P.mask = c->alt.pano.mask;
+        }
+    }
 
     // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
     // (the reference makes a fresh cuda::Stream per stitch_online call, timed.cpp:64, and relies on the NULL stream for ordering)
     if (c->last_stream_set && c->last_stream != st && c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
     c->last_stream = st; c->last_stream_set = true;
 
-    const ViewDesc *vt = (const ViewDesc *)c->view_tab.p;
     const uint8_t *g0 = (const uint8_t *)c->g0.p;
     uint8_t *gl = (uint8_t *)c->gl.p;
     int16_t *cl = (int16_t *)c->cl.p;
@@ -2915,7 +3045,8 @@ int ms_get_weight_level(const ms_ctx *c, int view, int level, ms_image *w)
     if (int e = ctx_check_view(c, view)) return e;
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_weight_level: call ms_init_blender first");
     MS_CHECK(w && level >= 0 && level <= c->pano.nb, "ms_get_weight_level: bad level %d", level);
-    const LevelDesc &L = c->h_views[view].lv[level];
+    if (c->tab_wait) MS_HIP(hipEventSynchronize(c->tab_ready));      // an enqueue-only ms_update_mask may still be filling the active copy
+    const LevelDesc &L = (c->tab_active == 1 ? c->alt.h_views : c->h_views)[view].lv[level];
     *w = ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.w, L.h, MS_32FC1};
     return MS_OK;
 }
@@ -2934,7 +3065,8 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
 {
     if (!c || !m) return fail(MS_ERR_INVALID, "null argument");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_result_mask: call ms_init_blender first");
-    *m = ms_image{c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
+    if (c->tab_wait) MS_HIP(hipEventSynchronize(c->tab_ready));
+    *m = ms_image{c->tab_active == 1 ? c->alt.result_mask.p : c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
     return MS_OK;
 }
 

@@ -75,6 +75,7 @@ struct Options {
     int views = 6, w = 1920, h = 1080, out_w = 3840, out_h = 1920, bands = 5, frames = 300;
     double hfov = 90.0;
     bool cpw = false, i420 = false, upload = true, nv12 = false, solve_mesh = false;
+    int update_mask = 0;                        // > 0: mb->update_mask(idx, ...) after every mesh swap (timed.cpp:598-605, commented out there), enqueue-only with this margin
     bool reference_calib = false;               // stitch_calib as the reference ships it: cylindrical warper, megapixel budgets of defs.h, seam-scale pipeline
     double work_mp = 0.6, seam_mp = 0.01, compose_mp = 1.4;      // WORK_MEGAPIX, SEAM_MEAGPIX, COMPOSE_MEGAPIX (defs.h:51-53)
     std::string dump;
@@ -176,6 +177,7 @@ int main(int argc, char **argv)
         else if (k == "--frames") o.frames = atoi(next());
         else if (k == "--cpw") o.cpw = true;
         else if (k == "--solve-mesh") o.cpw = o.solve_mesh = true;
+        else if (k == "--update-mask") { o.cpw = true; o.update_mask = atoi(next()); }
         else if (k == "--i420") o.i420 = true;
         else if (k == "--no-upload") o.upload = false;
         else if (k == "--nv12") o.nv12 = true;
@@ -216,7 +218,7 @@ int main(int argc, char **argv)
         } else {
             // BASELINE rig: the reference's rig model at full resolution, spherical warper with the full circle on out_w columns
             cal.rig = msshim::calibrateCameras(o.views, o.w, o.h, o.hfov, -1.0, 0.01, -1.0);
-            comp_owner.reset(new msshim::Compositor(o.views, o.w, o.h, MS_PROJ_SPHERICAL, (float)(o.out_w / (2.0 * M_PI)), o.bands, o.cpw, o.out_w, o.out_h, 1));
+            comp_owner.reset(new msshim::Compositor(o.views, o.w, o.h, MS_PROJ_SPHERICAL, (float)(o.out_w / (2.0 * M_PI)), o.bands, o.cpw, o.out_w, o.out_h, 1, o.cpw ? o.update_mask : 0));
             for (int i = 0; i < o.views; ++i) {
                 comp_owner->setCamera(i, cal.rig.K_compose[i], cal.rig.R[i]);
                 comp_owner->setGain(i, 1.0 + 0.02 * (i - (o.views - 1) / 2.0));
@@ -299,6 +301,7 @@ int main(int argc, char **argv)
 
         std::thread recalibrater;
         std::atomic<int> recalibrations{0};
+        std::vector<int> view_round(o.views, 0);          // the round whose mesh each view holds (read after the thread is joined)
         std::atomic<int> solver_iterations{0};
         std::atomic<long long> total_keypoints{0}, total_matches{0}, total_inliers{0};
         std::atomic<float> max_disp{0.f};
@@ -373,6 +376,8 @@ int main(int argc, char **argv)
                         std::vector<float> mx, my;
                         make_mesh(g.roi.width, g.roi.height, 10, 10, 0.1 * i + 0.37 * round, 6.0, mx, my);
                         comp.convertMeshToMap(i, mx.data(), my.data(), 10, 10, recal_stream);
+                        if (o.update_mask > 0) comp.update_mask(i, (ms_stream)recal_stream);      // timed.cpp:598-605
+                        view_round[i] = round;
                     }
                     ++round; ++recalibrations;
                 }
@@ -421,6 +426,42 @@ int main(int argc, char **argv)
         if (!failure.empty()) { fprintf(stderr, "stitch_app: %s\n", failure.c_str()); return 1; }
         if (!recal_failure.empty()) { fprintf(stderr, "stitch_app (recalibration): %s\n", recal_failure.c_str()); return 1; }
 
+        // --update-mask self-check: whatever interleaving of stitches, mesh swaps and enqueue-only mask updates happened above, the tables the context ended
+        // up with must be exactly what a fresh context gets from the same final meshes with the synchronous update_mask (one more frame through both)
+        int selfcheck = -1;
+        if (o.update_mask > 0 && !o.solve_mesh && !o.reference_calib) {
+            msshim::Compositor ref(o.views, o.w, o.h, MS_PROJ_SPHERICAL, (float)(o.out_w / (2.0 * M_PI)), o.bands, true, o.out_w, o.out_h, 1, 0);
+            for (int i = 0; i < o.views; ++i) {
+                ref.setCamera(i, cal.rig.K_compose[i], cal.rig.R[i]);
+                ref.setGain(i, 1.0 + 0.02 * (i - (o.views - 1) / 2.0));
+            }
+            ref.buildMaps(); ref.buildMasks(true); ref.init_gpu();
+            std::vector<DevMat> views(o.views);
+            std::vector<unsigned char> host((size_t)o.w * o.h * 3);
+            for (int i = 0; i < o.views; ++i) {
+                const ms_view_geom g = ref.viewGeom(i);
+                std::vector<float> mx, my;
+                make_mesh(g.roi.width, g.roi.height, 10, 10, 0.1 * i + (view_round[i] ? 0.37 * view_round[i] : 0.0), 6.0, mx, my);
+                ref.convertMeshToMap(i, mx.data(), my.data(), 10, 10, nullptr);
+                views[i].create(o.h, o.w, MS_8UC3, 3);
+                synth_frame(host.data(), o.w, o.h, (i + 3) % o.views);
+                HIPCHECK(hipMemcpy2D(views[i].data, views[i].step, host.data(), (size_t)o.w * 3, (size_t)o.w * 3, o.h, hipMemcpyHostToDevice));
+            }
+            for (int i = 0; i < o.views; ++i)
+                if (view_round[i]) ref.update_mask(i, nullptr);          // (round 0 = the start-up meshes: no mask update was issued for them)
+            DevMat a, b;
+            a.create(o.out_h, o.out_w, MS_8UC3, 3); b.create(o.out_h, o.out_w, MS_8UC3, 3);
+            HIPCHECK(hipMemset2D(a.data, a.step, 0, (size_t)o.out_w * 3, o.out_h)); HIPCHECK(hipMemset2D(b.data, b.step, 0, (size_t)o.out_w * 3, o.out_h));
+            comp.stitch_one(views, &a, (DevMat *)nullptr, (ms_stream)stitch_stream);
+            ref.stitch_one(views, &b, (DevMat *)nullptr, nullptr);
+            HIPCHECK(hipDeviceSynchronize());
+            std::vector<unsigned char> ha((size_t)o.out_w * o.out_h * 3), hb(ha.size());
+            HIPCHECK(hipMemcpy2D(ha.data(), (size_t)o.out_w * 3, a.data, a.step, (size_t)o.out_w * 3, o.out_h, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy2D(hb.data(), (size_t)o.out_w * 3, b.data, b.step, (size_t)o.out_w * 3, o.out_h, hipMemcpyDeviceToHost));
+            selfcheck = ha == hb ? 1 : 0;
+            for (auto &m : views) HIPCHECK(hipFree(m.data));
+            HIPCHECK(hipFree(a.data)); HIPCHECK(hipFree(b.data));
+        }
         for (unsigned char b : last_pano) checksum = (checksum ^ b) * 1099511628211ull;   // FNV-1a over the last 8U panorama
         if (!o.dump.empty()) {
             FILE *f = fopen(o.dump.c_str(), "wb");
@@ -429,10 +470,10 @@ int main(int argc, char **argv)
         }
         printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"upload\": %s, "
                "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"max_mesh_displacement_px\": %.2f, "
-               "\"orb_keypoints\": %lld, \"ratio_matches\": %lld, \"ransac_inliers\": %lld, \"checksum\": \"%016llx\"}\n",
+               "\"orb_keypoints\": %lld, \"ratio_matches\": %lld, \"ransac_inliers\": %lld, \"update_mask_margin\": %d, \"update_mask_equals_sync_rebuild\": %s, \"checksum\": \"%016llx\"}\n",
                o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.upload ? "true" : "false",
                consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), (double)max_disp.load(),
-               total_keypoints.load(), total_matches.load(), total_inliers.load(), checksum);
+               total_keypoints.load(), total_matches.load(), total_inliers.load(), o.update_mask, selfcheck < 0 ? "null" : (selfcheck ? "true" : "false"), checksum);
     } catch (const msshim::Error &e) {
         fprintf(stderr, "stitch_app: msstitch error %d: %s\n", e.code, e.what());
         return 1;

@@ -61,9 +61,10 @@ class Compositor {
 public:
     // num_bands as MultiBandBlender(try_gpu, num_bands); projection MS_PROJ_CYLINDRICAL is what calibration.cpp:100 ships
     Compositor(int num_views, int src_w, int src_h, int projection, float warp_scale, int num_bands, bool enable_local,
-               int out_w, int out_h, int frames_in_flight = 1)
+               int out_w, int out_h, int frames_in_flight = 1, int update_mask_margin = 0)
     {
         ms_config c{};
+        c.update_mask_margin = update_mask_margin;      // > 0: update_mask() only enqueues (timed.cpp:598-605 could call it after every mesh swap)
         c.struct_size = (unsigned)sizeof(ms_config);
         c.num_views = num_views; c.src_width = src_w; c.src_height = src_h; c.projection = projection; c.warp_scale = warp_scale;
         c.num_bands = num_bands; c.enable_cpw = enable_local; c.out_width = out_w; c.out_height = out_h; c.max_frames = frames_in_flight;
