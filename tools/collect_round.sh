@@ -5,6 +5,7 @@
 # 2. SQ / TCC / LDS counter passes, cfg2 and cfg3     -> <tag>_counters.txt, <tag>_cfg3_counters.txt
 # 3. kernel trace + FETCH/WRITE PMC passes, cfg3 then cfg2 (traffic_latest.json = cfg2, the bench default) + the per-kernel report
 # 4. live-path timeline (one frame per call)          -> <tag>_live_timeline.json
+# 5. shards / features / update_mask / host enqueue    -> <tag>_shards.json, <tag>_features.txt, <tag>_update_mask.txt, <tag>_host_enqueue.txt
 # Everything lands in gpurun_out/profiles_out/ (gpurun merges only gpurun_out/ back): copy into profiles/ and commit.
 set -uo pipefail
 TAG=${1:-r02}
@@ -20,5 +21,10 @@ bash tools/profile_traffic.sh ${TAG}_cfg3 cfg3 16 > $PO/traffic_cfg3.log 2>&1
 bash tools/profile_traffic.sh $TAG cfg2 16 > $PO/traffic.log 2>&1
 python tools/report.py $TAG > $PO/report.log 2>&1
 bash tools/live_timeline.sh $TAG > /dev/null 2>&1
+# 5. the two intra-frame sharding schemes on one GPU, the recalibration front-end, the enqueue-only mask update
+python tools/refresh_view_shards.py $TAG > $PO/shards.log 2>&1 && cp gpurun_out/${TAG}_shards.json $PO/
+python tools/bench_features.py $TAG > $PO/features.log 2>&1 && cp gpurun_out/${TAG}_features.txt $PO/
+python tools/time_update_mask.py 2>&1 | grep margin > $PO/${TAG}_update_mask.txt
+python tools/host_enqueue.py 2>&1 | grep calls > $PO/${TAG}_host_enqueue.txt
 cp profiles/${TAG}_* profiles/traffic_latest.json $PO/ 2>/dev/null
 du -sh gpurun_out; ls $PO

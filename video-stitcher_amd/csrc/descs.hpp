@@ -6,7 +6,7 @@ namespace ms {
 
 constexpr int MAX_LEVELS = 8;     // num_bands <= 7
 constexpr int MAX_VIEWS = 16;
-constexpr int MAX_SRC = 128;      // frames * views per ms_stitch call
+constexpr int MAX_SRC = 192;      // frames * views per ms_stitch call
 constexpr int MAX_FRAMES = 32;    // frames per ms_stitch call
 
 struct LevelDesc {
