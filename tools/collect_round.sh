@@ -20,11 +20,11 @@ cp gpurun_out/counters_${TAG}_cfg3.txt profiles/${TAG}_cfg3_counters.txt
 bash tools/profile_traffic.sh ${TAG}_cfg3 cfg3 16 > $PO/traffic_cfg3.log 2>&1
 bash tools/profile_traffic.sh $TAG cfg2 16 > $PO/traffic.log 2>&1
 python tools/report.py $TAG > $PO/report.log 2>&1
+cp profiles/${TAG}_* profiles/traffic_latest.json $PO/ 2>/dev/null
 bash tools/live_timeline.sh $TAG > /dev/null 2>&1
 # 5. the two intra-frame sharding schemes on one GPU, the recalibration front-end, the enqueue-only mask update
 python tools/refresh_view_shards.py $TAG > $PO/shards.log 2>&1 && cp gpurun_out/${TAG}_shards.json $PO/
 python tools/bench_features.py $TAG > $PO/features.log 2>&1 && cp gpurun_out/${TAG}_features.txt $PO/
 python tools/time_update_mask.py 2>&1 | grep margin > $PO/${TAG}_update_mask.txt
 python tools/host_enqueue.py 2>&1 | grep calls > $PO/${TAG}_host_enqueue.txt
-cp profiles/${TAG}_* profiles/traffic_latest.json $PO/ 2>/dev/null
 du -sh gpurun_out; ls $PO
