@@ -604,8 +604,8 @@ def test_stitch_i420_needs_the_tiled_band_path(ms, cuda):
 def test_create_destroy_cycles_release_device_memory(ms, cuda):
     """Every device buffer of a context belongs to it (RAII): create -> calibrate -> set meshes -> update_mask -> stitch -> destroy,
     repeated, must not lower the free device memory (owner maps, re-warped masks and the mesh displacement words used to leak)."""
-    def cycle():
-        comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
+    def cycle(k=0):
+        comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True, update_mask_margin=8 * (k % 2))      # both forms of update_mask (the second set of tables too)
         for i in range(cfg["n"]):
             r = comp.view_geom(i).roi
             comp.set_mesh(i, *synth.mesh(r.width, r.height, 6, 6, phase=0.3 * i, amp=3.0))
@@ -619,8 +619,8 @@ def test_create_destroy_cycles_release_device_memory(ms, cuda):
     cycle()
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
-    for _ in range(6):
-        cycle()
+    for k in range(6):
+        cycle(k)
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (1 << 20), "six create/destroy cycles lost %d bytes of device memory" % (free0 - free1)

@@ -19,8 +19,9 @@ pytestmark = pytest.mark.gpu
 def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed):
     hfov = min(130.0, 360.0 / n * spread)
     proj = ms.PROJ_CYLINDRICAL if cyl else ms.PROJ_SPHERICAL
-    comp = ms.Compositor(n, (w, h), proj, synth.warp_scale(out_w), num_bands=bands, enable_cpw=cpw, out_size=(out_w, out_w // 2))
     rng = np.random.default_rng(seed)
+    margin = int(rng.choice([0, 6, 16])) if cpw else 0      # > 0: work lists planned for masks that move (enqueue-only update_mask); must not change a result
+    comp = ms.Compositor(n, (w, h), proj, synth.warp_scale(out_w), num_bands=bands, enable_cpw=cpw, out_size=(out_w, out_w // 2), update_mask_margin=margin)
     gains = [float(g) for g in rng.uniform(0.9, 1.1, n)]
     for i in range(n):
         comp.set_camera(i, *synth.camera(n, w, h, hfov, i)); comp.set_gain(i, gains[i])
@@ -88,6 +89,20 @@ def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, ban
         assert np.array_equal(host(slabs[0]), host(ms.bgr_to_i420(canvas[y0:y0 + rows])))
     else:                         # small pyramids never reach the tiled level-0 kernel: the call must refuse, not approximate
         assert pg.dst_roi.width % 8 != 0 or pg.num_bands <= 2 or rows == 0
+    if margin:
+        # enqueue-only update_mask of one view: the oracle's update_mask if the mesh stays within the margin, nothing otherwise
+        u = int(rng.integers(0, n))
+        within = comp.mesh_displacement(u) <= margin
+        comp.update_mask(u)
+        comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+        torch.cuda.synchronize()
+        if within:
+            b.update_mask(u, *meshes[u])
+        for i in range(n):
+            xm, ym = [host(t) for t in comp.maps(i)]
+            b.stitch_online(i, frames[i], xm, ym, gains[i], *meshes[i])
+        ref2, refmask2 = b.blend()
+        assert np.array_equal(host(out16), ref2) and np.array_equal(host(comp.result_mask()), refmask2), "update_mask of view %d (within margin: %s)" % (u, within)
     b.close(); comp.close()
 
 
