@@ -745,6 +745,9 @@ def main():
         P_list.append((g.roi.width + g.left + g.right) * (g.roi.height + g.top + g.bottom))
     b_alg_frame = synth.algorithmic_bytes((cfg["w"], cfg["h"]), P_list, Q, (cfg["out_w"], cfg["out_h"]), warped_px=A, cpw=cpw)
     gpu_ms_step = float(sum(kmean.values()))
+    src_bytes = cfg["n"] * 3.0 * cfg["w"] * cfg["h"]
+    b_min_frame = src_bytes + 4.0 * (4.0 / 3.0) * float(sum(P_list)) + 3.0 * cfg["out_w"] * cfg["out_h"]
+    b_ref_frame = src_bytes + 20.0 * A + 96.0 * float(sum(P_list)) + (95.0 + 9.0) * Q
 
     # PMC-measured HBM bytes (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/profile_traffic.sh on the same workload, calibrated on a 1 GiB
     # copy): read from the committed summary -- counters cannot be collected inside this run -- and labelled as such
@@ -792,6 +795,8 @@ def main():
                                "achieved_GBps": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 1e9, 1),
                                "frac": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),
                                "wall_frac": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4),
+                               # SURVEY 8(d) bounds: B_min = perfect fusion (inputs + weight pyramids + output), B_ref = the reference's own pass structure
+                               "b_min_bytes_per_frame": int(b_min_frame), "b_ref_bytes_per_frame": int(b_ref_frame),
                                "hbm_bytes_per_frame": (int(traffic_call / Fs) if traffic_call else None),
                                "frac_traffic": (round(traffic_call / (gpu_ms_step * 1e-3) / 8e12, 4) if traffic_call else None),
                                "wall_frac_traffic": (round(traffic_call / Fs * total_frames / world / elapsed / 8e12, 4) if traffic_call else None),
