@@ -17,6 +17,18 @@ pytestmark = pytest.mark.gpu
 @given(n=st.integers(2, 6), w=st.integers(48, 150), h=st.integers(40, 110), spread=st.floats(1.25, 1.9), out_w=st.sampled_from([192, 256, 320, 448]),
        bands=st.integers(1, 4), cyl=st.booleans(), seams=st.booleans(), cpw=st.booleans(), seed=st.integers(0, 10 ** 6))
 def test_random_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed):
+    check_rig(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed)
+
+
+@settings(max_examples=int(os.environ.get("MS_TEST_EXAMPLES_MEDIUM", 6)), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(n=st.integers(3, 6), w=st.integers(300, 640), h=st.integers(200, 400), spread=st.floats(1.3, 1.8), out_w=st.sampled_from([1024, 1536, 2048]),
+       bands=st.integers(3, 5), cyl=st.booleans(), seams=st.booleans(), cpw=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_random_medium_rig_matches_oracle(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed):
+    """The same draw at sizes where every level takes the tiled / vectorised kernels, the fused tails, owner cells and XCD-ordered work lists."""
+    check_rig(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed)
+
+
+def check_rig(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seams, cpw, seed):
     hfov = min(130.0, 360.0 / n * spread)
     proj = ms.PROJ_CYLINDRICAL if cyl else ms.PROJ_SPHERICAL
     rng = np.random.default_rng(seed)
