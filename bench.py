@@ -657,6 +657,9 @@ def main():
     live_comp = None
     if not args.no_verify or not args.no_live:
         live_comp = make_comp(1)
+    if live_comp is not None and mesh_pool and recal["count"] > 0:      # the meshes the batch contexts held during the last pass
+        for i in range(cfg["n"]):
+            live_comp.set_mesh(i, *mesh_pool[(recal["count"] - 1) % 4][i])
     if not args.no_verify:
         b = state["last_b"]
         picks = sorted({k * Fs + j for k in range(S) for j in (0, Fs // 2, Fs - 1)})

@@ -1453,6 +1453,8 @@ struct ms_ctx {
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
     int n_warp_tiles = 0, n_down_tiles[MAX_LEVELS] = {}, n_blend_tiles[MAX_LEVELS] = {};
     int warp_lds_tiles = 0;            // tiles whose source bounding box fits a staging buffer of k_warp_a
+    bool warp_aligned = false;         // projection warp with the aligned 12-byte tap reads (k_warp_t<.., AL = true>): chosen from the tiles' minification
+    double warp_minification = 0;      // mean source columns per output column over the warp tiles
     int n_cus = 256;
     double plan_fraction = 1.0;        // needed level-0 pixels / padded pixels
     // CPW mesh maps, double buffered
@@ -1694,11 +1696,19 @@ static int build_plan(ms_ctx *c)
         if (!tiles.empty()) {
             MS_HIP(hipMemcpy(c->warp_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
             if (c->warp_tiled) {   // source bounding box of every tile (static: the projection maps do not change per frame)
-                k_tile_bbox<<<c->n_warp_tiles, dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX))>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width);
+                k_tile_bbox<<<c->n_warp_tiles, dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX))>>>((WarpTile *)c->warp_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width, 0);
                 MS_LAUNCH_CHECK();
                 MS_HIP(hipMemcpy(tiles.data(), c->warp_tiles.p, tiles.size() * sizeof(WarpTile), hipMemcpyDeviceToHost));
-                for (const WarpTile &t : tiles)
+                double sw_sum = 0; int sw_n = 0;
+                for (const WarpTile &t : tiles) {
                     if (t.flags & 1) ++c->warp_lds_tiles;
+                    if (t.sw > 0) { sw_sum += t.sw; ++sw_n; }
+                }
+                // aligned tap reads pay where neighbouring samples share dwords; at strong minification every read is isolated and the 28 extra
+                // registers (4 instead of 6 waves per SIMD) cost more than the alignment saves (measured: 1.9x -6 %, 2.7x +17 %)
+                c->warp_minification = sw_n ? sw_sum / sw_n / WARP_TW : 0.0;
+                c->warp_aligned = c->warp_minification > 0 && c->warp_minification < 2.3;
+                if (const char *e = getenv("MS_WARP_ALIGNED")) c->warp_aligned = atoi(e) != 0;
                 if (getenv("MS_DEBUG_PLAN")) {
                     int big = 0, last = 0, interior = 0; long long bytes = 0;
                     for (const WarpTile &t : tiles) {
@@ -1706,8 +1716,11 @@ static int build_plan(ms_ctx *c)
                         else if (t.sw > 0 && 16 * warp_lds_np(t.sw) * t.sh > WA_BUF_BYTES) ++big; else ++last;
                         interior += (t.flags & 4) != 0;
                     }
-                    fprintf(stderr, "[plan] warp tiles %zu: staged %d (mean %.0f B), box too large %d, last row / empty %d; interior %d\n", tiles.size(), c->warp_lds_tiles,
-                            c->warp_lds_tiles ? (double)bytes / c->warp_lds_tiles : 0.0, big, last, interior);
+                    int al = 0;
+                    for (const WarpTile &t : tiles) al += (t.flags & 8) != 0;
+                    fprintf(stderr, "[plan] warp tiles %zu: staged %d (mean %.0f B), box too large %d, last row / empty %d; interior %d; clear of the last source row %d; "
+                                    "minification %.2f -> %s tap reads\n", tiles.size(), c->warp_lds_tiles,
+                            c->warp_lds_tiles ? (double)bytes / c->warp_lds_tiles : 0.0, big, last, interior, al, c->warp_minification, c->warp_aligned ? "aligned" : "unaligned");
                 }
             }
         }
@@ -1749,6 +1762,11 @@ static int build_plan(ms_ctx *c)
         c->n_stage1_tiles = (int)tiles.size();
         if (int e = c->stage1_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
         MS_HIP(hipMemcpy(c->stage1_tiles.p, tiles.data(), tiles.size() * sizeof(WarpTile), hipMemcpyHostToDevice));
+        if (!tiles.empty() && c->warp_tiled) {     // flags bit 3 of every stage-1 tile: no sample reads the last source row (aligned tap reads allowed)
+            k_tile_bbox<<<c->n_stage1_tiles, dim3(WARP_BX, std::min(WARP_TH, 256 / WARP_BX))>>>((WarpTile *)c->stage1_tiles.p, (const ViewDesc *)c->view_tab.p, c->cfg.src_height, c->cfg.src_width, 1);
+            MS_LAUNCH_CHECK();
+            MS_HIP(hipDeviceSynchronize());
+        }
     }
     // pyrDown tiles: output tiles of level l+1
     for (int l = 0; l < nb; ++l) {
@@ -2667,6 +2685,14 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
         else K<MS_UNPAREN TARGS MS_PROJ_PLANE><<<MS_UNPAREN CFG>>>(__VA_ARGS__);                                                    \
     } while (0)
 
+// k_stage1_t<PROJ, AL>: the projection comes first there
+#define MS_PROJ_AL_LAUNCH(K, AL, CFG, ...)                                                                                  \
+    do {                                                                                                                    \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) K<MS_PROJ_SPHERICAL, AL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);               \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) K<MS_PROJ_CYLINDRICAL, AL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);      \
+        else K<MS_PROJ_PLANE, AL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);                                                          \
+    } while (0)
+
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
                        int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{}, ms_image *out_i420 = nullptr)
 {
@@ -2775,15 +2801,21 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
         if (c->cfg.debug_simple_kernels == 0)
-            MS_PROJ_LAUNCH(k_stage1_t, (), (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH / 2, 256 / WARP_BX)), 0, st), 
-                (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
+        {
+            if (c->warp_aligned)
+                MS_PROJ_AL_LAUNCH(k_stage1_t, true, (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH / 2, 256 / WARP_BX)), 0, st),
+                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
+            else
+                MS_PROJ_AL_LAUNCH(k_stage1_t, false, (dim3(c->n_stage1_tiles, 1, F), dim3(WARP_BX, std::min(WARP_TH / 2, 256 / WARP_BX)), 0, st),
+                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp);
+        }
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
-            MS_PROJ_LAUNCH(k_warp_t, (true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
+            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
@@ -2799,7 +2831,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             const int grid = (int)std::min<long long>(items, (long long)c->n_cus * (160 * 1024 / (2 * WA_BUF_BYTES)));
             MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         } else
-            MS_PROJ_LAUNCH(k_warp_t, (false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
+        {
+            if (c->warp_aligned)
+                MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
+            else
+                MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, 1, F), dim3(WARP_BX, WARP_BY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p);
+        }
     } else if (c->cfg.cpu_flavour_remap != 0) {
         k_warp<false, true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
             vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);

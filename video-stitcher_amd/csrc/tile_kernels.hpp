@@ -46,6 +46,21 @@ __device__ __forceinline__ Px2 load_px2(const uint8_t *p)
     __builtin_memcpy(&v, p, 8);
     return Px2{v.x, v.y};
 }
+// The same 8 bytes out of ONE dword-aligned 12-byte read (global_load_dwordx3) and two v_alignbyte_b32 by the address's low two bits: an unaligned
+// 8-byte gather costs the texture-address path 13 % more than an aligned one (profiles/r02_warp_probes.txt: 242 vs 210 us), the aligned 12-byte form
+// with the two extra VALU operations per tap row 223 us.  It reads up to 3 bytes before and 4 bytes after the 8-byte window: fine inside an image
+// (the neighbouring pixels / the next row), NOT behind the last image row of a caller's buffer -- tiles that sample it keep the unaligned read.
+struct Px3 { unsigned d0, d1, d2; };
+__device__ __forceinline__ Px3 load_px3(const uint8_t *p)
+{
+    Px3 v;
+    __builtin_memcpy(&v, __builtin_assume_aligned((const uint8_t *)((uintptr_t)p & ~(uintptr_t)3), 4), 12);
+    return v;
+}
+__device__ __forceinline__ Px2 px3_to_px2(const Px3 &q, unsigned addr_lo)      // v_alignbyte_b32 uses the low two bits of its shift operand
+{
+    return Px2{__builtin_amdgcn_alignbyte(q.d1, q.d0, addr_lo), __builtin_amdgcn_alignbyte(q.d2, q.d1, addr_lo)};
+}
 // uniform base + 32-bit lane offset: the address arithmetic stays in one VGPR (global_load ... v_off, s[base])
 __device__ __forceinline__ Px2 load_px2(const uint8_t *base, unsigned off) { return load_px2(base + off); }
 // Byte offset of the two tap rows of a sample, clamped so that both 8-byte reads stay inside the image: rows
@@ -182,22 +197,25 @@ constexpr int WA_BUF_BYTES = 8 * 1024;                    // one staged tile; a 
 
 // Bounding box (in source pixels) of every in-image bilinear tap of a tile: run once when the tables are built.
 // flags bit 0 = the box fits a staging buffer and does not touch the last image row (whose 16-byte chunks could run past the buffer).
-__global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int src_rows, int src_cols)
+// stage1 != 0: the tiles are CPW stage-1 tiles (origin in warped-view pixels, no reflect pad): only flags bit 3 is of interest there.
+__global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int src_rows, int src_cols, int stage1)
 {
-    __shared__ int s_box[4];
+    __shared__ int s_box[5];
     WarpTile T = tiles[blockIdx.x];
     const ViewDesc &V = views[T.view];
-    if (threadIdx.x == 0 && threadIdx.y == 0) { s_box[0] = s_box[2] = 0x7fffffff; s_box[1] = s_box[3] = -1; }
+    if (threadIdx.x == 0 && threadIdx.y == 0) { s_box[0] = s_box[2] = 0x7fffffff; s_box[1] = s_box[3] = -1; s_box[4] = -1; }
     __syncthreads();
-    const int x = T.x0 + 4 * (int)threadIdx.x;
-    for (int y = T.y0 + (int)threadIdx.y; y < T.y0 + WARP_TH; y += (int)blockDim.y)
-    if (x < V.pw && y < V.ph) {
+    const int ox = stage1 ? V.left : 0, oy = stage1 ? V.top : 0;      // stage-1 tiles: the same coordinates through the padded position (identity reflect inside the view)
+    const int x = T.x0 + 4 * (int)threadIdx.x + ox;
+    for (int y = T.y0 + (int)threadIdx.y + oy; y < T.y0 + oy + WARP_TH; y += (int)blockDim.y)
+    if (stage1 ? (x - ox < V.aw && y - oy < V.ah) : (x < V.pw && y < V.ph)) {
         float xc[4], yc[4];
         MeshTable none{};
-        warp_coords4<false>(V, none, T.view, x, y, xc, yc);
+        warp_coords4<false>(V, none, T.view, min(x, V.pw - 4), y, xc, yc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const Taps t = make_taps(xc[k], yc[k], src_rows, src_cols);
+            atomicMax(&s_box[4], min(max(f2i_rd(yc[k]), 0), src_rows - 2) + 1);       // lower tap row of the (clamped) read of ANY sample, see tap_offset
             if (t.fast) {
                 atomicMin(&s_box[0], t.x1); atomicMax(&s_box[1], t.x1 + 1);
                 atomicMin(&s_box[2], t.y1); atomicMax(&s_box[3], t.y1 + 1);
@@ -206,7 +224,8 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
     }
     __syncthreads();
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        T.flags &= ~1;
+        T.flags &= ~(1 | 8);
+        if (s_box[4] < src_rows - 1) T.flags |= 8;          // no sample of this tile reads the last image row: the aligned 12-byte tap reads stay inside the image
         if (s_box[1] < 0) { T.sx0 = T.sy0 = T.sw = T.sh = 0; }
         else {
             const int sx0 = s_box[0] & ~3;
@@ -229,7 +248,7 @@ constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = WARP_BX x WARP_BY lanes
 // One tile of Gaussian level 0 with the taps gathered straight from global memory (unaligned 8-byte reads): lane (tx, ty) of a
 // WARP_BX x WARP_BY arrangement.  Software pipeline over the WARP_NG row groups of the lane -- the tap reads of group g+1 are in
 // flight while group g is blended.  PROJ = the context's projection (compile-time: no per-pixel branches in the coordinate code).
-template <bool CPW, int PROJ>
+template <bool CPW, int PROJ, bool AL = false>      // AL: aligned 12-byte tap reads (see Px3); chosen per tile by the caller, never per lane
 __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
                                                  const SrcTable &src, int src_rows, int src_cols, const MeshTable &mesh,
                                                  const uint8_t *__restrict__ stage, long long stage_stride,
@@ -251,6 +270,10 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
     const size_t plane = (size_t)L.h * L.pitch;
     float xc[2][4], yc[2][4];
     Px2 r1[2][4], r2[2][4];
+    // AL: the raw tap reads in flight are 12 aligned bytes per tap row + the 2-bit byte shifts of the group's 4 pixels
+    Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];
+    unsigned sh1[2] = {0u, 0u}, sh2[2] = {0u, 0u};
+    const unsigned sp_lo = (unsigned)(uintptr_t)sp;
     // the 1-D tables of the projection are read ONCE, up front (column terms of the lane's 4 pixels, row term of each row group):
     // building the coordinates of a group is then pure arithmetic, with no load between it and the tap reads
     float2 ct[4], rt[WARP_NG];
@@ -302,8 +325,16 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
 #if defined(MS_PROBE) && MS_PROBE == 10      // no-gather probe (WRONG pixels): no tap reads at all
             r1[b][k] = Px2{off, off * 3u}; r2[b][k] = Px2{off ^ 0x55u, off + 7u};
 #else
-            r1[b][k] = load_px2(sp, off);
-            r2[b][k] = load_px2(sp + sstep, off);
+            if (AL) {
+                q1[AL ? b : 0][AL ? k : 0] = load_px3(sp + off);
+                q2[AL ? b : 0][AL ? k : 0] = load_px3(sp + sstep + off);
+                const unsigned a = sp_lo + off;
+                if (k == 0) { sh1[b] = a & 3u; sh2[b] = (a + sstep) & 3u; }
+                else { sh1[b] |= (a & 3u) << (2 * k); sh2[b] |= ((a + sstep) & 3u) << (2 * k); }
+            } else {
+                r1[b][k] = load_px2(sp, off);
+                r2[b][k] = load_px2(sp + sstep, off);
+            }
 #endif
         }
     };
@@ -319,6 +350,15 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
             for (int k = 0; k < 4; k += 2) {
                 float o[2][3];
                 Taps t[2];
+#if !(defined(MS_PROBE) && MS_PROBE == 10)
+                if (AL) {       // the pair's 8-byte windows out of the aligned reads, right before use (keeps the raw reads, not both forms, live)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        r1[b][k + j] = px3_to_px2(q1[AL ? b : 0][AL ? k + j : 0], sh1[b] >> (2 * (k + j)));
+                        r2[b][k + j] = px3_to_px2(q2[AL ? b : 0][AL ? k + j : 0], sh2[b] >> (2 * (k + j)));
+                    }
+                }
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
@@ -346,15 +386,23 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
     }
 }
 
-template <bool CPW, int PROJ>
+// AL: aligned 12-byte tap reads (Px3) for the tiles that allow them -- 28 more VGPRs (4 instead of 6 waves per SIMD), so the context picks the kernel:
+// aligned where neighbouring samples share dwords (moderate minification: config 2, -6 %; the CPW mesh remap, -10 %), unaligned where every tap
+// read is isolated and occupancy matters more (config 5's 2.7x minification: +17 % with AL).
+template <bool CPW, bool AL, int PROJ>
 __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
                                                          uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
 {
     const WarpTile T = tiles[blockIdx.x];
-    warp_tile_direct<CPW, PROJ>(T, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
-                                g0, g0_stride, tabs);
+    // aligned tap reads unless a sample of the tile reads the last row of a caller's image (flags bit 3, k_tile_bbox); the CPW stage buffer is ours and padded
+    if (AL && (CPW || (T.flags & 8)))
+        warp_tile_direct<CPW, PROJ, true>(T, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                          g0, g0_stride, tabs);
+    else
+        warp_tile_direct<CPW, PROJ, false>(T, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                           g0, g0_stride, tabs);
 }
 
 // ---- the same tiles with the source staged in LDS by asynchronous LDS-DMA: persistent, self-pipelined waves -------------------
@@ -549,14 +597,11 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
 
 // ---- CPW stage 1: images[i] = gain(remap(full_img, x_map, y_map)) (timed.cpp:90-94), 4 px per lane --------------
 // Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).
-template <int PROJ>
-__global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
-                                                  SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp)
+template <int PROJ, bool AL>
+__device__ __forceinline__ void stage1_tile(const WarpTile &T, int f, const ViewDesc *__restrict__ views, int n_views,
+                                            const SrcTable &src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
 {
-    const WarpTile T = tiles[blockIdx.x];
-    const int f = blockIdx.z, v = T.view;
-    // the mesh of this view moves no sample further than the bound the plan assumed: stage 2 never reads this tile
-    if (!(T.flags & 2) && *disp.p[v] <= disp.limit_bits) return;
+    const int v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * (int)threadIdx.x;
     if (x >= V.aw) return;
@@ -578,6 +623,9 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
     constexpr int S1_NG = WARP_TH / S1_BY;                                                 // row groups per lane
     float xc[2][4], yc[2][4];
     Px2 r1[2][4], r2[2][4];
+    Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];      // AL: aligned 12-byte tap reads, as in warp_tile_direct
+    unsigned sh1[2] = {0u, 0u}, sh2[2] = {0u, 0u};
+    const unsigned sp_lo = (unsigned)(uintptr_t)sp;
     auto issue = [&](int y, int b) {
         if (y >= V.ah) return;
         const float2 rt = V.rowtab[y];
@@ -585,8 +633,16 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
         for (int k = 0; k < 4; ++k) {
             warp_combine(PROJ, ct[k], rt, V.wp, xc[b][k], yc[b][k]);
             const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
-            r1[b][k] = load_px2(sp, off);
-            r2[b][k] = load_px2(sp + sstep, off);
+            if (AL) {
+                q1[AL ? b : 0][AL ? k : 0] = load_px3(sp + off);
+                q2[AL ? b : 0][AL ? k : 0] = load_px3(sp + sstep + off);
+                const unsigned a = sp_lo + off;
+                if (k == 0) { sh1[b] = a & 3u; sh2[b] = (a + sstep) & 3u; }
+                else { sh1[b] |= (a & 3u) << (2 * k); sh2[b] |= ((a + sstep) & 3u) << (2 * k); }
+            } else {
+                r1[b][k] = load_px2(sp, off);
+                r2[b][k] = load_px2(sp + sstep, off);
+            }
         }
     };
     issue(T.y0 + (int)threadIdx.y, 0);
@@ -600,6 +656,13 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
         for (int k = 0; k < 4; k += 2) {
             float o[2][3];
             Taps t[2];
+            if (AL) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    r1[b][k + j] = px3_to_px2(q1[AL ? b : 0][AL ? k + j : 0], sh1[b] >> (2 * (k + j)));
+                    r2[b][k + j] = px3_to_px2(q2[AL ? b : 0][AL ? k + j : 0], sh2[b] >> (2 * (k + j)));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
@@ -621,6 +684,17 @@ __global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ t
                 for (int c = 0; c < 3; ++c) { const int i = 3 * k + c; d[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3))); }
         }
     }
+}
+
+template <int PROJ, bool AL>
+__global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                  SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    // the mesh of this view moves no sample further than the bound the plan assumed: stage 2 never reads this tile
+    if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;
+    if (AL && (T.flags & 8)) stage1_tile<PROJ, true>(T, (int)blockIdx.z, views, n_views, src, srows, scols, stage, stage_stride);
+    else stage1_tile<PROJ, false>(T, (int)blockIdx.z, views, n_views, src, srows, scols, stage, stage_stride);
 }
 
 // ---- pyrDown, tile list, DOWN_ROWS (4) rows x 4 cols per lane (block 32 x 8): 11 input rows for 4 output rows (2 rows per lane: 7 for 2, 16 % slower) ----
