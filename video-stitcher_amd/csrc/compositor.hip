@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__
             const uint8_t *mrow = P.mask + mul24(y, P.mask_pitch);
             const int nvalid = min(8, P.fw - x0);
             uint2 mk8 = make_uint2(0u, 0u);                 // result mask of the 8 pixels: bytes 0 / 255 (k_finish_den)
-            if (nvalid == 8) mk8 = load8_a1(mrow + x0);
+            if (nvalid == 8) __builtin_memcpy(&mk8, __builtin_assume_aligned(mrow + x0, 8), 8);
             else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -2224,13 +2224,13 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         }
     }
     P.fw = c->bg.dst_roi_final.width; P.fh = c->bg.dst_roi_final.height;
-    P.mask_pitch = P.fw;
+    P.mask_pitch = round_up(P.fw, 16);      // rows start on 16-byte boundaries: the level-0 band kernel reads 8 mask bytes per lane with one aligned load
     P.alpha = (float)(1. / 255.);
     P.canvas_x = c->canvas_x; P.canvas_y = c->canvas_y; P.out_w = c->cfg.out_width; P.out_h = c->cfg.out_height;
     P.i_y0 = std::max(0, c->canvas_y & ~1); P.i_rows = std::max(0, std::min(c->cfg.out_height & ~1, (c->canvas_y + P.fh + 1) & ~1) - P.i_y0);
     c->den_total = den_total;
     if (int e = c->den.alloc(den_total * sizeof(float))) return e;
-    if (int e = c->result_mask.alloc((size_t)P.fw * P.fh)) return e;
+    if (int e = c->result_mask.alloc((size_t)P.mask_pitch * P.fh)) return e;
     MS_HIP(hipMemsetAsync(c->den.p, 0, den_total * sizeof(float), st));
     for (int l = 0; l <= nb; ++l) P.den[l] = (const float *)c->den.p + c->den_off[l];
     P.mask = (const uint8_t *)c->result_mask.p;
@@ -2347,7 +2347,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         if (int e = A.weights.alloc(c->w_total * sizeof(float))) return e;
         if (int e = A.wm0.alloc(c->wm0_total)) return e;
         if (int e = A.den.alloc(c->den_total * sizeof(float))) return e;
-        if (int e = A.result_mask.alloc((size_t)c->pano.fw * c->pano.fh)) return e;
+        if (int e = A.result_mask.alloc((size_t)c->pano.mask_pitch * c->pano.fh)) return e;
         if (int e = A.pure_maps.alloc(std::max<size_t>(1, c->pure_total))) return e;
         if (int e = A.view_tab.alloc(sizeof(ViewDesc) * N)) return e;
         A.h_views = c->h_views;
