@@ -163,7 +163,7 @@ __host__ __device__ inline void tail_range(const int *w, int l0, int nb, int str
     a[nb] = strip * TAIL_STRIP; b[nb] = min(a[nb] + TAIL_STRIP, w[nb]);
     for (int l = nb - 1; l >= l0; --l) { a[l] = max(2 * a[l + 1] - 2, 0); b[l] = min(2 * b[l + 1] + 2, w[l]); }
 }
-__global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ views, int n_views, int l0, int nb, int max_strips,
+__global__ void __launch_bounds__(1024) k_down_tail(const ViewDesc *__restrict__ views, int n_views, int l0, int nb, int max_strips,
                                                    uint8_t *__restrict__ gl, long long gl_stride, unsigned own_mask)
 {
     extern __shared__ uint8_t s_lv[];
@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
     if (strip * TAIL_STRIP >= w[nb]) return;
     tail_range(w, l0, nb, strip, a, b);
     uint8_t *base = gl + (size_t)f * gl_stride;
-    const int tx = threadIdx.x, ty = threadIdx.y;           // block 64 x 4
+    const int tx = threadIdx.x, ty = threadIdx.y;           // block 64 x 4 (64 x 16 in live mode: the same strip on four times the lanes)
+    const int nthr = (int)(blockDim.x * blockDim.y);
     uint8_t *cur = s_lv;
     {
         const LevelDesc &La = V.lv[l0];
@@ -184,18 +185,18 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
         const int wl = b[l0] - a[l0];
         // 8 columns per 8-byte read (a[l0] is even: the address is 2-byte aligned, the hardware takes it), four reads in flight per lane before the first LDS write
         const int nchunk = (wl + 7) >> 3, total = La.h * nchunk, tid = ty * 64 + tx;
-        for (int i0 = tid; i0 < total; i0 += 1024) {
+        for (int i0 = tid; i0 < total; i0 += 4 * nthr) {
             uint2 q[4];
             int yy[4], cc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + 256 * u, total - 1);
+                const int i = min(i0 + nthr * u, total - 1);
                 yy[u] = i / nchunk; cc[u] = i - yy[u] * nchunk;
                 __builtin_memcpy(&q[u], in + (size_t)yy[u] * La.pitch + 8 * cc[u], 8);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (i0 + 256 * u >= total) continue;
+                if (i0 + nthr * u >= total) continue;
                 const unsigned d[2] = {q[u].x, q[u].y};
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256) k_down_tail(const ViewDesc *__restrict__ 
         // flat index over the strip's outputs: every lane works (strips are only 16..40 columns wide); i -> (y, xo) with one fp32
         // multiply: (i + 0.5) / wo is at least 0.5 / 64 away from an integer, far more than the fp32 error for i < 2^16
         const float rwo = 1.0f / (float)wo;
-        for (int i = ty * 64 + tx; i < wo * Lo.h; i += 256) {
+        for (int i = ty * 64 + tx; i < wo * Lo.h; i += nthr) {
             const int y = (int)(((float)i + 0.5f) * rwo), xo = i - y * wo;
             const int x = a[l + 1] + xo;
             int ry[5], cx[5];
@@ -2850,7 +2851,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     const int dt_l0 = c->tail_l0, dt_lds = c->tail_lds, dt_strips = c->tail_strips;     // (starting the reduce tail a level finer was measured slower even for one frame)
     for (int l = 0; l < nb; ++l) {
         if (l == dt_l0 && c->cfg.debug_simple_kernels == 0) {
-            k_down_tail<<<dim3(F * N * 3 * dt_strips), blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask & c->needed_mask);
+            k_down_tail<<<dim3(F * N * 3 * dt_strips), F <= 2 ? dim3(64, 16) : blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask & c->needed_mask);
             MS_LAUNCH_CHECK();
             if (int e = mark("k_down_tail")) return e;
             break;
