@@ -701,16 +701,17 @@ __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, u
 }
 
 template <bool L0, int MODE>
-__global__ void __launch_bounds__(256) MS_BLEND_OCC k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
+__global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
                                                 const uint8_t *__restrict__ gl, long long gl_stride,
                                                 int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
 {
     const BlendTile T = tiles[blockIdx.x];
     const int f = blockIdx.z;
-    // block 32 x 8 lanes = 256 x 16 px; wave w covers the 64 x 16 px cell w of the tile (8 lanes x 8 lane-rows), so that a whole wave
-    // usually lies inside one view's exclusive region and can take the single-view path below
-    const int tid = (int)threadIdx.y * 32 + (int)threadIdx.x, lane = tid & 63;
+    // A tile is 256 x 16 px = four 64 x 16 px cells (8 lanes x 8 lane-rows of 8 x 2 px), ONE WAVE PER WORKGROUP (blockIdx.y = the cell): the waves share
+    // nothing, and single-wave workgroups fill the SIMDs more evenly than four-wave ones (level 0: 134 -> 127 us).  A whole wave usually lies inside one
+    // view's exclusive region and can take the single-view path below.
+    const int tid = 64 * (int)blockIdx.y + (int)threadIdx.y * 32 + (int)threadIdx.x, lane = tid & 63;
     const int x0 = T.x0 + 64 * (tid >> 6) + 8 * (lane & 7), y0 = T.y0 + 2 * (lane >> 3);
     if (x0 >= P.qw[l] || y0 >= P.qh[l]) return;
     // owner of this wave's cell: the one view with non-zero weights there, all exactly 1 -- then (short)(L * 1.f) = L and the weight sum
@@ -2912,7 +2913,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     }
     for (int l = l_first; l >= 0; --l) {
         if (c->blend_vec[l] && c->cfg.debug_simple_kernels == 0) {
-            const dim3 g(c->n_blend_tiles[l], 1, F), b(32, 8);
+            const dim3 g(c->n_blend_tiles[l], 4, F), b(32, 2);
             if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else        MS_MODE_LAUNCH2(k_blend8, false, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         } else {
