@@ -193,7 +193,10 @@ __device__ __forceinline__ void warp_coltab4(const ViewDesc &V, int x, float2 ct
 // a row takes `np` chunk slots, np odd (rows then start on different LDS banks).
 __host__ __device__ __forceinline__ int warp_lds_ncopy(int sw) { return (3 * sw + 15 + 15) / 16; }   // worst-case leading misalignment of 15 bytes
 __host__ __device__ __forceinline__ int warp_lds_np(int sw) { return (warp_lds_ncopy(sw) + 1) | 1; }  // + one chunk of slack for the 12-byte reads
-constexpr int WA_BUF_BYTES = 8 * 1024;                    // one staged tile; a wave owns two (double buffer): 10 waves per CU
+#ifndef MS_WA_BUF
+#define MS_WA_BUF 8192
+#endif
+constexpr int WA_BUF_BYTES = MS_WA_BUF;                    // one staged tile; a wave owns two (double buffer): 10 waves per CU
 
 // Bounding box (in source pixels) of every in-image bilinear tap of a tile: run once when the tables are built.
 // flags bit 0 = the box fits a staging buffer and does not touch the last image row (whose 16-byte chunks could run past the buffer).
