@@ -120,3 +120,49 @@ def test_front_end_recovers_the_offset_between_two_views_of_one_scene(ms, cuda):
     H, mask = ms.find_homography_ransac(src, dst)
     assert H is not None and mask.sum() > 0.8 * len(q)
     assert np.allclose(H, [[1, 0, -off], [0, 1, 0], [0, 0, 1]], atol=0.05), H
+
+
+def _homography_test_case(n, rng, sigma=0.0):
+    """The data of the reference's own Calib3d_Homography test (calib3d/test/test_homography.cpp:250-300, 395-410): n random points in a 100 x 100 image,
+    a random rotation + translation, optional N(0, sigma) noise on the destination points; mask = noise within the reprojection threshold."""
+    image_size, thr = 100, 3.0
+    src = (rng.random((n, 2)) * image_size).astype(np.float32)
+    fi = rng.random() * 2 * np.pi
+    tx, ty = rng.random(2) * np.sqrt(image_size)
+    H = np.array([[np.cos(fi), -np.sin(fi), tx], [np.sin(fi), np.cos(fi), ty], [0, 0, 1]], np.float64)
+    d = (H.astype(np.float32) @ np.c_[src, np.ones(n, np.float32)].T).T
+    dst = (d[:, :2] / d[:, 2:3]).astype(np.float32)
+    noise = (rng.normal(0, sigma, (n, 2)) if sigma else np.zeros((n, 2))).astype(np.float32)
+    return src, dst + noise, dst, noise, H, np.hypot(noise[:, 0], noise[:, 1]) <= thr
+
+
+def _check_reference_homography_criteria(find, n, seed):
+    """CV_HomographyTest::run for method RANSAC (test_homography.cpp:344-440 noise-free, :472-560 noisy): max_diff 1e-2 / max_2diff 2e-2, threshold 3.0."""
+    rng = np.random.default_rng(seed)
+    thr, max_diff, max_2diff = 3.0, 1e-2, 2e-2
+    norms = (lambda a: np.abs(a).sum(), lambda a: np.sqrt((a * a).sum()), lambda a: np.abs(a).max())      # NORM_L1, NORM_L2, NORM_INF
+    # noise-free: every point an inlier, H within max_diff of the true one in all three norms
+    src, dst, _, _, H, _ = _homography_test_case(n, rng)
+    Hr, m = find(src, dst)
+    assert Hr is not None and m.shape == (n,) and m.min() == 1 and m.max() == 1
+    for nrm in norms:
+        assert nrm(Hr / Hr[2, 2] - H) <= max_diff
+    # noisy destination points (sigma 0.01): mask == (reprojection error <= threshold), no true inlier lost, inliers reproject within max_2diff of the noise
+    src, dst_n, dst, noise, H, mask0 = _homography_test_case(n, rng, sigma=0.01)
+    Hr, m = find(src, dst_n)
+    assert Hr is not None and set(np.unique(m)) <= {0, 1}
+    p = (Hr.astype(np.float32) @ np.c_[src, np.ones(n, np.float32)].T).T
+    p = (p[:, :2] / p[:, 2:3]).astype(np.float32)
+    err = np.hypot(*(p - dst_n).T)
+    assert np.array_equal(m.astype(bool), err <= thr), "mask must be the reprojection test"
+    assert not (mask0 & ~m.astype(bool)).any(), "an inlier of the original mask is an outlier of the found one"
+    for k in np.nonzero(m)[0]:
+        for nrm in norms:
+            assert nrm(p[k] - dst[k]) - nrm(noise[k]) <= max_2diff
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 16, 50, 151, 303])
+def test_find_homography_passes_the_references_own_homography_test(ms, cuda, n):
+    """ms_find_homography_ransac under the criteria of the reference's Calib3d_Homography accuracy test (the RANSAC branch), and the oracle under the same."""
+    _check_reference_homography_criteria(lambda s, d: ms.find_homography_ransac(s, d, reproj_threshold=3.0), n, 100 + n)
+    _check_reference_homography_criteria(lambda s, d: oo.find_homography_ransac(s, d, 3.0), n, 100 + n)
