@@ -155,6 +155,14 @@ MS_API int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream stream);
  * RGB888toYUV420pInvoker (OCV/imgproc/src/color.cpp:9082-9160).  src 8UC3 with even width/height; dst contiguous
  * 8UC1 of (rows*3/2) x cols = planar I420.  Also what bench.py gathers across GPUs (half the bytes of BGR). */
 MS_API int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream stream);
+/* consume()'s pixel work on the device, in ONE pass (APP/timed.cpp:251-316): the 8U panorama resized (INTER_LINEAR) to out_width x image_height --
+ * image_height = (int)(out_width / cols * rows + 0.5) capped at out_height when keep_aspect_ratio (timed.cpp:256-271), else out_height --, placed in the middle of a
+ * black out_width x out_height frame (from row out_height / 2 - image_height / 2, timed.cpp:283-289) and converted to the encoder's planar I420
+ * (timed.cpp:308-316; the two BGR2RGB swaps before it cancel).  The reference resizes on the CPU (cv::resize's fixed-point arithmetic); this is
+ * cuda::resize's (the arithmetic of ms_resize_linear), i.e. what moving the step to the GPU with the reference's own library gives: <= 1 LSB apart.
+ * Equal, bit for bit, to ms_resize_linear + copy into a black frame + ms_bgr_to_i420.  dst: DEVICE 8UC1 contiguous (out_height * 3 / 2) x out_width;
+ * image_height (may be NULL) receives the height used. */
+MS_API int ms_consume_i420(const ms_image *pano8u, ms_image *dst, int out_width, int out_height, int keep_aspect_ratio, int *image_height, ms_stream stream);
 /* cuda::cvtColor(gpu_img, gpu_img, CV_BGR2GRAY) of featurefinder::findFeatures (APP/featurefinder.cpp:34) -> RGB2GrayConvert
  * (OCV/core/include/opencv2/core/cuda/detail/color_detail.hpp:97-101, :444-447): (b * 1868 + g * 9617 + r * 4899 + 2^13) >> 14. */
 MS_API int ms_bgr_to_gray(const ms_image *src, ms_image *dst, ms_stream stream);

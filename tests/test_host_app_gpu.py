@@ -65,6 +65,21 @@ def test_host_app_cpw_with_concurrent_recalibration(ms, cuda, tmp_path):
     assert info["recalibrations"] >= 1
 
 
+def test_host_app_consume_on_the_device(ms, cuda, tmp_path):
+    """--consume WxH: the consumer thread runs consume()'s resize + black bars + BGR2YUV_I420 (timed.cpp:251-316) as one kernel on its own stream and hands the
+    encoder frame to the host; the frame of the last panorama must equal the binding's ms_consume_i420 of the dumped panorama (FNV-1a checksum)."""
+    cfg = synth.CONFIGS["cfg2"]
+    info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
+                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 40, "--consume", "1024x512")
+    pano = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
+    frame, ih = ms.consume_i420(to_dev(pano), (1024, 512))
+    assert info["consume_image_height"] == ih == 512
+    h = 0xcbf29ce484222325 * 0          # the app starts its FNV-1a variant at 0
+    for b in host(frame).reshape(-1).tolist():
+        h = ((h ^ b) * 1099511628211) & 0xffffffffffffffff
+    assert info["consume_checksum"] == "%016x" % h
+
+
 @pytest.mark.parametrize("rig", ["mini6", "cfg2"])
 def test_host_app_updates_masks_on_the_recalibration_thread(ms, cuda, tmp_path, rig):
     """timed.cpp:598-605 re-enabled: after every mesh swap the recalibration thread calls mb->update_mask(idx) -- enqueue-only here (update_mask_margin),

@@ -281,6 +281,30 @@ def test_remap_cpu_flavour_fixed_point(ms, cuda, oracle, cn):
     assert 0 < d.max() <= 8          # the two flavours do differ on noise (up to 6)
 
 
+@pytest.mark.parametrize("src_size,out_size,keep", [((3839, 627), (4096, 2048), True), ((1279, 401), (1024, 512), True), ((640, 480), (320, 120), True),
+                                                    ((333, 97), (256, 128), False), ((96, 50), (128, 66), True)])
+def test_consume_i420_equals_resize_then_bars_then_conversion(ms, cuda, oracle, src_size, out_size, keep):
+    """consume() (timed.cpp:251-316) as one pass: must equal the three steps it fuses, each through the oracle -- cuda::resize's INTER_LINEAR to
+    out_w x image_height (timed.cpp:261-271), the result in the middle of a black frame (:287), cvtColor(BGR2YUV_I420) -- and the per-op entry points."""
+    rng = rng_for("consume", src_size + out_size)
+    w, h = src_size
+    ow, oh = out_size
+    pano = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    got, ih = ms.consume_i420(to_dev(pano), out_size, keep_aspect_ratio=keep)
+    want_ih = min(int(ow / w * h + 0.5), oh) if keep else oh
+    assert ih == want_ih
+    frame = np.zeros((oh, ow, 3), np.uint8)
+    y0 = oh // 2 - ih // 2
+    frame[y0:y0 + ih] = oracle.resize_linear_8u(pano, dsize=(ow, ih))
+    assert np.array_equal(host(got), oracle.bgr_to_i420(frame))
+    small = ms.resize_linear(to_dev(pano), dsize=(ow, ih))
+    fr = torch.zeros((oh, ow, 3), dtype=torch.uint8, device=cuda)
+    fr[y0:y0 + ih] = small
+    assert torch.equal(got, ms.bgr_to_i420(fr))
+    got2, _ = ms.consume_i420(to_dev_roi(pano, rng), out_size, keep_aspect_ratio=keep)       # padded source step
+    assert torch.equal(got, got2)
+
+
 def test_bgr_to_i420_batch_equals_single_calls(ms, cuda):
     rng = np.random.default_rng(77)
     frames = [to_dev(rng.integers(0, 256, (46, 64, 3), dtype=np.uint8)) for _ in range(70)]      # > one launch's table of 64

@@ -226,6 +226,23 @@ int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream s)
     return launch_bgr_to_i420(*src, *dst, as_stream(s));
 }
 
+int ms_consume_i420(const ms_image *pano8u, ms_image *dst, int out_width, int out_height, int keep_aspect_ratio, int *image_height, ms_stream s)
+{
+    PRE() IMG(pano8u, "ms_consume_i420 src") IMG(dst, "ms_consume_i420 dst")
+    MS_CHECK(pano8u->type == MS_8UC3 && dst->type == MS_8UC1, "ms_consume_i420: 8UC3 -> 8UC1 planes");
+    MS_CHECK(out_width >= 2 && out_height >= 2 && out_width % 2 == 0 && out_height % 2 == 0, "ms_consume_i420: output size must be even");
+    MS_CHECK(dst->cols == out_width && dst->rows == out_height * 3 / 2 && dst->step == (size_t)dst->cols,
+             "ms_consume_i420: dst must be a contiguous 8UC1 image of %d x %d", out_width, out_height * 3 / 2);
+    int ih = out_height;
+    if (keep_aspect_ratio) {      // timed.cpp:256-266: width is the restricting dimension, the height follows the aspect ratio (rounded), capped
+        ih = (int)((double)out_width / (double)pano8u->cols * pano8u->rows + 0.5);
+        if (ih > out_height) ih = out_height;
+    }
+    MS_CHECK(ih >= 1, "ms_consume_i420: the panorama is too flat for a %d-column output", out_width);
+    if (image_height) *image_height = ih;
+    return launch_consume_i420(*pano8u, *dst, out_width, out_height, ih, out_height / 2 - ih / 2, as_stream(s));      // timed.cpp:287
+}
+
 int ms_bgr_to_gray(const ms_image *src, ms_image *dst, ms_stream s)
 {
     PRE() IMG(src, "ms_bgr_to_gray src") IMG(dst, "ms_bgr_to_gray dst")

@@ -665,6 +665,58 @@ __global__ void __launch_bounds__(256) k_bgr_to_i420(const uint8_t *__restrict__
     if (wide) bgr_to_i420_cell8(src, sstep, w, h, dst, x, y);
     else bgr_to_i420_cell(src, sstep, w, h, dst, x, y);
 }
+// consume()'s pixel work in one pass (APP/timed.cpp:251-316): cv::resize(INTER_LINEAR) of the 8U panorama to out_w x ih -- in cuda::resize's arithmetic, the
+// same operations as k_resize_linear --, the result in the middle of a black out_w x out_h frame, BGR -> I420.  One lane = one 2 x 2 block of the frame.
+__global__ void __launch_bounds__(256) k_consume_i420(const uint8_t *__restrict__ src, size_t sstep, int srows, int scols, uint8_t *__restrict__ dst,
+                                                      int out_w, int out_h, int ih, int y_off, float ify, float ifx)
+{
+    const int x = 2 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= out_w || y >= out_h) return;
+    constexpr int SH = 20, HALF = 1 << (SH - 1);
+    constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+    uint8_t *Y = dst, *U = dst + (size_t)out_w * out_h, *V = U + (size_t)(out_w / 2) * (out_h / 2);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            int b = 0, g = 0, rr = 0;                      // the black bars
+            const int yy = y + dy - y_off, xx = x + dx;
+            if (yy >= 0 && yy < ih) {
+                const float sx = (float)xx * ifx, sy = (float)yy * ify;
+                const int x1 = f2i_rd(sx), y1 = f2i_rd(sy);
+                const int x2 = x1 + 1, y2 = y1 + 1;
+                const int x2r = min(x2, scols - 1), y2r = min(y2, srows - 1);
+                const float w11 = ((float)x2 - sx) * ((float)y2 - sy), w12 = (sx - (float)x1) * ((float)y2 - sy);
+                const float w21 = ((float)x2 - sx) * (sy - (float)y1), w22 = (sx - (float)x1) * (sy - (float)y1);
+                const uint8_t *r1 = row_ptr<uint8_t>(src, sstep, y1), *r2 = row_ptr<uint8_t>(src, sstep, y2r);
+                int px[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float out = 0.f;
+                    out = __builtin_fmaf((float)r1[(size_t)x1 * 3 + c], w11, out);
+                    out = __builtin_fmaf((float)r1[(size_t)x2r * 3 + c], w12, out);
+                    out = __builtin_fmaf((float)r2[(size_t)x1 * 3 + c], w21, out);
+                    out = __builtin_fmaf((float)r2[(size_t)x2r * 3 + c], w22, out);
+                    px[c] = sat_u8(out);
+                }
+                b = px[0]; g = px[1]; rr = px[2];
+            }
+            Y[(size_t)(y + dy) * out_w + x + dx] = clamp_u8((CRY * rr + CGY * g + CBY * b + HALF + (16 << SH)) >> SH);
+            if (dy == 0 && dx == 0) {
+                U[(size_t)(y / 2) * (out_w / 2) + x / 2] = clamp_u8((CRU * rr + CGU * g + CBU * b + HALF + (128 << SH)) >> SH);
+                V[(size_t)(y / 2) * (out_w / 2) + x / 2] = clamp_u8((CBU * rr + CGV * g + CBV * b + HALF + (128 << SH)) >> SH);
+            }
+        }
+}
+int launch_consume_i420(const ms_image &src, ms_image &dst, int out_w, int out_h, int ih, int y_off, hipStream_t st)
+{
+    // cv::resize with an explicit dsize: fx = dsize.width / src.cols (double), the kernel gets (float)(1 / fx)  (resize.cpp:72-81,105)
+    const double fx = (double)out_w / src.cols, fy = (double)ih / src.rows;
+    k_consume_i420<<<dim3(div_up(out_w / 2, BX), div_up(out_h / 2, BY)), dim3(BX, BY), 0, st>>>(
+        (const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, out_w, out_h, ih, y_off, (float)(1.0 / fy), (float)(1.0 / fx));
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
 // the same for up to I420_BATCH frames of one geometry in one launch (the egress of a batch of panoramas: one launch instead of one per frame)
 struct I420Batch { const uint8_t *src[I420_BATCH]; uint8_t *dst[I420_BATCH]; };
 __global__ void __launch_bounds__(256) k_bgr_to_i420_batch(I420Batch T, size_t sstep, int w, int h, int wide)

@@ -75,6 +75,7 @@ struct Options {
     int views = 6, w = 1920, h = 1080, out_w = 3840, out_h = 1920, bands = 5, frames = 300;
     double hfov = 90.0;
     bool cpw = false, i420 = false, upload = true, nv12 = false, solve_mesh = false;
+    int consume_w = 0, consume_h = 0;           // > 0: consume()'s resize + black bars + BGR2YUV_I420 on the device (timed.cpp:251-316), OUTPUT_WIDTH x OUTPUT_HEIGHT
     int update_mask = 0;                        // > 0: mb->update_mask(idx, ...) after every mesh swap (timed.cpp:598-605, commented out there), enqueue-only with this margin
     bool reference_calib = false;               // stitch_calib as the reference ships it: cylindrical warper, megapixel budgets of defs.h, seam-scale pipeline
     double work_mp = 0.6, seam_mp = 0.01, compose_mp = 1.4;      // WORK_MEGAPIX, SEAM_MEAGPIX, COMPOSE_MEGAPIX (defs.h:51-53)
@@ -178,6 +179,7 @@ int main(int argc, char **argv)
         else if (k == "--cpw") o.cpw = true;
         else if (k == "--solve-mesh") o.cpw = o.solve_mesh = true;
         else if (k == "--update-mask") { o.cpw = true; o.update_mask = atoi(next()); }
+        else if (k == "--consume") sscanf(next(), "%dx%d", &o.consume_w, &o.consume_h);
         else if (k == "--i420") o.i420 = true;
         else if (k == "--no-upload") o.upload = false;
         else if (k == "--nv12") o.nv12 = true;
@@ -286,11 +288,27 @@ int main(int argc, char **argv)
         std::vector<unsigned char> last_pano((size_t)o.out_w * o.out_h * 3);
         unsigned long long checksum = 0;
         long long consumed = 0;
+        DevMat encoder_frame;                           // consume(): the resized, letterboxed I420 frame the encoder gets (one buffer: the consumer is one thread)
+        std::vector<unsigned char> encoder_host;
+        hipStream_t consume_stream = nullptr;
+        int consume_image_height = 0;
+        unsigned long long consume_checksum = 0;
+        if (o.consume_w > 0) {
+            encoder_frame.create(o.consume_h * 3 / 2, o.consume_w, MS_8UC1, 1, true);
+            encoder_host.resize((size_t)o.consume_w * o.consume_h * 3 / 2);
+            HIPCHECK(hipStreamCreateWithFlags(&consume_stream, hipStreamNonBlocking));
+        }
         std::thread consumer([&] {                      // consume(): wait for the frame, (I420,) bring it to the host side
             for (;;) {
                 Slot *s = results.pop();
                 if (!s) break;
                 HIPCHECK(hipEventSynchronize(s->done));
+                if (o.consume_w > 0) {                  // timed.cpp:251-316 without the download / CPU resize / CPU cvtColor: one kernel, then the encoder's copy
+                    consume_image_height = msshim::consume_i420(s->pano8u, encoder_frame, o.consume_w, o.consume_h, true, (ms_stream)consume_stream);
+                    HIPCHECK(hipMemcpyAsync(encoder_host.data(), encoder_frame.data, encoder_host.size(), hipMemcpyDeviceToHost, consume_stream));
+                    HIPCHECK(hipStreamSynchronize(consume_stream));
+                    if (s->seq == o.frames - 1) for (unsigned char b : encoder_host) consume_checksum = (consume_checksum ^ b) * 1099511628211ull;
+                }
                 if (s->seq == o.frames - 1) {           // keep the last panorama for the checksum / dump
                     HIPCHECK(hipMemcpy2D(last_pano.data(), (size_t)o.out_w * 3, s->pano8u.data, s->pano8u.step, (size_t)o.out_w * 3, o.out_h, hipMemcpyDeviceToHost));
                 }
@@ -470,10 +488,10 @@ int main(int argc, char **argv)
         }
         printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"upload\": %s, "
                "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"max_mesh_displacement_px\": %.2f, "
-               "\"orb_keypoints\": %lld, \"ratio_matches\": %lld, \"ransac_inliers\": %lld, \"update_mask_margin\": %d, \"update_mask_equals_sync_rebuild\": %s, \"checksum\": \"%016llx\"}\n",
+               "\"orb_keypoints\": %lld, \"ratio_matches\": %lld, \"ransac_inliers\": %lld, \"update_mask_margin\": %d, \"update_mask_equals_sync_rebuild\": %s, \"consume_image_height\": %d, \"consume_checksum\": \"%016llx\", \"checksum\": \"%016llx\"}\n",
                o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.upload ? "true" : "false",
                consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), (double)max_disp.load(),
-               total_keypoints.load(), total_matches.load(), total_inliers.load(), o.update_mask, selfcheck < 0 ? "null" : (selfcheck ? "true" : "false"), checksum);
+               total_keypoints.load(), total_matches.load(), total_inliers.load(), o.update_mask, selfcheck < 0 ? "null" : (selfcheck ? "true" : "false"), consume_image_height, consume_checksum, checksum);
     } catch (const msshim::Error &e) {
         fprintf(stderr, "stitch_app: msstitch error %d: %s\n", e.code, e.what());
         return 1;

@@ -92,7 +92,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420",
 ]
 
 _lib = None
@@ -325,6 +325,15 @@ def bgr_to_i420(src, dst=None):
         dst = _new((src.shape[0] * 3 // 2, src.shape[1]), _torch().uint8)
     _chk(load().ms_bgr_to_i420(C.byref(img(src)), C.byref(img(dst)), _stream()))
     return dst
+
+
+def consume_i420(pano8u, out_size=(4096, 2048), keep_aspect_ratio=True):
+    """consume()'s resize + black bars + BGR2YUV_I420 in one pass (timed.cpp:251-316).  Returns (I420 tensor (out_h * 3 / 2, out_w), image_height)."""
+    ow, oh = out_size
+    dst = _new((oh * 3 // 2, ow), _torch().uint8)
+    ih = C.c_int(0)
+    _chk(load().ms_consume_i420(C.byref(img(pano8u)), C.byref(img(dst)), ow, oh, 1 if keep_aspect_ratio else 0, C.byref(ih), _stream()))
+    return dst, ih.value
 
 
 def bgr_to_gray(src):

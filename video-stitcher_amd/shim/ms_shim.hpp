@@ -52,6 +52,15 @@ template <class Mat> void addSrcWeightGpu32F(const Mat &src, const Mat &w, Mat &
 { ms_image a = wrap(src), b = wrap(w), d = wrap(dst), e = wrap(dst_w); check(ms_add_src_weight_32f(&a, &b, &d, &e, rc_w, rc_h, s)); }
 template <class Mat> void normalizeUsingWeightMapGpu32F(const Mat &w, Mat &src, int width, int height, ms_stream s = nullptr)
 { ms_image a = wrap(w), d = wrap(src); check(ms_normalize_using_weight_32f(&a, &d, width, height, s)); }
+// consume()'s resize + black bars + cvtColor(BGR2YUV_I420) (timed.cpp:251-316) in one pass; i420: contiguous 8UC1 (out_h * 3 / 2) x out_w.  Returns image_height.
+template <class Mat> int consume_i420(const Mat &pano8u, Mat &i420, int out_w, int out_h, bool keep_aspect_ratio = true, ms_stream s = nullptr)
+{
+    ms_image a = wrap(pano8u), b = wrap(i420);
+    int ih = 0;
+    check(ms_consume_i420(&a, &b, out_w, out_h, keep_aspect_ratio ? 1 : 0, &ih, s));
+    return ih;
+}
+
 // custom_resize (APP/calibration.h:15)
 template <class Mat> void custom_resize(const Mat &in, Mat &out, ms_stream s = nullptr)
 { ms_image a = wrap(in), d = wrap(out); check(ms_custom_resize_32f(&a, &d, s)); }
