@@ -88,6 +88,9 @@ MS_API int ms_remap(const ms_image *src, const ms_image *xmap, const ms_image *y
  *                     saturate_cast<int>(cols*fx) x saturate_cast<int>(rows*fy); the kernel gets 1/fx, 1/fy;
  *   fx == 0 && fy == 0: dsize = dst size; fx = dsize.width / src.cols, fy likewise. */
 MS_API int ms_resize_linear(const ms_image *src, ms_image *dst, double fx, double fy, ms_stream stream);
+/* The same for n 8UC3 images of one geometry in ONE launch: stitch_online's cuda::resize of every view by compose_scale (APP/timed.cpp:75-85 -- on the
+ * per-frame path with the shipped COMPOSE_MEGAPIX, defs.h:53) for all views of a frame (or of a batch of frames).  Bit-identical to n ms_resize_linear calls. */
+MS_API int ms_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double fx, double fy, ms_stream stream);
 
 /* GpuMat::convertTo(dst, same type, alpha)  OCV/core/src/cuda/gpu_mat.cu:488-512 (exposure gain,
  * APP/timed.cpp:94 / GainCompensator::apply_gpu exposure_compensate.cpp:155-160).  8U any channels, in place ok. */

@@ -305,6 +305,19 @@ def test_consume_i420_equals_resize_then_bars_then_conversion(ms, cuda, oracle, 
     assert torch.equal(got, got2)
 
 
+def test_resize_linear_batch_equals_single_calls(ms, cuda, oracle):
+    """stitch_online's per-view cuda::resize by compose_scale (timed.cpp:75-85) for all views in one launch: equal to the single calls and to the oracle."""
+    rng = rng_for("resize_batch", (6,))
+    srcs = [rng.integers(0, 256, size=(270, 480, 3), dtype=np.uint8) for _ in range(6)]
+    s = math.sqrt(1.4e6 / (1920 * 1080))            # compose_scale of the shipped COMPOSE_MEGAPIX for 1080p (calibration.cpp:149)
+    got = ms.resize_linear_batch([to_dev(x) for x in srcs], fx=s, fy=s)
+    for x, g in zip(srcs, got):
+        assert np.array_equal(host(g), oracle.resize_linear_8u(x, fx=s, fy=s))
+        assert torch.equal(g, ms.resize_linear(to_dev(x), fx=s, fy=s))
+    with pytest.raises(ms.MsError, match="one geometry"):
+        ms.resize_linear_batch([to_dev(srcs[0]), to_dev(srcs[1][:100])], fx=s, fy=s)
+
+
 def test_bgr_to_i420_batch_equals_single_calls(ms, cuda):
     rng = np.random.default_rng(77)
     frames = [to_dev(rng.integers(0, 256, (46, 64, 3), dtype=np.uint8)) for _ in range(70)]      # > one launch's table of 64

@@ -93,6 +93,24 @@ int ms_resize_linear(const ms_image *src, ms_image *dst, double fx, double fy, m
     return launch_resize_linear(*src, *dst, fx, fy, as_stream(s));
 }
 
+int ms_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double fx, double fy, ms_stream s)
+{
+    PRE()
+    MS_CHECK(src && dst && n >= 1, "ms_resize_linear_batch: null argument / empty batch");
+    MS_CHECK((fx > 0 && fy > 0) || (fx == 0 && fy == 0), "ms_resize_linear_batch: fx, fy must both be > 0 or both be 0");
+    for (int i = 0; i < n; ++i) {
+        MS_CHECK(src[i].data && dst[i].data && src[i].type == MS_8UC3 && dst[i].type == MS_8UC3, "ms_resize_linear_batch: image %d must be a device 8UC3 image", i);
+        MS_CHECK(src[i].rows == src[0].rows && src[i].cols == src[0].cols && src[i].step == src[0].step && dst[i].rows == dst[0].rows && dst[i].cols == dst[0].cols &&
+                 dst[i].step == dst[0].step, "ms_resize_linear_batch: all images of a batch must share one geometry (image %d differs)", i);
+    }
+    MS_CHECK(dst[0].rows != src[0].rows || dst[0].cols != src[0].cols, "ms_resize_linear_batch: equal sizes (cuda::resize copies: use the images as they are)");
+    if (fx > 0) {
+        const int w = (int)__builtin_rint(src[0].cols * fx), h = (int)__builtin_rint(src[0].rows * fy);
+        MS_CHECK(dst[0].cols == w && dst[0].rows == h, "ms_resize_linear_batch: dst must be %dx%d for fx=%g fy=%g (resize.cpp:74)", w, h, fx, fy);
+    }
+    return launch_resize_linear_batch(src, dst, n, fx, fy, as_stream(s));
+}
+
 int ms_convert_scale_8u(const ms_image *src, ms_image *dst, double alpha, ms_stream s)
 {
     PRE() IMG(src, "ms_convert_scale_8u src") IMG(dst, "ms_convert_scale_8u dst") SAME(src, dst, "ms_convert_scale_8u")

@@ -8,6 +8,7 @@ namespace ms {
 
 int launch_remap(const ms_image &src, const ms_image &xm, const ms_image &ym, ms_image &dst, int interp, int border, hipStream_t st);
 int launch_resize_linear(const ms_image &src, ms_image &dst, double fx, double fy, hipStream_t st);
+int launch_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double fx, double fy, hipStream_t st);
 int launch_convert_scale_8u(const ms_image &src, ms_image &dst, double alpha, hipStream_t st);
 int launch_convert(const ms_image &src, ms_image &dst, double alpha, hipStream_t st);
 int launch_sub_16s(const ms_image &a, const ms_image &b, ms_image &dst, hipStream_t st);

@@ -167,6 +167,46 @@ __global__ void __launch_bounds__(256) k_resize_linear(const uint8_t *__restrict
     }
 }
 
+// the same for up to RESIZE_BATCH images of one geometry in one launch: stitch_online's per-view cuda::resize by compose_scale (timed.cpp:75-85) for all views of a frame
+constexpr int RESIZE_BATCH = 64;
+struct ResizeBatch { const uint8_t *src[RESIZE_BATCH]; uint8_t *dst[RESIZE_BATCH]; };
+__global__ void __launch_bounds__(256) k_resize_linear3_batch(ResizeBatch T, size_t sstep, int srows, int scols, size_t dstep, int drows, int dcols, float ify, float ifx)
+{
+    XY_GUARD(dcols, drows)
+    const uint8_t *src = T.src[blockIdx.z];
+    const float sx = (float)x * ifx, sy = (float)y * ify;
+    const int x1 = f2i_rd(sx), y1 = f2i_rd(sy);
+    const int x2 = x1 + 1, y2 = y1 + 1;
+    const int x2r = min(x2, scols - 1), y2r = min(y2, srows - 1);
+    const float w11 = ((float)x2 - sx) * ((float)y2 - sy), w12 = (sx - (float)x1) * ((float)y2 - sy);
+    const float w21 = ((float)x2 - sx) * (sy - (float)y1), w22 = (sx - (float)x1) * (sy - (float)y1);
+    const uint8_t *r1 = row_ptr<uint8_t>(src, sstep, y1), *r2 = row_ptr<uint8_t>(src, sstep, y2r);
+    uint8_t *d = row_ptr<uint8_t>(T.dst[blockIdx.z], dstep, y) + (size_t)x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float out = 0.f;
+        out = __builtin_fmaf((float)r1[(size_t)x1 * 3 + c], w11, out);
+        out = __builtin_fmaf((float)r1[(size_t)x2r * 3 + c], w12, out);
+        out = __builtin_fmaf((float)r2[(size_t)x1 * 3 + c], w21, out);
+        out = __builtin_fmaf((float)r2[(size_t)x2r * 3 + c], w22, out);
+        d[c] = sat_u8(out);
+    }
+}
+int launch_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double fx, double fy, hipStream_t st)
+{
+    if (!(fx > 0 && fy > 0)) { fx = (double)dst[0].cols / src[0].cols; fy = (double)dst[0].rows / src[0].rows; }
+    const float ifx = (float)(1.0 / fx), ify = (float)(1.0 / fy);
+    for (int i0 = 0; i0 < n; i0 += RESIZE_BATCH) {
+        const int m = std::min(RESIZE_BATCH, n - i0);
+        ResizeBatch T{};
+        for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
+        const dim3 g2 = grid2d(dst[0].cols, dst[0].rows);
+        k_resize_linear3_batch<<<dim3(g2.x, g2.y, m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx);
+        MS_LAUNCH_CHECK();
+    }
+    return MS_OK;
+}
+
 int launch_resize_linear(const ms_image &src, ms_image &dst, double fx, double fy, hipStream_t st)
 {
     if (dst.rows == src.rows && dst.cols == src.cols) {   // resize.cpp:86-90: plain copy

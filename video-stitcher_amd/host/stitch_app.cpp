@@ -420,7 +420,7 @@ int main(int argc, char **argv)
                 }
             }
             if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)
-                for (int i = 0; i < o.views; ++i) msshim::cuda::resize(full_imgs[i], small_imgs[i], cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);
+                msshim::cuda::resize(full_imgs, small_imgs, cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);      // all views, one launch
                 comp.stitch_one(small_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
             } else
                 comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);

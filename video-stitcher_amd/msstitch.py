@@ -92,7 +92,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch",
 ]
 
 _lib = None
@@ -214,6 +214,21 @@ def resize_linear(src, dsize=None, fx=0.0, fy=0.0):
     dst = _new((dsize[1], dsize[0]) + tuple(src.shape[2:]), src.dtype)
     _chk(load().ms_resize_linear(C.byref(img(src)), C.byref(img(dst)), C.c_double(fx), C.c_double(fy), _stream()))
     return dst
+
+
+def resize_linear_batch(srcs, dsize=None, fx=0.0, fy=0.0):
+    """n 8UC3 images of one geometry through cuda::resize's arithmetic in one launch; returns the list of resized tensors."""
+    import numpy as np
+    rows, cols = srcs[0].shape[:2]
+    if dsize is None:
+        dsize = (int(np.rint(cols * fx)), int(np.rint(rows * fy)))
+    else:
+        fx = fy = 0.0
+    dsts = [_new((dsize[1], dsize[0], 3), srcs[0].dtype) for _ in srcs]
+    n = len(srcs)
+    a = (Image * n)(*[img(t) for t in srcs]); b = (Image * n)(*[img(t) for t in dsts])
+    _chk(load().ms_resize_linear_batch(a, b, n, C.c_double(fx), C.c_double(fy), _stream()))
+    return dsts
 
 
 def convert_scale_8u(src, alpha, inplace=False):

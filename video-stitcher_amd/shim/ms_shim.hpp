@@ -30,6 +30,13 @@ template <class Mat> void remap(const Mat &src, Mat &dst, const Mat &xmap, const
 { ms_image a = wrap(src), x = wrap(xmap), y = wrap(ymap), d = wrap(dst); check(ms_remap(&a, &x, &y, &d, interpolation, borderMode, s)); }
 template <class Mat> void resize(const Mat &src, Mat &dst, double fx, double fy, ms_stream s = nullptr)
 { ms_image a = wrap(src), d = wrap(dst); check(ms_resize_linear(&a, &d, fx, fy, s)); }
+// every view of a frame in one launch (the loop of cuda::resize calls of stitch_online, timed.cpp:75-85)
+template <class Mat> void resize(const std::vector<Mat> &src, std::vector<Mat> &dst, double fx, double fy, ms_stream s = nullptr)
+{
+    std::vector<ms_image> a(src.size()), d(dst.size());
+    for (size_t i = 0; i < src.size(); ++i) { a[i] = wrap(src[i]); d[i] = wrap(dst[i]); }
+    check(ms_resize_linear_batch(a.data(), d.data(), (int)src.size(), fx, fy, s));
+}
 template <class Mat> void copyMakeBorder(const Mat &src, Mat &dst, int top, int bottom, int left, int right, int borderType, ms_stream s = nullptr)
 { ms_image a = wrap(src), d = wrap(dst); check(ms_copy_make_border(&a, &d, top, bottom, left, right, borderType, s)); }
 template <class Mat> void pyrDown(const Mat &src, Mat &dst, ms_stream s = nullptr)
