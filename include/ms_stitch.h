@@ -153,6 +153,8 @@ MS_API int ms_build_warp_maps(int projection, int tl_u, int tl_v, ms_image *map_
  * (APP/networking.cpp:45-47, 1920x1620 NV12 -> 1920x1080 BGR, defs.h:10-17) -> YUV420sp2RGB888Invoker<0,0>
  * (OCV/imgproc/src/color.cpp).  src 8UC1 of (rows*3/2) x cols (Y plane, then interleaved UV); dst 8UC3, even size. */
 MS_API int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream stream);
+/* The same for n cameras of one geometry in ONE launch (the capture threads convert per camera, networking.cpp:45-47).  Bit-identical to n single calls. */
+MS_API int ms_nv12_to_bgr_batch(const ms_image *src, ms_image *dst, int n, ms_stream stream);
 
 /* cvtColor(src, dst, COLOR_BGR2YUV_I420): the encoder input of consume() (APP/timed.cpp:308-316) ->
  * RGB888toYUV420pInvoker (OCV/imgproc/src/color.cpp:9082-9160).  src 8UC3 with even width/height; dst contiguous

@@ -260,6 +260,17 @@ def test_nv12_to_bgr(ms, cuda, oracle, size):
     assert tuple(ref[0, 0]) == (0, 0, 0) and tuple(ref[0, 1]) == (255, 255, 255)
 
 
+def test_nv12_to_bgr_batch_equals_single_calls(ms, cuda, oracle):
+    """All cameras of a frame in one launch: equal to the oracle and to the single calls; mixed geometries are refused."""
+    rng = rng_for("nv12_batch", (6,))
+    srcs = [rng.integers(0, 256, size=(90 * 3 // 2, 164), dtype=np.uint8) for _ in range(6)]
+    got = ms.nv12_to_bgr_batch([to_dev(x) for x in srcs])
+    for x, g in zip(srcs, got):
+        assert np.array_equal(host(g), oracle.nv12_to_bgr(x))
+    with pytest.raises(ms.MsError, match="one geometry"):
+        ms.nv12_to_bgr_batch([to_dev(srcs[0]), to_dev(srcs[1][:60 * 3 // 2])])
+
+
 @pytest.mark.parametrize("cn", [1, 3])
 def test_remap_cpu_flavour_fixed_point(ms, cuda, oracle, cn):
     """ms_remap(MS_INTER_LINEAR_FIXPT) = cv::remap(INTER_LINEAR) on the CPU: 1/32-px coordinates, 15-bit weight table, (v + 2^14) >> 15

@@ -234,6 +234,20 @@ int ms_nv12_to_bgr(const ms_image *src, ms_image *dst, ms_stream s)
     return launch_nv12_to_bgr(*src, *dst, as_stream(s));
 }
 
+int ms_nv12_to_bgr_batch(const ms_image *src, ms_image *dst, int n, ms_stream s)
+{
+    PRE()
+    MS_CHECK(src && dst && n >= 1, "ms_nv12_to_bgr_batch: null argument / empty batch");
+    for (int i = 0; i < n; ++i) {
+        MS_CHECK(src[i].data && dst[i].data && src[i].type == MS_8UC1 && dst[i].type == MS_8UC3, "ms_nv12_to_bgr_batch: image %d: 8UC1 planes -> 8UC3", i);
+        MS_CHECK(dst[i].cols % 2 == 0 && dst[i].rows % 2 == 0 && src[i].cols == dst[i].cols && src[i].rows == dst[i].rows * 3 / 2,
+                 "ms_nv12_to_bgr_batch: src %d must be (rows*3/2) x cols of an even-sized dst", i);
+        MS_CHECK(src[i].rows == src[0].rows && src[i].cols == src[0].cols && src[i].step == src[0].step && dst[i].step == dst[0].step,
+                 "ms_nv12_to_bgr_batch: all images of a batch must share one geometry (image %d differs)", i);
+    }
+    return launch_nv12_to_bgr_batch(src, dst, n, as_stream(s));
+}
+
 int ms_bgr_to_i420(const ms_image *src, ms_image *dst, ms_stream s)
 {
     PRE() IMG(src, "ms_bgr_to_i420 src") IMG(dst, "ms_bgr_to_i420 dst")

@@ -25,6 +25,7 @@ int launch_zero_masked(ms_image &img, const ms_image &mask, hipStream_t st);
 int launch_dilate3(const ms_image &src, ms_image &dst, hipStream_t st);
 int launch_build_warp_maps(int proj, int tl_u, int tl_v, ms_image &mx, ms_image &my, const float *k_rinv, const float *t, float scale, hipStream_t st);
 int launch_nv12_to_bgr(const ms_image &src, ms_image &dst, hipStream_t st);
+int launch_nv12_to_bgr_batch(const ms_image *src, ms_image *dst, int n, hipStream_t st);
 int launch_bgr_to_i420(const ms_image &src, ms_image &dst, hipStream_t st);
 int launch_consume_i420(const ms_image &src, ms_image &dst, int out_w, int out_h, int ih, int y_off, hipStream_t st);
 int launch_bgr_to_gray(const ms_image &src, ms_image &dst, hipStream_t st);

@@ -576,10 +576,8 @@ int launch_build_warp_maps(int proj, int tl_u, int tl_v, ms_image &mx, ms_image 
 // ------------------------------------------------------------------------------------------------
 // cvtColor(COLOR_YUV2BGR_NV12)  [imgproc/src/color.cpp:8738-8745 + YUV420sp2RGB888Invoker<0,0>]: the per-camera ingest the
 // reference does on the CPU (APP/networking.cpp:45-47).  One lane = 2 rows x 4 pixels: two 4-byte Y loads, one 4-byte UV load.
-__global__ void __launch_bounds__(256) k_nv12_to_bgr(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep)
+__device__ __forceinline__ void nv12_to_bgr_cell(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep, int x, int y)
 {
-    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
-    if (x >= w || y >= h) return;
     constexpr int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
     const int n = min(4, w - x);
     const uint8_t *uvrow = src + (size_t)(h + y / 2) * sstep + x;
@@ -600,6 +598,32 @@ __global__ void __launch_bounds__(256) k_nv12_to_bgr(const uint8_t *__restrict__
             d[3 * k + 2] = (uint8_t)min(max((yy + ruv) >> SH, 0), 255);
         }
     }
+}
+__global__ void __launch_bounds__(256) k_nv12_to_bgr(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= w || y >= h) return;
+    nv12_to_bgr_cell(src, sstep, w, h, dst, dstep, x, y);
+}
+// every camera of a frame in one launch (the capture threads' per-camera cvtColor, networking.cpp:45-47)
+constexpr int NV12_BATCH = 64;
+struct Nv12Batch { const uint8_t *src[NV12_BATCH]; uint8_t *dst[NV12_BATCH]; };
+__global__ void __launch_bounds__(256) k_nv12_to_bgr_batch(Nv12Batch T, size_t sstep, int w, int h, size_t dstep)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= w || y >= h) return;
+    nv12_to_bgr_cell(T.src[blockIdx.z], sstep, w, h, T.dst[blockIdx.z], dstep, x, y);
+}
+int launch_nv12_to_bgr_batch(const ms_image *src, ms_image *dst, int n, hipStream_t st)
+{
+    for (int i0 = 0; i0 < n; i0 += NV12_BATCH) {
+        const int m = std::min(NV12_BATCH, n - i0);
+        Nv12Batch T{};
+        for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
+        k_nv12_to_bgr_batch<<<dim3(div_up(div_up(dst[0].cols, 4), BX), div_up(dst[0].rows / 2, BY), m), dim3(BX, BY), 0, st>>>(T, src[0].step, dst[0].cols, dst[0].rows, dst[0].step);
+        MS_LAUNCH_CHECK();
+    }
+    return MS_OK;
 }
 int launch_nv12_to_bgr(const ms_image &src, ms_image &dst, hipStream_t st)
 {

@@ -412,11 +412,14 @@ int main(int argc, char **argv)
                     if (o.nv12) {         // half the PCIe bytes: upload NV12, convert on the device
                         HIPCHECK(hipMemcpy2DAsync(nv12_imgs[i].data, nv12_imgs[i].step, imgs.v[i].p, (size_t)o.w, (size_t)o.w, o.h * 3 / 2,
                                                   hipMemcpyHostToDevice, stitch_stream));
-                        ms_image s8 = msshim::wrap(nv12_imgs[i]), d8 = msshim::wrap(full_imgs[i]);
-                        msshim::check(ms_nv12_to_bgr(&s8, &d8, (ms_stream)stitch_stream));
                     } else
                         HIPCHECK(hipMemcpy2DAsync(full_imgs[i].data, full_imgs[i].step, imgs.v[i].p, (size_t)o.w * 3, (size_t)o.w * 3, o.h,
                                                   hipMemcpyHostToDevice, stitch_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
+                }
+                if (o.nv12) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47)
+                    std::vector<ms_image> a(o.views), d(o.views);
+                    for (int i = 0; i < o.views; ++i) { a[i] = msshim::wrap(nv12_imgs[i]); d[i] = msshim::wrap(full_imgs[i]); }
+                    msshim::check(ms_nv12_to_bgr_batch(a.data(), d.data(), o.views, (ms_stream)stitch_stream));
                 }
             }
             if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)

@@ -92,7 +92,7 @@ EXPORTS = [
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
-    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch",
+    "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
 ]
 
 _lib = None
@@ -333,6 +333,15 @@ def nv12_to_bgr(src, dst=None):
         dst = _new((src.shape[0] * 2 // 3, src.shape[1], 3), _torch().uint8)
     _chk(load().ms_nv12_to_bgr(C.byref(img(src)), C.byref(img(dst)), _stream()))
     return dst
+
+
+def nv12_to_bgr_batch(srcs):
+    """cvtColor(YUV2BGR_NV12) of n cameras of one geometry in one launch; returns the list of BGR tensors."""
+    dsts = [_new((t.shape[0] * 2 // 3, t.shape[1], 3), _torch().uint8) for t in srcs]
+    n = len(srcs)
+    a = (Image * n)(*[img(t) for t in srcs]); b = (Image * n)(*[img(t) for t in dsts])
+    _chk(load().ms_nv12_to_bgr_batch(a, b, n, _stream()))
+    return dsts
 
 
 def bgr_to_i420(src, dst=None):
