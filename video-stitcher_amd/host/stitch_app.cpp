@@ -266,12 +266,23 @@ int main(int argc, char **argv)
         });
 
         // ---- stitch_one + results queue + consume -----------------------------------------------------------------
-        std::vector<DevMat> full_imgs(o.views);
-        for (auto &m : full_imgs) m.create(o.h, o.w, MS_8UC3, 3);
+        // The uploaded frames are double-buffered and travel on their own stream: the H2D copies of frame t+1 overlap the stitch of frame t (the reference
+        // uploads and stitches on one stream per view, timed.cpp:64-68).  up_done[b]: buffer b is filled; buf_free[b]: the stitch that read it is done.
+        std::vector<DevMat> full_imgs_b[2], nv12_imgs_b[2];
+        hipStream_t upload_stream;
+        HIPCHECK(hipStreamCreateWithFlags(&upload_stream, hipStreamNonBlocking));
+        hipEvent_t up_done[2], buf_free[2];
+        bool buf_used[2] = {false, false};
+        for (int b = 0; b < 2; ++b) {
+            full_imgs_b[b].resize(o.views);
+            for (auto &m : full_imgs_b[b]) m.create(o.h, o.w, MS_8UC3, 3);
+            nv12_imgs_b[b].resize(o.nv12 ? o.views : 0);
+            for (auto &m : nv12_imgs_b[b]) m.create(o.h * 3 / 2, o.w, MS_8UC1, 1);
+            HIPCHECK(hipEventCreateWithFlags(&up_done[b], hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&buf_free[b], hipEventDisableTiming));
+        }
         std::vector<DevMat> small_imgs(resize_in ? o.views : 0);
         for (auto &m : small_imgs) m.create(ch, cw, MS_8UC3, 3);
-        std::vector<DevMat> nv12_imgs(o.nv12 ? o.views : 0);
-        for (auto &m : nv12_imgs) m.create(o.h * 3 / 2, o.w, MS_8UC1, 1);
         const int RING = 4;
         std::vector<Slot> ring(RING);
         const ms_pano_geom pg = comp.panoGeom();
@@ -406,21 +417,26 @@ int main(int argc, char **argv)
         try {
         for (int t = 0; t < o.frames; ++t) {            // main loop: stitch_one per frame
             Slot *s = free_slots.pop();
+            const int ib = o.upload ? (t & 1) : 0;
+            std::vector<DevMat> &full_imgs = full_imgs_b[ib], &nv12_imgs = nv12_imgs_b[ib];
             if (o.upload || t == 0) {
                 std::lock_guard<std::mutex> lk(imgs.mu);                                  // imgs.lock() ... imgs.unlock()
+                if (buf_used[ib]) HIPCHECK(hipStreamWaitEvent(upload_stream, buf_free[ib], 0));     // the stitch of frame t-2 has read this buffer
                 for (int i = 0; i < o.views; ++i) {
                     if (o.nv12) {         // half the PCIe bytes: upload NV12, convert on the device
                         HIPCHECK(hipMemcpy2DAsync(nv12_imgs[i].data, nv12_imgs[i].step, imgs.v[i].p, (size_t)o.w, (size_t)o.w, o.h * 3 / 2,
-                                                  hipMemcpyHostToDevice, stitch_stream));
+                                                  hipMemcpyHostToDevice, upload_stream));
                     } else
                         HIPCHECK(hipMemcpy2DAsync(full_imgs[i].data, full_imgs[i].step, imgs.v[i].p, (size_t)o.w * 3, (size_t)o.w * 3, o.h,
-                                                  hipMemcpyHostToDevice, stitch_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
+                                                  hipMemcpyHostToDevice, upload_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
                 }
                 if (o.nv12) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47)
                     std::vector<ms_image> a(o.views), d(o.views);
                     for (int i = 0; i < o.views; ++i) { a[i] = msshim::wrap(nv12_imgs[i]); d[i] = msshim::wrap(full_imgs[i]); }
-                    msshim::check(ms_nv12_to_bgr_batch(a.data(), d.data(), o.views, (ms_stream)stitch_stream));
+                    msshim::check(ms_nv12_to_bgr_batch(a.data(), d.data(), o.views, (ms_stream)upload_stream));
                 }
+                HIPCHECK(hipEventRecord(up_done[ib], upload_stream));
+                HIPCHECK(hipStreamWaitEvent(stitch_stream, up_done[ib], 0));
             }
             if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)
                 msshim::cuda::resize(full_imgs, small_imgs, cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);      // all views, one launch
@@ -434,6 +450,7 @@ int main(int argc, char **argv)
             }
             s->seq = t;
             HIPCHECK(hipEventRecord(s->done, stitch_stream));
+            HIPCHECK(hipEventRecord(buf_free[ib], stitch_stream)); buf_used[ib] = true;
             results.push(s);
         }
         } catch (const msshim::Error &e) { failure = e.what(); }        // threads must be joined before the error is reported
