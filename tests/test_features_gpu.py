@@ -30,7 +30,7 @@ def as_set(kp, desc):
     return {(float(k[0]), float(k[1]), int(k[4])): (float(k[2]), float(k[3]), float(k[5]), bytes(d)) for k, d in zip(kp, desc)}
 
 
-@pytest.mark.parametrize("size,nfeatures,use_mask", [((640, 360), 500, False), ((517, 389), 2500, False), ((640, 360), 300, True)])
+@pytest.mark.parametrize("size,nfeatures,use_mask", [((640, 360), 500, False), ((517, 389), 2500, False), ((640, 360), 300, True), ((1920, 1080), 2500, False)])      # last: the size and budget featurefinder.cpp uses
 def test_orb_matches_oracle(ms, cuda, oracle, size, nfeatures, use_mask):
     """Keypoints as a set (the reference's own order is left to atomics and an unstable sort): same locations per level, bit-equal Harris responses
     (integer sums, float formula in the same order), angles, sizes and 256-bit descriptors."""
