@@ -406,8 +406,10 @@ def main():
     ap.add_argument("--no-live", action="store_true", help="skip the one-frame-per-call latency measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive run of the C++ host pipeline (stitch_app)")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--gather-every", type=int, default=1, help="N>1: gather the slabs of every k-th pass only (0 = pick k so that a rank sends about "
-                    "30 frames/s: the live rate, at which the sink's links are idle and compute scaling is what is measured)")
+    ap.add_argument("--gather-every", type=int, default=0, help="N>1: gather the slabs of every k-th pass only.  0 (default) = pick k so that a rank sends about 30 "
+                    "batches a second -- BASELINE configs[3] is a LIVE-RATE stream (30 fps), whose gather keeps the sink's links idle, so `value` measures the "
+                    "frame-parallel scaling; the rate with EVERY frame gathered (link-bound at benchmark rate) is reported beside it as `value_full_gather`; 1 = "
+                    "gather every pass in the main region")
     ap.add_argument("--frames", type=int, default=None, help="frames per step, split evenly over --streams contexts (default 48 = 3 x 16; cfg3: 16 on one context; cfg5: 24; 1 = live mode)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -639,10 +641,17 @@ def main():
         el_ng, _ = timed_region(max(1, args.steps // 2), args.warmup)
         no_gather = world * F * args.passes * max(1, args.steps // 2) / el_ng
         state["gather_on"] = True
-        if args.gather_every == 0:      # live rate: about 30 gathered frames per second and rank
+        if args.gather_every == 0:      # live rate: about 30 gathered batches per second and rank (still F x 30 frames/s: far above a 30 fps stream, far below a link)
             per_rank = no_gather / world
             state["gather_every"] = max(1, int(round(per_rank / 30.0 / F)))
     elapsed, n_gathered = timed_region(args.steps, args.warmup)
+    full_gather = None
+    if gather and state["gather_every"] != 1:      # and with every frame of every rank sent to the sink: what the sink's xGMI links carry at benchmark rate
+        keep = state["gather_every"]
+        state["gather_every"] = 1
+        el_fg, n_fg = timed_region(max(1, args.steps // 2), max(1, args.warmup // 2))
+        full_gather = (world * F * args.passes * max(1, args.steps // 2) / el_fg, n_fg * F * (world - 1) * slabs[0][0].numel() / el_fg / 1e9)
+        state["gather_every"] = keep
 
     if args.calib:
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255); b = torch.empty_like(a)
@@ -770,7 +779,7 @@ def main():
         if gather:
             par += ", RCCL gather of the %s pano rows on rank 0 (%.1f MB/frame)%s, overlapped" % (
                 args.gather_format.upper(), slabs[0][0].numel() / 1e6,
-                "" if state["gather_every"] == 1 else " for every %d-th pass (about 30 frames/s per rank: live rate)" % state["gather_every"])
+                "" if state["gather_every"] == 1 else " for every %d-th pass (about 30 batches/s per rank: a live-rate egress; `value_full_gather` = every pass gathered)" % state["gather_every"])
         if share:
             par += " [DEBUG: ranks share one GPU, gloo]"
         res = {
@@ -812,6 +821,9 @@ def main():
             res["value_no_gather"] = round(no_gather, 2)
             res["gather"] = {"gathered_passes": n_gathered, "of_passes": args.steps * args.passes, "every": state["gather_every"],
                              "GBps_into_sink": round(n_gathered * F * (world - 1) * slabs[0][0].numel() / elapsed / 1e9, 2)}
+            if full_gather is not None:
+                res["value_full_gather"] = round(full_gather[0], 2)
+                res["gather"]["full_gather_GBps_into_sink"] = round(full_gather[1], 2)
         if live is not None:
             res["live"] = live
         if pcie is not None:

@@ -39,12 +39,19 @@ def test_single_gpu_line_has_the_contract_keys():
 def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     env = dict(os.environ, MS_BENCH_SHARE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                        "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--gather-every", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "gather" in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
     assert d["value_no_gather"] > 0 and d["gather"]["gathered_passes"] == 4 and d["verified"] is True
+    # the default: a live-rate egress in the main region (`value`), the every-pass gather beside it
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29535",
+                        "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--passes", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = last_json(p.stdout)
+    assert d["verified"] is True and d["value"] > 0 and d["value_no_gather"] > 0 and d["value_full_gather"] > 0
+    assert d["gather"]["every"] > 1 and d["gather"]["gathered_passes"] < d["gather"]["of_passes"] and "live-rate" in d["config"]["parallelism"]
 
 
 def test_view_sharded_ranks_exchange_partials_and_match_the_unsharded_frame():
