@@ -733,8 +733,11 @@ def main():
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
             pj = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
             pcie = {"value": pj["frames_per_s"], "unit": "frames/s", "frames": pj["frames"],
-                    "how": "video-stitcher_amd/stitch_app: capture thread -> hipMemcpy2DAsync of all %d views from pinned memory per frame -> ms_stitch (1 frame) -> "
-                           "consume thread; %.1f MB over PCIe per frame" % (cfg["n"], cfg["n"] * cfg["w"] * cfg["h"] * 3 / 1e6)}
+                    "how": "video-stitcher_amd/stitch_app: capture thread -> hipMemcpy2DAsync of all %d views from pinned memory per frame (double-buffered, own stream) -> "
+                           "ms_stitch (1 frame) -> consume thread; %.1f MB over PCIe per frame" % (cfg["n"], cfg["n"] * cfg["w"] * cfg["h"] * 3 / 1e6)}
+            # the same with the cameras' NV12 uploaded (half the bytes) and cvtColor(YUV2BGR_NV12) on the device -- a per-camera CPU step in the reference (networking.cpp:45-47)
+            pr = subprocess.run(cmd + ["--nv12"], capture_output=True, text=True, timeout=180)
+            pcie["nv12_ingest_value"] = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])["frames_per_s"]
         except Exception as e:      # the number is optional; never fail the bench line on it
             pcie = {"error": str(e)[:200]}
 
