@@ -186,3 +186,9 @@ def test_random_plane_rig_matches_oracle(ms, cuda, oracle, n, w, h, step, hfov, 
     ref, refmask = b.blend()
     assert np.array_equal(host(out16), ref) and np.array_equal(host(comp.result_mask()), refmask)
     b.close(); comp.close()
+
+
+@pytest.mark.parametrize("n,bands,cpw", [(16, 7, False), (16, 5, True), (12, 6, False)])
+def test_maximum_views_and_bands(ms, cuda, oracle, n, bands, cpw):
+    """The limits of the C-ABI (MS_MAX_VIEWS = 16 views, num_bands up to 7) on a rig that is still cheap for the oracle: same checks as the random rigs."""
+    check_rig(ms, cuda, oracle, n, 96, 72, 1.6, 2048, bands, False, True, cpw, 4242 + n)
