@@ -144,14 +144,17 @@ def test_update_mask_matches_oracle(ms, cuda, oracle, margin):
     comp.close()
 
 
-def test_batched_frames_equal_single_frames(ms, cuda):
-    comp, cfg, gains = make_rig(ms, "mini6", max_frames=3)
+@pytest.mark.parametrize("nf", [3, 32])        # 32 frames x 6 views = the per-call limits of the ABI (MS_MAX_FRAMES, 192 sources)
+def test_batched_frames_equal_single_frames(ms, cuda, nf):
+    comp, cfg, gains = make_rig(ms, "mini6", max_frames=nf)
     pg = comp.pano_geom()
     shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
-    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(3)]
-    batch = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(3)]
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(nf)]
+    batch = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(nf)]
     comp.stitch(frames, out16s=batch)
-    for t in range(3):
+    with pytest.raises(ms.MsError):
+        ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), max_frames=33)
+    for t in range(nf):
         single = torch.zeros(shape, dtype=torch.int16, device=cuda)
         comp.stitch([frames[t]], out16s=[single])
         assert torch.equal(single, batch[t])
