@@ -397,6 +397,10 @@ MS_API int ms_mesh_default_params(ms_mesh_params *prm);      /* defs.h values, 1
  * sal_host[(i * mesh_cols + j) * 8 + t], NaN where triangle t of vertex (j, i) leaves the mesh.  The pixel pass (masked sum / sum of squares
  * per cell crop, cv::meanStdDev under a cv::fillConvexPoly mask) runs on the device. */
 MS_API int ms_mesh_saliency(const ms_image *warped_view, int mesh_cols, int mesh_rows, float *sal_host, ms_stream stream);
+/* The 8 triangle masks of one mesh cell as calcSmoothnessTerm builds them (meshwarper.cpp:527-551: `Mat mask(cell_h, cell_w)` +
+ * cv::fillConvexPoly of the triangle's corners), produced by the device kernel ms_mesh_saliency uses.  masks_host: 8 * cell_h * cell_w bytes
+ * (0 / 255), triangle-major; counts_host (may be NULL): 8 set-pixel counts.  Inspection / test aid. */
+MS_API int ms_mesh_triangle_masks(int cell_w, int cell_h, uint8_t *masks_host, unsigned *counts_host, ms_stream stream);
 /* createMesh's loop + solve (meshwarper.cpp:279-301): for every view calcLocalTerm, calcGlobalTerm, calcSmoothnessTerm[, calcTemporalLocalTerm],
  * then x = LeastSquaresConjugateGradient(A).solve(b) in fp64 on the device and convertVectorToMesh.
  * warped_views[n_views]: the remapped frames `images[idx]` (device 8UC3; mesh_size = their sizes).  matches: the per-view lists back to back,
@@ -469,15 +473,22 @@ MS_API int ms_get_needed_views(const ms_ctx *ctx, unsigned *mask);
 MS_API int ms_stitch_timed(ms_ctx *ctx, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s,
                            ms_stream stream, int cap, const char **names, float *ms);
 
-/* Profiling aid: streaming device-to-device copy (16 B per lane) of a known byte count, used to calibrate the rocprofv3
- * FETCH_SIZE / WRITE_SIZE counters (tools/profile_traffic.sh). */
+/* Profiling aid: tuned streaming device-to-device copy (16 B per lane, four loads in flight, non-temporal) of a known byte count.
+ * Calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/profile_traffic.sh) and is the measured bandwidth ceiling the
+ * per-frame kernels are compared with (bench.py `ceiling`; no reference counterpart). */
 MS_API int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream stream);
+/* ... and its read-only companion (the read side alone sustains more than a copy: the per-frame kernels read 3-5x what they write). */
+MS_API int ms_calib_read(const void *src, size_t bytes, ms_stream stream);
 
 /* Self-test of the shared-reciprocal division used by the band kernels (normalizeUsingWeightKernel32F,
  * multiband_blend.cu:85-100 divides three channels by the same w + 1e-5): for each of the n HOST denominators,
  * all 65536 int16 numerators are divided both ways on the device; returns the number of results whose bits differ
  * from the compiler's correctly rounded a / d (expected 0), or a negative ms_status. */
 MS_API int ms_selftest_divide(const float *denominators_host, int n, ms_stream stream);
+/* The same comparison for EVERY float denominator in [d_lo, d_hi] (all bit patterns in between) x all 65536 int16 numerators, enumerated
+ * on the device.  [1e-5, 64) -- every value a weight sum + 1e-5 of up to 16 views can take, with margin -- is 1.9e8 denominators = 1.2e13
+ * quotients (tests/test_prims_gpu.py runs it: the proof by enumeration behind the bit-exactness of the normalise step). */
+MS_API int ms_selftest_divide_range(float d_lo, float d_hi, unsigned long long *mismatches_out, unsigned long long *checked_out, ms_stream stream);
 
 /* Self-test of the single-instruction saturate_cast<uchar>(float) (v_cvt_pk_u8_f32) used by the warp kernels: compares it with
  * the rint / clamp / NaN->0 definition over ALL 2^32 float bit patterns on the device; *mismatches_out must come back 0. */

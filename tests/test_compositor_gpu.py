@@ -144,6 +144,64 @@ def test_update_mask_matches_oracle(ms, cuda, oracle, margin):
     comp.close()
 
 
+def test_synchronous_update_mask_is_safe_beside_a_stitching_thread(ms, cuda):
+    """with update_mask_margin = 0, ms_update_mask rebuilds (reallocates) the static tables.  Issued from a second thread while the first
+    keeps calling ms_stitch it must neither crash nor corrupt a frame: the rebuild and the stitch enqueue exclude each other (ms_ctx::tables_mu), and
+    the rebuild waits for the stitches already on the GPU.  Every frame stitched meanwhile must equal the result before OR after some prefix of the
+    updates, and the final frame a sequential context's."""
+    import threading
+    comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True, update_mask_margin=0)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 2)) for i in range(cfg["n"])]]
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    meshes = []
+    for i in range(cfg["n"]):
+        r = comp.view_geom(i).roi
+        meshes.append(synth.mesh(r.width, r.height, 9, 11, phase=0.3 * i, amp=5.0))
+        comp.set_mesh(i, *meshes[i])
+    # the sequential answers: after 0, 1, 2, ... updates
+    seq, _, _ = make_rig(ms, "mini6", enable_cpw=True, update_mask_margin=0)
+    for i in range(cfg["n"]):
+        seq.set_mesh(i, *meshes[i])
+    answers = []
+    o = torch.zeros(shape, dtype=torch.int16, device=cuda)
+    seq.stitch(frames, out16s=[o]); torch.cuda.synchronize(); answers.append(host(o).copy())
+    order = [0, 3, 1, 4]
+    for v in order:
+        seq.update_mask(v)
+        seq.stitch(frames, out16s=[o]); torch.cuda.synchronize(); answers.append(host(o).copy())
+    seq.close()
+    errors, seen, stop = [], [], threading.Event()
+
+    def stitcher():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                out = torch.zeros(shape, dtype=torch.int16, device=cuda)
+                while not stop.is_set():
+                    comp.stitch(frames, out16s=[out]); st.synchronize()
+                    seen.append(host(out).copy())
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    t = threading.Thread(target=stitcher)
+    t.start()
+    try:
+        st2 = torch.cuda.Stream()
+        with torch.cuda.stream(st2):
+            for v in order:
+                comp.update_mask(v)
+    finally:
+        stop.set(); t.join()
+    assert not errors, errors
+    assert len(seen) >= 1
+    for k, fr in enumerate(seen):
+        assert any(np.array_equal(fr, a) for a in answers), "frame %d of %d matches no sequential state" % (k, len(seen))
+    comp.stitch(frames, out16s=[o]); torch.cuda.synchronize()
+    assert np.array_equal(host(o), answers[-1])
+    comp.close()
+
+
 @pytest.mark.parametrize("nf", [3, 32])        # 32 frames x 6 views = the per-call limits of the ABI (MS_MAX_FRAMES, 192 sources)
 def test_batched_frames_equal_single_frames(ms, cuda, nf):
     comp, cfg, gains = make_rig(ms, "mini6", max_frames=nf)

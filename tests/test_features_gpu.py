@@ -91,6 +91,17 @@ def test_find_homography_ransac_matches_oracle(ms, cuda, n, outliers, seed):
         assert np.linalg.norm(H / H[2, 2] - Htrue) / np.linalg.norm(Htrue) < 2e-2
 
 
+def test_orb_rejects_thresholds_the_kernels_cannot_honour(ms, cuda):
+    """edge_threshold below the reach of the descriptor / angle / Harris windows would read outside the level image; fast_threshold 0 would make
+    the score map's "no corner" value a corner: both are argument errors, not device faults."""
+    g = torch.zeros((120, 160), dtype=torch.uint8, device="cuda")
+    for kw in (dict(edge_threshold=18), dict(edge_threshold=0), dict(fast_threshold=0), dict(fast_threshold=255)):
+        with pytest.raises(ms.MsError):
+            ms.orb_detect_and_compute(g, nfeatures=100, **kw)
+    kp, _ = ms.orb_detect_and_compute(g, nfeatures=100, edge_threshold=19, fast_threshold=1)      # the smallest legal values run (and find nothing in a flat image)
+    assert len(kp) == 0
+
+
 def test_find_homography_degenerate_inputs(ms, cuda):
     src = np.array([[0, 0], [1, 0], [0, 1]], np.float32)
     H, m = ms.find_homography_ransac(src, src)

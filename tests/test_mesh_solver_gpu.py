@@ -33,6 +33,20 @@ def test_saliency_is_bit_equal_to_oracle(ms, cuda, w, h, M, N):
         assert got[5, 1, 0] == np.float32(np.sqrt(0.5))
 
 
+def test_triangle_masks_equal_fill_convex_poly(ms, cuda):
+    """The device kernel's closed-form row spans against the oracle's general cv::fillConvexPoly restatement (drawing.cpp:1109-1271): every
+    cell size up to 24 x 24 (incl. the degenerate 1-pixel-wide / 1-pixel-high cells whose diagonal clipLine rejects), the cell sizes of the
+    10 x 10 and 40 x 40 meshes on 1080p-class views, and very flat / very tall cells."""
+    sizes = [(w, h) for w in range(1, 25) for h in range(1, 25)] + [(213, 120), (106, 69), (49, 27), (24, 16), (640, 37), (37, 640), (1, 300), (300, 1), (333, 332)]
+    for (w, h) in sizes:
+        got, cnt = ms.mesh_triangle_masks(w, h)
+        for t in range(8):
+            ref = mo.triangle_mask(t, np.float32(w) + np.float32(0.4), np.float32(h) + np.float32(0.7))      # float cell sizes truncate to (w, h)
+            assert ref.shape == (h, w)
+            assert np.array_equal(got[t], ref), (t, w, h)
+            assert cnt[t] == int(np.count_nonzero(ref))
+
+
 def test_saliency_accepts_pitched_views(ms, cuda):
     rng = np.random.default_rng(1)
     big = torch.from_numpy(rng.integers(0, 256, (80, 140, 3), dtype=np.uint8)).cuda()

@@ -235,6 +235,23 @@ def test_shared_reciprocal_division_is_ieee(ms, cuda):
     assert ms.selftest_divide(np.array(dens, np.float32)) == 0
 
 
+def test_shared_reciprocal_division_is_ieee_for_every_weight_sum(ms, cuda):
+    """... and by enumeration: EVERY float32 denominator in [1e-5, 64) -- a weight sum of up to 16 views + 1e-5 lies in [1e-5, 16.00001] -- times
+    all 65536 int16 numerators (1.2e13 quotients, enumerated on the device).  MS_TEST_DIVIDE_FULL=0 restricts the run to the binades
+    [1e-5, 2^-16) and [0.5, 4) for a quick pass; the default is the full range."""
+    import os
+    if os.environ.get("MS_TEST_DIVIDE_FULL", "1") == "0":
+        ranges = [(1e-5, float(np.nextafter(np.float32(2.0 ** -16), np.float32(0)))), (0.5, float(np.nextafter(np.float32(4.0), np.float32(0))))]
+    else:
+        ranges = [(1e-5, float(np.nextafter(np.float32(64.0), np.float32(0))))]
+    total = 0
+    for lo, hi in ranges:
+        bad, n = ms.selftest_divide_range(lo, hi)
+        assert bad == 0, (lo, hi, bad)
+        total += n
+    assert total >= (1 << 23) * 65536
+
+
 @pytest.mark.parametrize("size", [(628, 3840), (36, 50), (2, 2), (10, 6)])
 def test_bgr_to_i420(ms, cuda, oracle, size):
     """consume()'s cvtColor(COLOR_BGR2YUV_I420) (timed.cpp:308-316): BT.601 fixed point, chroma from the top-left pixel."""

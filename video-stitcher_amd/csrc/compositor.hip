@@ -1077,6 +1077,24 @@ __global__ void __launch_bounds__(256) k_selftest_divide(const float *__restrict
     if (__float_as_uint(ref) != __float_as_uint(got)) atomicAdd(mismatches, 1u);
 }
 
+// ... and over a whole RANGE of denominators: every float whose bit pattern lies in [bits0, bits0 + n) (positive floats are ordered like their
+// bits), one lane per denominator, all 65536 int16 numerators each.  ms_selftest_divide_range walks [1e-5, 64) with it: the proof, by
+// enumeration, that DivBy is the correctly rounded quotient for every weight sum a context can hold.
+__global__ void __launch_bounds__(256) k_selftest_divide_range(unsigned bits0, unsigned n, unsigned long long *mismatches)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    unsigned bad = 0;
+    if (j < n) {
+        const float d = __uint_as_float(bits0 + j);
+        const DivBy div(d);
+        for (int i = -32768; i < 32768; ++i) {
+            const float a = (float)i;
+            bad += __float_as_uint(a / d) != __float_as_uint(div(a));
+        }
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // exhaustive check of the one-instruction saturate_cast<uchar>(float) against its definition: all 2^32 bit patterns
 __global__ void __launch_bounds__(256) k_selftest_cvt_u8(unsigned long long *mismatches)
 {
@@ -1090,11 +1108,46 @@ __global__ void __launch_bounds__(256) k_selftest_cvt_u8(unsigned long long *mis
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
-// PMC calibration: a plain 16-byte-per-lane streaming copy of a known size, so that FETCH_SIZE / WRITE_SIZE of the
-// real kernels can be scaled by what the counters report for a known byte count (MI355X guide, HBM section)
-__global__ void __launch_bounds__(256) k_calib_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+// PMC calibration AND the bandwidth ceiling the per-frame kernels are compared with: a tuned 16-byte-per-lane
+// streaming copy of a known size.  Four independent non-temporal loads in flight per lane, each wave-instruction one contiguous 1 KiB
+// segment, 16 workgroups of 256 lanes per CU: the fastest of the 130 variants of tools/copy_probe.hip on MI355X (6.08 TB/s read + written;
+// the one-load-in-flight loop this replaces reached 4.87 - 5.49 TB/s depending on the box; profiles/r03_copy_probe.txt).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_calib_copy(const u32x4_t *__restrict__ src, u32x4_t *__restrict__ dst, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    constexpr int U = 4;
+    const size_t chunk = (size_t)U * 256;
+    for (size_t base = (size_t)blockIdx.x * chunk; base < n16; base += (size_t)gridDim.x * chunk) {
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < n16) v[u] = __builtin_nontemporal_load(src + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < n16) __builtin_nontemporal_store(v[u], dst + i);
+        }
+    }
+}
+// read-only companion (XOR-reduced, one dword written per workgroup at most): what the read side alone sustains (7.0 - 7.2 TB/s non-temporal)
+__global__ void __launch_bounds__(256) k_calib_read(const u32x4_t *__restrict__ src, unsigned *__restrict__ sink, size_t n16)
+{
+    constexpr int U = 8;
+    const size_t chunk = (size_t)U * 256;
+    u32x4_t acc = {0u, 0u, 0u, 0u};
+    for (size_t base = (size_t)blockIdx.x * chunk; base < n16; base += (size_t)gridDim.x * chunk) {
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            v[u] = i < n16 ? __builtin_nontemporal_load(src + i) : acc;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = 1u;      // (keeps the loads alive)
 }
 
 // ---- static-table kernels ---------------------------------------------------------------------
@@ -1469,6 +1522,11 @@ struct ms_ctx {
     int mesh_parity = 0;
     std::mutex mesh_mu;                // guards the active indices / events shared with ms_stitch: held only across enqueues, never across a host wait
     std::mutex mesh_update_mu;         // serialises mesh updates among themselves (shared scratch, staging slots); taken BEFORE mesh_mu
+    // Held by ms_stitch for the length of its enqueue and by everything that REBUILDS the static tables (ms_init_blender, and through it the synchronous
+    // ms_update_mask): a rebuild on the recalibration thread reallocates weights, sums and work lists, so it must neither overlap a stitch that is
+    // being enqueued (this lock) nor one that still runs on the GPU (the rebuild first waits for last_stitch under the lock).  Lock order:
+    // mesh_update_mu, tables_mu, mesh_mu.  The enqueue-only update paths (ms_set_mesh, ms_update_mask with a margin) never take it.
+    std::recursive_mutex tables_mu;
     hipStream_t last_stream = nullptr; bool last_stream_set = false;
     hipEvent_t last_stitch = nullptr;
     std::atomic<bool> stitch_pending{false};
@@ -2104,6 +2162,8 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     if (!c) return fail(MS_ERR_INVALID, "null context");
     if (!c->maps_built || !c->masks_built) return fail(MS_ERR_STATE, "ms_init_blender: maps and masks must be built first");
     hipStream_t st = as_stream(stream);
+    std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);      // no ms_stitch enqueue while the tables are rebuilt ...
+    if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch)); // ... and none still reading the old ones on the GPU
     const int nb = c->bg.num_bands, N = c->N, F = c->cfg.max_frames;
 
     // ---- layout of every per-view level -------------------------------------------------------
@@ -2572,6 +2632,7 @@ static int update_mask_async(ms_ctx *c, int view, hipStream_t st)
         from = c->tab_active; mesh_idx = c->mesh_active[view];
         if (c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
         if (c->mesh_ready[view]) MS_HIP(hipStreamWaitEvent(st, c->mesh_ready[view], 0));
+        if (c->mesh_chain_set) MS_HIP(hipStreamWaitEvent(st, c->mesh_chain, 0));
         if (c->tab_wait) MS_HIP(hipStreamWaitEvent(st, c->tab_ready, 0));
     }
     const bool to_alt = from == 0;
@@ -2628,6 +2689,9 @@ static int update_mask_async(ms_ctx *c, int view, hipStream_t st)
         std::lock_guard<std::mutex> mk(c->mesh_mu);
         MS_HIP(hipEventRecord(c->tab_ready, st));
         c->tab_active = from ^ 1; c->tab_wait = true;
+        // the re-warp above READS this view's mesh slot and displacement entry: later mesh updates (any stream) are ordered behind it through the
+        // chain event they all wait for, so the second ms_set_mesh from now cannot overwrite the slot under the re-warp
+        if (c->mesh_chain) { MS_HIP(hipEventRecord(c->mesh_chain, st)); c->mesh_chain_set = true; }
     }
     c->use_eff[view] = true;
     return MS_OK;
@@ -2644,6 +2708,7 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
     hipStream_t st = as_stream(stream);
     std::lock_guard<std::mutex> ulk(c->mesh_update_mu);
     if (c->cfg.update_mask_margin > 0) return update_mask_async(c, view, st);
+    std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);      // synchronous form: safe against a concurrent ms_stitch, which blocks for the rebuild
     if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
     if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
@@ -2699,6 +2764,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
                        int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{}, ms_image *out_i420 = nullptr)
 {
     if (!c) return fail(MS_ERR_INVALID, "null context");
+    std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);      // a synchronous table rebuild on another thread (ms_update_mask without a margin) waits for this enqueue, and vice versa
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_stitch: call ms_build_maps / masks / ms_init_blender first");
     MS_CHECK(n_frames >= 1 && n_frames <= c->cfg.max_frames, "ms_stitch: n_frames %d not in [1,%d]", n_frames, c->cfg.max_frames);
     const int N = c->N, nb = c->pano.nb, F = n_frames;
@@ -3084,8 +3150,10 @@ int ms_get_weight_level(const ms_ctx *c, int view, int level, ms_image *w)
     if (int e = ctx_check_view(c, view)) return e;
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_weight_level: call ms_init_blender first");
     MS_CHECK(w && level >= 0 && level <= c->pano.nb, "ms_get_weight_level: bad level %d", level);
-    if (c->tab_wait) MS_HIP(hipEventSynchronize(c->tab_ready));      // an enqueue-only ms_update_mask may still be filling the active copy
-    const LevelDesc &L = (c->tab_active == 1 ? c->alt.h_views : c->h_views)[view].lv[level];
+    int active; bool wait;                                            // the pair is swapped by the recalibration thread under mesh_mu
+    { std::lock_guard<std::mutex> mk(const_cast<ms_ctx *>(c)->mesh_mu); active = c->tab_active; wait = c->tab_wait; }
+    if (wait) MS_HIP(hipEventSynchronize(c->tab_ready));              // an enqueue-only ms_update_mask may still be filling the active copy
+    const LevelDesc &L = (active == 1 ? c->alt.h_views : c->h_views)[view].lv[level];
     *w = ms_image{(void *)L.wgt, (size_t)L.wpitch * sizeof(float), L.w, L.h, MS_32FC1};
     return MS_OK;
 }
@@ -3104,16 +3172,37 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
 {
     if (!c || !m) return fail(MS_ERR_INVALID, "null argument");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_result_mask: call ms_init_blender first");
-    if (c->tab_wait) MS_HIP(hipEventSynchronize(c->tab_ready));
-    *m = ms_image{c->tab_active == 1 ? c->alt.result_mask.p : c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
+    int active; bool wait;
+    { std::lock_guard<std::mutex> mk(c->mesh_mu); active = c->tab_active; wait = c->tab_wait; }
+    if (wait) MS_HIP(hipEventSynchronize(c->tab_ready));
+    *m = ms_image{active == 1 ? c->alt.result_mask.p : c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
     return MS_OK;
+}
+
+static int calib_grid()
+{
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 16 * cus;
 }
 
 int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream stream)
 {
     if (int e = require_device()) return e;
     MS_CHECK(src && dst && bytes >= 16 && bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "ms_calib_copy: 16-byte aligned buffers and size required");
-    k_calib_copy<<<2048, 256, 0, as_stream(stream)>>>((const uint4 *)src, (uint4 *)dst, bytes / 16);
+    k_calib_copy<<<calib_grid(), 256, 0, as_stream(stream)>>>((const u32x4_t *)src, (u32x4_t *)dst, bytes / 16);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
+int ms_calib_read(const void *src, size_t bytes, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(src && bytes >= 16 && bytes % 16 == 0 && ((uintptr_t)src & 15) == 0, "ms_calib_read: 16-byte aligned buffer and size required");
+    unsigned *sink = (unsigned *)device_scratch().get(16);
+    if (!sink) return fail(MS_ERR_NOMEM, "ms_calib_read: no device scratch");
+    k_calib_read<<<calib_grid(), 256, 0, as_stream(stream)>>>((const u32x4_t *)src, sink, bytes / 16);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
@@ -3151,6 +3240,32 @@ int ms_selftest_divide(const float *dens_host, int n, ms_stream stream)
     MS_HIP(hipStreamSynchronize(st));
     d.release(); cnt.release();
     return (int)h;
+}
+
+int ms_selftest_divide_range(float d_lo, float d_hi, unsigned long long *mismatches_out, unsigned long long *checked_out, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(mismatches_out && d_lo > 0.f && d_hi >= d_lo && d_hi < 3.0e38f, "ms_selftest_divide_range: needs 0 < d_lo <= d_hi (finite) and an output");
+    hipStream_t st = as_stream(stream);
+    DevBuf cnt;
+    if (int e = cnt.alloc(sizeof(unsigned long long))) return e;
+    MS_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), st));
+    unsigned b0, b1;
+    memcpy(&b0, &d_lo, 4); memcpy(&b1, &d_hi, 4);
+    unsigned long long total = 0;
+    for (unsigned long long b = b0; b <= b1; b += (1u << 22)) {          // launches of <= 4 M denominators (a fraction of a second each)
+        const unsigned n = (unsigned)std::min<unsigned long long>(1u << 22, (unsigned long long)b1 - b + 1);
+        k_selftest_divide_range<<<(n + 255) / 256, 256, 0, st>>>((unsigned)b, n, (unsigned long long *)cnt.p);
+        MS_LAUNCH_CHECK();
+        total += n;
+    }
+    unsigned long long h = 0;
+    MS_HIP(hipMemcpyAsync(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
+    cnt.release();
+    *mismatches_out = h;
+    if (checked_out) *checked_out = total * 65536ull;
+    return MS_OK;
 }
 
 }  // extern "C"

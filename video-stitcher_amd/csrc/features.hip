@@ -445,6 +445,11 @@ int ms_orb_detect_and_compute(const ms_image *gray, const ms_image *mask, const 
     MS_CHECK(!mask || (mask->data && mask->type == MS_8UC1 && mask->rows == gray->rows && mask->cols == gray->cols), "ms_orb_detect_and_compute: mask must be 8UC1 of the image size");
     MS_CHECK(prm->nlevels >= 1 && prm->nlevels <= 16 && prm->first_level == 0 && prm->patch_size == 31 && prm->nfeatures >= 1 && prm->scale_factor > 1.f,
              "ms_orb_detect_and_compute: supports first_level 0, patch_size 31 (the learned pattern), 1..16 levels");
+    // the device kernels read a (rotated) 31-px patch, the 15-px intensity-centroid disc and the 7 x 7 Harris block + Sobel halo around every keypoint WITHOUT bounds
+    // checks: keypoints must keep the creator's border (orb.cpp:686-689, edgeThreshold 31 by default; 19 = ceil(18.4) is the reach of the rotated pattern);
+    // a FAST threshold of 0 would make score 0 -- "no corner" in the score map -- a valid corner (fast.cu:224-282 has the same encoding), 255 can never fire
+    MS_CHECK(prm->edge_threshold >= 19 && prm->edge_threshold >= prm->patch_size / 2 + 1 && prm->fast_threshold >= 1 && prm->fast_threshold <= 254,
+             "ms_orb_detect_and_compute: edge_threshold %d must be >= 19 and fast_threshold %d in [1, 254]", prm->edge_threshold, prm->fast_threshold);
     MS_CHECK(desc->type == MS_8UC1 && desc->cols == 32 && desc->rows >= max_keypoints && max_keypoints >= prm->nfeatures, "ms_orb_detect_and_compute: descriptors must be 8UC1 max_keypoints x 32, max_keypoints >= nfeatures");
     hipStream_t st = as_stream(stream);
     const int half = prm->patch_size / 2;

@@ -9,7 +9,8 @@
 //           k_lscg_cols     A^T residual, z     (CSC, 16 lanes per column)
 //           all fp64; every reduction is a fixed-order tree over per-block partials (<= LSCG_PARTS blocks), re-summed by each consumer
 //           block, so the solve is run-to-run reproducible and needs no in-launch hand-off between workgroups.
-//   host    triangle masks (cv::fillConvexPoly restated), coefficient arithmetic in the reference's float expressions, CSR/CSC layout.
+//           k_tri_masks     the 8 triangle masks of a cell (what cv::fillConvexPoly produces for them), closed form per row
+//   host    coefficient arithmetic in the reference's float expressions, CSR/CSC layout.
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -20,127 +21,106 @@
 namespace ms {
 namespace {
 
-// ------------------------------------------------------------------------------------------------ cv::fillConvexPoly, 3 points
-// drawing.cpp:1109-1271 (line_type 8, shift 0): the polygon outline with Line() (8-connected Bresenham of LineIterator :165-252 with
-// left_to_right, clipped by clipLine :97-148), then the scan conversion with 16.16 fixed-point edges.
-struct Pt { long long x, y; };
-constexpr int XY_SHIFT = 16;
-constexpr long long XY_ONE = 1ll << XY_SHIFT;
-
-bool clip_line(long long w, long long h, Pt &a, Pt &b)
-{
-    const long long right = w - 1, bottom = h - 1;
-    if (w <= 0 || h <= 0) return false;
-    long long &x1 = a.x, &y1 = a.y, &x2 = b.x, &y2 = b.y;
-    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
-    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
-    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-        long long e;
-        if (c1 & 12) { e = c1 < 8 ? 0 : bottom; x1 += (long long)((double)(e - y1) * (x2 - x1) / (y2 - y1)); y1 = e; c1 = (x1 < 0) + (x1 > right) * 2; }
-        if (c2 & 12) { e = c2 < 8 ? 0 : bottom; x2 += (long long)((double)(e - y2) * (x2 - x1) / (y2 - y1)); y2 = e; c2 = (x2 < 0) + (x2 > right) * 2; }
-        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-            if (c1) { e = c1 == 1 ? 0 : right; y1 += (long long)((double)(e - x1) * (y2 - y1) / (x2 - x1)); x1 = e; c1 = 0; }
-            if (c2) { e = c2 == 1 ? 0 : right; y2 += (long long)((double)(e - x2) * (y2 - y1) / (x2 - x1)); x2 = e; c2 = 0; }
-        }
-    }
-    return (c1 | c2) == 0;
-}
-
-void draw_line8(std::vector<uint8_t> &img, int w, int h, Pt a, Pt b)
-{
-    if (a.x < 0 || a.x >= w || b.x < 0 || b.x >= w || a.y < 0 || a.y >= h || b.y < 0 || b.y >= h)
-        if (!clip_line(w, h, a, b)) return;
-    long long dx = b.x - a.x, dy = b.y - a.y;
-    if (dx < 0) { dx = -dx; dy = -dy; a = b; }                  // walk from the left end point
-    const int ystep = dy < 0 ? -1 : 1;
-    if (dy < 0) dy = -dy;
-    int mx = 1, my = 0, px = 0, py = ystep;                     // "minus" step (every pixel), "plus" step (when err < 0)
-    if (dy > dx) { std::swap(dx, dy); std::swap(mx, px); std::swap(my, py); }
-    long long err = dx - 2 * dy;
-    long long x = a.x, y = a.y;
-    for (long long i = 0; i <= dx; ++i) {
-        img[(size_t)y * w + x] = 255;
-        const bool neg = err < 0;
-        err += -2 * dy + (neg ? 2 * dx : 0);
-        x += mx + (neg ? px : 0);
-        y += my + (neg ? py : 0);
-    }
-}
-
-void fill_convex3(std::vector<uint8_t> &img, int w, int h, const Pt v[3])
-{
-    const int n = 3;
-    long long xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y;
-    int imin = 0;
-    Pt p0 = v[n - 1];
-    for (int i = 0; i < n; ++i) {
-        if (v[i].y < ymin) { ymin = v[i].y; imin = i; }
-        ymax = std::max(ymax, v[i].y); xmax = std::max(xmax, v[i].x); xmin = std::min(xmin, v[i].x);
-        draw_line8(img, w, h, p0, v[i]);
-        p0 = v[i];
-    }
-    if (xmax < 0 || ymax < 0 || xmin >= w || ymin >= h) return;
-    ymax = std::min<long long>(ymax, h - 1);
-    struct { int idx, di; long long x, dx; long long ye; } e[2] = {{imin, 1, -XY_ONE, 0, ymin}, {imin, n - 1, -XY_ONE, 0, ymin}};
-    int edges = n;
-    long long y = ymin;
-    do {
-        for (int i = 0; i < 2; ++i) {
-            if (y >= e[i].ye) {
-                int idx0 = e[i].idx, idx = idx0 + e[i].di;
-                if (idx >= n) idx -= n;
-                for (; edges-- > 0;) {
-                    const long long ty = v[idx].y;
-                    if (ty > y) {
-                        const long long xs = v[idx0].x << XY_SHIFT, xe = v[idx].x << XY_SHIFT;
-                        e[i].ye = ty;
-                        e[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
-                        e[i].x = xs;
-                        e[i].idx = idx;
-                        break;
-                    }
-                    idx0 = idx;
-                    idx += e[i].di;
-                    if (idx >= n) idx -= n;
-                }
-            }
-        }
-        if (edges < 0) break;
-        if (y >= 0) {
-            const int l = e[0].x > e[1].x ? 1 : 0, r = 1 - l;
-            long long xx1 = (e[l].x + (XY_ONE >> 1)) >> XY_SHIFT, xx2 = (e[r].x + (XY_ONE >> 1)) >> XY_SHIFT;
-            if (xx2 >= 0 && xx1 < w) {
-                xx1 = std::max<long long>(xx1, 0);
-                xx2 = std::min<long long>(xx2, w - 1);
-                for (long long x = xx1; x <= xx2; ++x) img[(size_t)y * w + x] = 255;
-            }
-        }
-        e[0].x += e[0].dx;
-        e[1].x += e[1].dx;
-    } while (++y <= ymax);
-}
-
+// ------------------------------------------------------------------------------------------------ triangle masks of a mesh cell
 // meshwarper.cpp:441-486: offsets (x, y) of V1, V2 (the vertex itself), V3 of the 8 triangles around a vertex
 const int TRI[8][3][2] = {
     {{-1, 0}, {0, 0}, {-1, -1}}, {{0, -1}, {0, 0}, {-1, -1}}, {{0, -1}, {0, 0}, {1, -1}}, {{1, 0}, {0, 0}, {1, -1}},
     {{-1, 0}, {0, 0}, {-1, 1}},  {{0, 1}, {0, 0}, {-1, 1}},   {{0, 1}, {0, 0}, {1, 1}},   {{1, 0}, {0, 0}, {1, 1}},
 };
 
-// meshwarper.cpp:527-551: Mat mask(cell_height, cell_width) = 0; fillConvexPoly(mask, {Vi_rel * cell}, 255)
-void triangle_mask(int t, float cell_w, float cell_h, std::vector<uint8_t> &mask, int &mw, int &mh)
+// meshwarper.cpp:527-551 fills `Mat mask(cell_height, cell_width)` with cv::fillConvexPoly of the triangle's three vertices in
+// cell-relative pixels.  Those vertices are always three CORNERS of the W x H cell (W = (int)cell_width, H = (int)cell_height;
+// the corners at x = W / y = H lie one pixel outside the mask), so each mask is one of the four halves of the cell cut by a diagonal,
+// and what fillConvexPoly (drawing.cpp:1109-1271) sets in row y has a closed form -- evaluated here by one lane per row, no polygon
+// walker and no line iterator:
+//   * scan conversion: between the triangle's vertical leg (x = 0 or W) and its diagonal, both in 16.16 fixed point with the rounded slope
+//     s = trunc((2 dX + H) / 2H), dX = +-W << 16: x_d(y) = x_top + y s; columns round(min) .. round(max) (+ 0x8000 >> 16), clipped to the mask;
+//   * outline: a leg on row 0 sets the whole row, a leg on column 0 the whole column (the legs on row H / column W are outside and
+//     rejected by clipLine); the diagonal is an 8-connected Bresenham line from its LEFT end between the end points clipLine (:97-148)
+//     leaves inside the mask.  After k steps along its major axis the minor coordinate of that line is round-half-down(k b / a)
+//     = floor((2 b k + a - 1) / 2a) (a >= b the axis extents; LineIterator's error term starts at a - 2b and steps when negative), so a
+//     y-major line sets one pixel per row and an x-major line the run of k with that minor coordinate.
+// The mask is the union.  oracle/mesh_oracle.py keeps the general fillConvexPoly restatement; tests compare the two bit for bit.
+struct TriShape {
+    int row0, col0;       // the leg on row 0 / on column 0 belongs to the triangle
+    int main_diag;        // hypotenuse (0,0)-(W,H) rather than (W,0)-(0,H)
+    int leg_right;        // the vertical leg is at x = W rather than x = 0
+};
+struct TriShapes { TriShape s[8]; };
+
+TriShapes triangle_shapes()
 {
-    mw = (int)cell_w; mh = (int)cell_h;
-    mask.assign((size_t)mw * mh, 0);
-    int rel[3][2], minx = 0, miny = 0;
-    for (int k = 0; k < 3; ++k) { rel[k][0] = TRI[t][k][0]; rel[k][1] = TRI[t][k][1]; minx = std::min(minx, rel[k][0]); miny = std::min(miny, rel[k][1]); }
-    Pt v[3];
-    for (int k = 0; k < 3; ++k) {
-        if (minx < 0) rel[k][0]++;
-        if (miny < 0) rel[k][1]++;
-        v[k].x = (int)(rel[k][0] * cell_w);
-        v[k].y = (int)(rel[k][1] * cell_h);
+    TriShapes out;
+    for (int t = 0; t < 8; ++t) {
+        int minx = 0, miny = 0;
+        for (int k = 0; k < 3; ++k) { minx = std::min(minx, TRI[t][k][0]); miny = std::min(miny, TRI[t][k][1]); }
+        bool corner[2][2] = {{false, false}, {false, false}};      // [x][y] in cell units after the shift into the cell
+        for (int k = 0; k < 3; ++k) corner[TRI[t][k][0] - minx][TRI[t][k][1] - miny] = true;
+        TriShape &S = out.s[t];
+        S.row0 = corner[0][0] && corner[1][0];
+        S.col0 = corner[0][0] && corner[0][1];
+        S.main_diag = corner[0][0] && corner[1][1];
+        // the third corner (the right angle) carries the vertical leg
+        S.leg_right = S.main_diag ? !corner[0][1] : !corner[0][0];
     }
-    fill_convex3(mask, mw, mh, v);
+    return out;
+}
+
+__device__ __forceinline__ long long floor_div(long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }      // b > 0
+
+// block t = triangle t; one lane per mask row; nz[t] = number of set pixels
+__global__ void __launch_bounds__(256) k_tri_masks(TriShapes shapes, int W, int H, uint8_t *__restrict__ masks, unsigned *__restrict__ nz)
+{
+    const int t = blockIdx.x;
+    const TriShape S = shapes.s[t];
+    uint8_t *m = masks + (size_t)t * W * H;
+    // diagonal of the scan conversion: from its top end down, rounded 16.16 slope (C division truncates toward zero)
+    const long long top = (S.main_diag ? 0ll : (long long)W) << 16, bot = (S.main_diag ? (long long)W : 0ll) << 16;
+    const long long num = (bot - top) * 2 + H;
+    const long long slope = num >= 0 ? num / (2ll * H) : -((-num) / (2ll * H));
+    const long long leg = (S.leg_right ? (long long)W : 0ll) << 16;
+    // diagonal of the outline: left end (lx, ly), extents (ax, ay) >= 0, direction of y from the left end
+    int lx = 0, ly = 0, ax = 0, ay = 0, ydir = 1;
+    bool line = true;
+    if (S.main_diag) {                    // (0,0) - (W,H): the far end is pulled back onto the last row, then (narrow cells) onto the last column
+        if (W >= H) { ax = W - W / H; ay = H - 1; }
+        else { ax = W - 1; ay = H - 1 - (H - 1) / W; }
+    } else if (H == 1) {
+        line = false;                     // (W,0) - (0,1): both ends stay right of the mask after the first clip: rejected
+    } else {                              // (W,0) - (0,H): left end pulled up onto the last row, right end pulled in onto the last column
+        lx = W / H; ly = H - 1;
+        ax = W - 1 - lx; ay = ly - (H - 1) / (W - lx);
+        ydir = -1;
+    }
+    unsigned count = 0;
+    for (int y = (int)threadIdx.x; y < H; y += (int)blockDim.x) {
+        // scan-conversion span
+        const long long xd = top + (long long)y * slope;
+        long long f0 = ((xd < leg ? xd : leg) + 0x8000) >> 16, f1 = ((xd < leg ? leg : xd) + 0x8000) >> 16;
+        if (f1 < 0 || f0 >= W) { f0 = 1; f1 = 0; }
+        else { if (f0 < 0) f0 = 0; if (f1 > W - 1) f1 = W - 1; }
+        // diagonal-line span
+        long long d0 = 1, d1 = 0;
+        const int k = (y - ly) * ydir;
+        if (line && k >= 0 && k <= ay) {
+            if (ay > ax) d0 = d1 = lx + floor_div(2ll * ax * k + ay - 1, 2ll * ay);
+            else if (ay == 0) { d0 = lx; d1 = lx + ax; }
+            else {
+                long long i0 = -floor_div(-(2ll * ax * k - ax + 1), 2ll * ay), i1 = floor_div(2ll * ax * k + ax, 2ll * ay);
+                if (i0 < 0) i0 = 0;
+                if (i1 > ax) i1 = ax;
+                d0 = lx + i0; d1 = lx + i1;
+            }
+        }
+        const bool full = S.row0 && y == 0;
+        for (int x = 0; x < W; ++x) {
+            const bool in = full || (S.col0 && x == 0) || (x >= f0 && x <= f1) || (x >= d0 && x <= d1);
+            m[(size_t)y * W + x] = in ? 255 : 0;
+            count += in;
+        }
+    }
+    for (int off = 32; off; off >>= 1) count += __shfl_xor(count, off);
+    if ((threadIdx.x & 63) == 0 && count) atomicAdd(&nz[t], count);
 }
 
 // moves between the per-thread pinned staging block and the per-thread device scratch (see PinnedScratch / DeviceScratch in common.hpp)
@@ -180,15 +160,9 @@ int view_saliency(const ms_image &im, int M, int N, std::vector<float> &sal, hip
 {
     const float width = (float)im.cols, height = (float)im.rows;
     const float cw = width / (M - 1), ch = height / (N - 1);
-    std::vector<uint8_t> masks, one;
-    int mw = 0, mh = 0, nz[8];
-    for (int t = 0; t < 8; ++t) {
-        triangle_mask(t, cw, ch, one, mw, mh);
-        nz[t] = 0;
-        for (uint8_t b : one) nz[t] += b != 0;
-        masks.insert(masks.end(), one.begin(), one.end());
-    }
+    const int mw = (int)cw, mh = (int)ch;                                               // Mat mask(cell_height, cell_width): float -> int truncation
     MS_CHECK(mw >= 1 && mh >= 1, "ms_create_mesh: a %dx%d mesh on a %dx%d view has empty cells", M, N, im.cols, im.rows);
+    const size_t mask_bytes = (size_t)8 * mw * mh;
     std::vector<TriJob> jobs;
     std::vector<int> slot((size_t)N * M * 8, -1);
     for (int i = 0; i < N; ++i)
@@ -207,20 +181,23 @@ int view_saliency(const ms_image &im, int M, int N, std::vector<float> &sal, hip
                 slot[((size_t)i * M + j) * 8 + t] = (int)jobs.size();
                 jobs.push_back(jb);
             }
-    // one pinned block: masks | jobs (up) and the sums (down); one device block of the same layout
-    const size_t off_jobs = (masks.size() + 15) & ~(size_t)15, off_sums = off_jobs + ((jobs.size() * sizeof(TriJob) + 15) & ~(size_t)15);
-    const size_t total = off_sums + ((jobs.size() * 6 * sizeof(unsigned long long) + 15) & ~(size_t)15);
-    uint8_t *host = (uint8_t *)pinned_scratch().get(total);
+    // device block: masks (built on the device) | jobs (up) | sums, mask pixel counts (down)
+    const size_t off_jobs = (mask_bytes + 15) & ~(size_t)15, off_sums = off_jobs + ((jobs.size() * sizeof(TriJob) + 15) & ~(size_t)15);
+    const size_t off_nz = off_sums + ((jobs.size() * 6 * sizeof(unsigned long long) + 15) & ~(size_t)15), total = off_nz + 64;
+    uint8_t *host = (uint8_t *)pinned_scratch().get(total);                             // (same offsets as the device block; the mask area stays unused)
     if (!host) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of pinned staging memory", total);
-    memcpy(host, masks.data(), masks.size());
     memcpy(host + off_jobs, jobs.data(), jobs.size() * sizeof(TriJob));
     uint8_t *dev = (uint8_t *)device_scratch().get(total);
     if (!dev) return fail(MS_ERR_NOMEM, "ms_create_mesh: cannot allocate %zu bytes of device scratch", total);
-    if (int e = copy_async(host, dev, off_sums, st)) return e;
+    if (int e = copy_async(host + off_jobs, dev + off_jobs, off_sums - off_jobs, st)) return e;
+    MS_HIP(hipMemsetAsync(dev + off_nz, 0, 64, st));
+    k_tri_masks<<<8, 256, 0, st>>>(triangle_shapes(), mw, mh, dev, (unsigned *)(dev + off_nz));
+    MS_LAUNCH_CHECK();
     k_tri_stats<<<(unsigned)jobs.size(), 64, 0, st>>>((const uint8_t *)im.data, im.step, dev, mw, mh, (const TriJob *)(dev + off_jobs), (unsigned long long *)(dev + off_sums));
     MS_LAUNCH_CHECK();
-    if (int e = copy_async(dev + off_sums, host + off_sums, (total - off_sums + 15) & ~(size_t)15, st)) return e;
+    if (int e = copy_async(dev + off_sums, host + off_sums, total - off_sums, st)) return e;
     MS_HIP(hipStreamSynchronize(st));
+    const unsigned *nz = (const unsigned *)(host + off_nz);
     const unsigned long long *sums = (const unsigned long long *)(host + off_sums);
     sal.assign((size_t)N * M * 8, NAN);
     for (size_t k = 0; k < slot.size(); ++k) {
@@ -662,6 +639,25 @@ int ms_mesh_saliency(const ms_image *view, int mesh_cols, int mesh_rows, float *
     std::vector<float> sal;
     if (int e = view_saliency(*view, mesh_cols, mesh_rows, sal, as_stream(stream))) return e;
     memcpy(sal_host, sal.data(), sal.size() * sizeof(float));
+    return MS_OK;
+}
+
+int ms_mesh_triangle_masks(int cell_w, int cell_h, uint8_t *masks_host, unsigned *counts_host, ms_stream stream)
+{
+    if (int e = require_device()) return e;
+    MS_CHECK(cell_w >= 1 && cell_h >= 1 && cell_w <= 8192 && cell_h <= 8192 && masks_host, "ms_mesh_triangle_masks: cell %dx%d out of range", cell_w, cell_h);
+    const size_t mask_bytes = (size_t)8 * cell_w * cell_h, off_nz = (mask_bytes + 15) & ~(size_t)15;
+    uint8_t *dev = (uint8_t *)device_scratch().get(off_nz + 64);
+    if (!dev) return fail(MS_ERR_NOMEM, "ms_mesh_triangle_masks: cannot allocate %zu bytes of device scratch", off_nz + 64);
+    hipStream_t st = as_stream(stream);
+    MS_HIP(hipMemsetAsync(dev + off_nz, 0, 64, st));
+    k_tri_masks<<<8, 256, 0, st>>>(triangle_shapes(), cell_w, cell_h, dev, (unsigned *)(dev + off_nz));
+    MS_LAUNCH_CHECK();
+    MS_HIP(hipMemcpyAsync(masks_host, dev, mask_bytes, hipMemcpyDeviceToHost, st));
+    unsigned nz[8];
+    MS_HIP(hipMemcpyAsync(nz, dev + off_nz, sizeof(nz), hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
+    if (counts_host) memcpy(counts_host, nz, sizeof(nz));
     return MS_OK;
 }
 

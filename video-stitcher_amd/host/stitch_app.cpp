@@ -206,7 +206,7 @@ int main(int argc, char **argv)
                 synth_frame(host.data(), o.w, o.h, i);
                 HIPCHECK(hipMemcpy2D(first[i].data, first[i].step, host.data(), (size_t)o.w * 3, (size_t)o.w * 3, o.h, hipMemcpyHostToDevice));
             }
-            comp_owner = msshim::stitch_calib(first, MS_PROJ_CYLINDRICAL, o.cpw, cal, o.hfov, o.work_mp, o.seam_mp, o.compose_mp, 5.f, -1, -1, 1);
+            comp_owner = msshim::stitch_calib(first, MS_PROJ_CYLINDRICAL, o.cpw, cal, o.hfov, o.work_mp, o.seam_mp, o.compose_mp, 5.f, -1, -1, 1, -1, nullptr, o.cpw ? o.update_mask : 0);
             for (auto &m : first) HIPCHECK(hipFree(m.data));
             const ms_pano_geom g = comp_owner->panoGeom();
             o.out_w = (2 * std::max(std::abs(cal.pano_roi.x), std::abs(cal.pano_roi.x + cal.pano_roi.width)) + 1) & ~1;

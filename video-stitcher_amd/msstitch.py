@@ -91,7 +91,7 @@ EXPORTS = [
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
     "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
-    "ms_selftest_divide", "ms_calib_copy", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
+    "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
 ]
 
@@ -178,6 +178,18 @@ def device_count():
 def calib_copy(src, dst):
     n = src.numel() * src.element_size()
     _chk(load().ms_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), _stream()))
+
+
+def calib_read(src):
+    n = src.numel() * src.element_size()
+    _chk(load().ms_calib_read(C.c_void_p(src.data_ptr()), C.c_size_t(n), _stream()))
+
+
+def selftest_divide_range(d_lo, d_hi):
+    """(mismatches, quotients checked) of DivBy against IEEE division for every float denominator in [d_lo, d_hi] x all int16 numerators."""
+    bad, n = C.c_ulonglong(1), C.c_ulonglong(0)
+    _chk(load().ms_selftest_divide_range(C.c_float(d_lo), C.c_float(d_hi), C.byref(bad), C.byref(n), _stream()))
+    return bad.value, n.value
 
 
 def selftest_cvt_u8():
@@ -404,7 +416,7 @@ class OrbParams(C.Structure):
                 ("patch_size", C.c_int), ("fast_threshold", C.c_int)]
 
 
-def orb_detect_and_compute(gray, mask=None, nfeatures=2500, scale_factor=1.2, nlevels=8, fast_threshold=20):
+def orb_detect_and_compute(gray, mask=None, nfeatures=2500, scale_factor=1.2, nlevels=8, fast_threshold=20, edge_threshold=None):
     """cuda::ORB::create(nfeatures, scaleFactor, nlevels)->detectAndCompute (featurefinder.cpp:15-40): gray / mask torch uint8 (H, W) on the device.
     Returns (keypoints (n, 6) float32 numpy: x, y, response, angle, octave, size; descriptors (n, 32) uint8 torch tensor on the device)."""
     import numpy as np
@@ -412,6 +424,8 @@ def orb_detect_and_compute(gray, mask=None, nfeatures=2500, scale_factor=1.2, nl
     prm = OrbParams()
     _chk(load().ms_orb_default_params(C.byref(prm)))
     prm.nfeatures, prm.scale_factor, prm.nlevels, prm.fast_threshold = nfeatures, scale_factor, nlevels, fast_threshold
+    if edge_threshold is not None:
+        prm.edge_threshold = edge_threshold
     cap = nfeatures
     kp = np.zeros((cap, 6), np.float32)
     desc = torch.zeros((cap, 32), dtype=torch.uint8, device=gray.device)
@@ -469,6 +483,15 @@ def mesh_saliency(view, mesh_cols, mesh_rows):
     out = np.empty((mesh_rows, mesh_cols, 8), np.float32)
     _chk(load().ms_mesh_saliency(C.byref(img(view)), mesh_cols, mesh_rows, out.ctypes.data_as(C.POINTER(C.c_float)), _stream()))
     return out
+
+
+def mesh_triangle_masks(cell_w, cell_h):
+    """The 8 fillConvexPoly triangle masks of a cell_w x cell_h mesh cell, (8, cell_h, cell_w) uint8, and their set-pixel counts."""
+    import numpy as np
+    out = np.empty((8, cell_h, cell_w), np.uint8)
+    cnt = (C.c_uint * 8)()
+    _chk(load().ms_mesh_triangle_masks(int(cell_w), int(cell_h), out.ctypes.data_as(C.POINTER(C.c_ubyte)), cnt, _stream()))
+    return out, list(cnt)
 
 
 def _match_array(lists):

@@ -173,11 +173,13 @@ struct Calibration {
 // init_gpu for every view (:240).  full_imgs: the first frame of every camera, device 8UC3 at full size.  With compose_scale more than 10 %
 // from 1 the returned compositor expects frames already resized to rig.compose_width x compose_height (msshim::cuda::resize, timed.cpp:75-85).
 // projection: the app ships MS_PROJ_CYLINDRICAL (calibration.cpp:100,156); out_w / out_h: canvas for the 8U output, 0 = none.
+// update_mask_margin > 0 (CPW only): update_mask() on the returned compositor only enqueues, so the recalibration thread may call it after every
+// mesh swap while frames flow; with 0 it is the synchronous rebuild, which makes a concurrent stitch_one wait (never race) for its ~50 ms.
 template <class Mat>
 std::unique_ptr<Compositor> stitch_calib(const std::vector<Mat> &full_imgs, int projection, bool enable_local, Calibration &cal,
                                          double hfov_deg = 90.0, double work_megapix = 0.6, double seam_megapix = 0.01, double compose_megapix = 1.4,
                                          float blend_strength = 5.f, int out_w = 0, int out_h = 0, int frames_in_flight = 1,
-                                         int num_bands_override = -1, ms_stream s = nullptr)
+                                         int num_bands_override = -1, ms_stream s = nullptr, int update_mask_margin = 0)
 {
     const int n = (int)full_imgs.size();
     if (n < 1) throw Error(MS_ERR_INVALID, "stitch_calib: no images");
@@ -195,7 +197,7 @@ std::unique_ptr<Compositor> stitch_calib(const std::vector<Mat> &full_imgs, int 
         out_h = projection == MS_PROJ_SPHERICAL ? ((r.y + r.height + 1) & ~1) : ((2 * std::max(std::abs(r.y), std::abs(r.y + r.height)) + 1) & ~1);
     }
     std::unique_ptr<Compositor> comp(new Compositor(n, rig.compose_width, rig.compose_height, projection, rig.compose_warp_scale, cal.num_bands,
-                                                    enable_local, out_w, out_h, frames_in_flight));
+                                                    enable_local, out_w, out_h, frames_in_flight, enable_local ? update_mask_margin : 0));
     for (int i = 0; i < n; ++i) comp->setCamera(i, rig.K_compose[i], rig.R[i]);
     comp->buildMaps(s);                                                                                          // :196, :221
     ms_seam_params sp{rig.seam_scale, rig.seam_warp_scale, enable_local ? 1 : 0, 1};
