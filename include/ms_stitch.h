@@ -43,8 +43,10 @@ typedef enum ms_status {
     MS_ERR_HIP = -3,          /* HIP runtime error (cudaSafeCall in the reference)  */
     MS_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                           */
     MS_ERR_STATE = -5,        /* call order violated (e.g. stitch before calibrate) */
-    MS_ERR_NOMEM = -6
+    MS_ERR_NOMEM = -6,
+    MS_ERR_COMM = -7          /* multi-GPU transport (RCCL / host mailbox) failure or timeout: ms_dist.h */
 } ms_status;
+#define MS_ERR_COMM MS_ERR_COMM
 
 /* OpenCV type codes CV_MAKETYPE(depth, cn) = depth + ((cn-1) << 3)  (OCV/core/include/opencv2/core/hal/interface.h) */
 enum { MS_8UC1 = 0, MS_8UC3 = 16, MS_16SC1 = 3, MS_16SC3 = 19, MS_32FC1 = 5 };

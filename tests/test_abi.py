@@ -1,4 +1,4 @@
-"""The C-ABI library loads, exports exactly what include/ms_stitch.h declares, and refuses to compute
+"""The C-ABI library loads, exports exactly what include/*.h declare, and refuses to compute
 without a device (no CPU fallback)."""
 import ctypes as C
 import os
@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ms_stitch.h")).read()
+def declared_symbols(header="ms_stitch.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"MS_API\s+[\w\s\*]+?\b(ms_\w+)\s*\(", text)))
 
@@ -22,6 +22,13 @@ def test_header_symbols_are_exported(ms):
     for n in names:
         assert hasattr(lib, n), "libmsstitch.so does not export %s" % n
     assert sorted(ms.EXPORTS) == names, "msstitch.EXPORTS out of sync with include/ms_stitch.h"
+    # the multi-GPU layer (include/ms_dist.h) lives in the same library
+    import msdist
+    dist_names = declared_symbols("ms_dist.h")
+    assert len(dist_names) >= 12 and sorted(os.listdir(os.path.join(ROOT, "include"))) == ["ms_dist.h", "ms_stitch.h"]
+    for n in dist_names:
+        assert hasattr(lib, n), "libmsstitch.so does not export %s" % n
+    assert sorted(msdist.EXPORTS) == dist_names, "msdist.EXPORTS out of sync with include/ms_dist.h"
 
 
 def test_no_oracle_in_product():
@@ -29,7 +36,7 @@ def test_no_oracle_in_product():
     import subprocess
     out = subprocess.run(["nm", "-D", os.path.join(ROOT, "video-stitcher_amd", "libmsstitch.so")], capture_output=True, text=True).stdout
     assert "orc_" not in out
-    for f in ("msstitch.py", "synth.py", "dist_frames.py"):
+    for f in ("msstitch.py", "msdist.py", "synth.py", "dist_frames.py"):
         src = open(os.path.join(ROOT, "video-stitcher_amd", f)).read()
         assert "oracle" not in src.replace("no oracle", "").lower() or f == "synth.py" and "import oracle" not in src
     for f in os.listdir(os.path.join(ROOT, "video-stitcher_amd", "csrc")):

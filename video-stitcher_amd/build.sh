@@ -5,16 +5,16 @@ cd "$(dirname "$0")/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function ${MS_EXTRA_FLAGS:-}"
 mkdir -p ../build
-newest_hdr=$(ls -t *.hpp *.inc ../../include/ms_stitch.h | head -1)
+newest_hdr=$(ls -t *.hpp *.inc ../../include/ms_stitch.h ../../include/ms_dist.h | head -1)
 pids=()
-for f in prims.hip compositor.hip mesh_solver.hip matcher.hip features.hip calib.hip api.cpp geometry.cpp; do
+for f in prims.hip compositor.hip mesh_solver.hip matcher.hip features.hip calib.hip api.cpp geometry.cpp dist.cpp; do
   o=../build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
     $HIPCC $FLAGS -x hip -c "$f" -o "$o" & pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || { echo "compile failed" >&2; exit 1; }; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmsstitch.so ../build/prims.o ../build/compositor.o ../build/mesh_solver.o ../build/matcher.o ../build/features.o ../build/calib.o ../build/api.o ../build/geometry.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmsstitch.so ../build/prims.o ../build/compositor.o ../build/mesh_solver.o ../build/matcher.o ../build/features.o ../build/calib.o ../build/api.o ../build/geometry.o ../build/dist.o -ldl -lrt
 # C++ host pipeline over the C-ABI (thread / queue graph of the reference's timed.cpp); host code only, links the library above
 if [ ! -f ../stitch_app ] || [ ../host/stitch_app.cpp -nt ../stitch_app ] || [ ../shim/ms_shim.hpp -nt ../stitch_app ] || [ ../../include/ms_stitch.h -nt ../stitch_app ]; then
   $HIPCC -O2 -std=c++17 -Wall -Wno-unused-result -pthread ../host/stitch_app.cpp -I../../include -L.. -lmsstitch -Wl,-rpath,'$ORIGIN' -o ../stitch_app

@@ -2452,6 +2452,9 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             if (bad > 0) return fail(MS_ERR_INVALID, "ms_init_blender: shared-reciprocal division differs from IEEE division for %d (numerator, denominator) pairs", bad);
         }
     }
+    // the tables are complete when this returns, whichever stream the next ms_stitch runs on (calibration-time call: a host wait costs nothing here,
+    // and a stitch enqueued on another stream right after a rebuild on the recalibration thread must not read half-built tables)
+    MS_HIP(hipStreamSynchronize(st));
     c->blender_ready = true;
     return MS_OK;
 }
