@@ -1,0 +1,134 @@
+"""Multi-GPU product path on the GPU box: video-stitcher_amd/stitch_dist (one thread per rank over ms_dist) must deliver, on the sink, the SAME
+I420 frames whatever the number of ranks, the batch size, the column-shard grouping and the transport -- compared through `checksum_all` with
+the single-rank run.  With one GPU on the box the ranks share it over the host (shared-memory) transport; where two or more GPUs are visible
+the same tests also run over RCCL.  The single-rank runs already go through RCCL (a communicator of one), so the library is loaded, the
+communicator initialised and its all-gather executed on every box."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import make_rig, to_dev
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+APP = os.path.join(ROOT, "video-stitcher_amd", "stitch_dist")
+
+
+def run(*args, rig="mini6", timeout=600):
+    cfg = synth.CONFIGS[rig]
+    base = ["--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]), "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"]]
+    out = subprocess.run([APP] + [str(a) for a in base + list(args)], capture_output=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def multi(n):
+    """arguments that put n ranks on this box: their own GPUs over RCCL if there are enough, else all on device 0 over the host transport"""
+    return ["--gpus", n] if torch.cuda.device_count() >= n else ["--gpus", n, "--share-gpu"]
+
+
+def test_single_rank_runs_over_rccl_and_matches_the_python_binding(ms, cuda):
+    one = run("--gpus", 1, "--frames", 8, "--batch", 4)
+    assert one["dist"]["transport"] == "rccl" and one["dist"]["nranks"] == 1 and one["dist"]["comm_nranks"] == 1 and one["dist"]["rccl_version"] > 0
+    assert one["frames"] == 8 and len(one["dist"]["pci_bus_ids"][0]) > 4
+    # frame 0 of the app = synth pattern variant 0: the same frame through the binding's ms_stitch_i420
+    cfg = synth.CONFIGS["mini6"]
+    comp, _, _ = make_rig(ms, "mini6")
+    frames = [to_dev(synth.frame(cfg["w"], cfg["h"], i, 0, noise=False)) for i in range(cfg["n"])]
+    slab = comp.new_i420(1)
+    comp.stitch_i420([frames], slab)
+    torch.cuda.synchronize()
+    h = 1469598103934665603
+    for b in slab[0].cpu().numpy().tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert "%016x" % h == one["first_frame_checksum"]
+    comp.close()
+
+
+@pytest.mark.parametrize("ranks,batch", [(2, 2), (2, 4), (4, 1)])
+def test_frame_parallel_ranks_deliver_the_single_gpu_frames(cuda, ranks, batch):
+    one = run("--gpus", 1, "--frames", 16, "--batch", 4)
+    many = run(*multi(ranks), "--frames", 16, "--batch", batch)
+    assert many["dist"]["nranks"] == ranks and many["frames"] == 16
+    assert many["checksum_all"] == one["checksum_all"]
+    if torch.cuda.device_count() >= ranks:
+        assert many["dist"]["transport"] == "rccl" and many["dist"]["comm_nranks"] == ranks and len(set(many["dist"]["pci_bus_ids"])) == ranks
+    else:
+        assert many["dist"]["transport"] == "host" and many["share_gpu"] is True
+
+
+def test_recalibration_broadcast_swaps_meshes_at_the_agreed_frame(cuda):
+    """cfg3 shape: CPW on, new meshes every 8 frames from rank 0's recalibration thread, broadcast one batch ahead with the swap frame."""
+    one = run("--gpus", 1, "--frames", 32, "--batch", 4, "--recalib-every", 8, "--mesh", "9x11")
+    assert one["recalibrations_applied"] == 3 and one["cpw"] is True
+    static = run("--gpus", 1, "--frames", 32, "--batch", 4, "--cpw", "--mesh", "9x11")
+    assert static["checksum_all"] != one["checksum_all"], "the recalibrations must change the frames"
+    assert static["first_frame_checksum"] == one["first_frame_checksum"]
+    for ranks, batch in ((2, 4), (2, 2), (4, 2)):
+        many = run(*multi(ranks), "--frames", 32, "--batch", batch, "--recalib-every", 8, "--mesh", "9x11")
+        assert many["recalibrations_applied"] == 3
+        assert many["checksum_all"] == one["checksum_all"], (ranks, batch)
+
+
+def test_column_shard_groups_times_frame_parallel_groups(cuda):
+    """BASELINE configs[4] shape: S GPUs per frame x several frames in flight.  2 shards x 2 groups (and 2 x 1, 4 x 1) against the unsharded run,
+    with and without CPW recalibration; a shard reads only the views that reach its window."""
+    one = run("--gpus", 1, "--frames", 16, "--batch", 2)
+    for ranks, shards in ((2, 2), (4, 2), (4, 4)):
+        many = run(*multi(ranks), "--col-shards", shards, "--frames", 16, "--batch", 2)
+        assert many["groups"] == ranks // shards and many["checksum_all"] == one["checksum_all"], (ranks, shards)
+        assert min(many["views_read_per_rank"]) < one["views"]
+    one = run("--gpus", 1, "--frames", 16, "--batch", 2, "--recalib-every", 8)
+    many = run(*multi(4), "--col-shards", 2, "--frames", 16, "--batch", 2, "--recalib-every", 8)
+    assert many["recalibrations_applied"] == 1 and many["checksum_all"] == one["checksum_all"]
+
+
+def test_full_size_two_ranks(cuda):
+    """config 2 at full size through two ranks (frame-parallel) and through a 2-shard group"""
+    one = run("--gpus", 1, "--frames", 8, "--batch", 2, rig="cfg2")
+    assert run(*multi(2), "--frames", 8, "--batch", 2, rig="cfg2")["checksum_all"] == one["checksum_all"]
+    assert run(*multi(2), "--col-shards", 2, "--frames", 8, "--batch", 2, rig="cfg2")["checksum_all"] == one["checksum_all"]
+
+
+def test_device_buffers_through_the_binding(ms, cuda):
+    """msdist.Dist with device tensors: a one-rank communicator on RCCL (self send / recv in a group, broadcast, barrier) and, from two threads
+    sharing the GPU, the host transport moving device memory."""
+    import threading
+    import msdist
+    d = msdist.Dist(0, 1, msdist.unique_id(1, msdist.RCCL), device=0)
+    info = d.info()
+    assert info["transport"] == "rccl" and info["comm_nranks"] == 1
+    a = torch.arange(1 << 20, dtype=torch.int32, device=cuda)
+    b = torch.zeros_like(a)
+    d.group_begin(); d.send(a, 0); d.recv(b, 0); d.group_end()
+    d.broadcast(a, 0); d.barrier()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    d.close()
+    idb = msdist.unique_id(2, msdist.HOST)
+    res, errs = {}, []
+
+    def rank(r):
+        try:
+            dd = msdist.Dist(r, 2, idb, device=0)
+            mine = torch.full((3 * (1 << 20) + 7,), 40 + r, dtype=torch.uint8, device=cuda)
+            got = torch.zeros_like(mine)
+            dd.group_begin(); dd.send(mine, 1 - r); dd.recv(got, 1 - r); dd.group_end()
+            slab = torch.full((1000,), 7 + r, dtype=torch.uint8, device=cuda)
+            recv = [None, torch.zeros(1000, dtype=torch.uint8, device=cuda)] if r == 0 else None
+            dd.gather_slabs(slab, recv, sink=0)
+            torch.cuda.synchronize()
+            res[r] = (int(got[0]), int(got[-1]), None if r else int(recv[1][0]))
+            dd.barrier(); dd.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]; [t.join(timeout=180) for t in ts]
+    assert not errs, errs
+    assert res == {0: (41, 41, 8), 1: (40, 40, None)}

@@ -19,4 +19,8 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmsstitch.so ../build/prims.o
 if [ ! -f ../stitch_app ] || [ ../host/stitch_app.cpp -nt ../stitch_app ] || [ ../shim/ms_shim.hpp -nt ../stitch_app ] || [ ../../include/ms_stitch.h -nt ../stitch_app ]; then
   $HIPCC -O2 -std=c++17 -Wall -Wno-unused-result -pthread ../host/stitch_app.cpp -I../../include -L.. -lmsstitch -Wl,-rpath,'$ORIGIN' -o ../stitch_app
 fi
+# the multi-GPU host pipeline (one thread per GPU over ms_dist: RCCL / host transport)
+if [ ! -f ../stitch_dist ] || [ ../host/stitch_dist.cpp -nt ../stitch_dist ] || [ ../../include/ms_dist.h -nt ../stitch_dist ] || [ ../../include/ms_stitch.h -nt ../stitch_dist ]; then
+  $HIPCC -O2 -std=c++17 -Wall -Wno-unused-result -pthread ../host/stitch_dist.cpp -I../../include -L.. -lmsstitch -Wl,-rpath,'$ORIGIN' -o ../stitch_dist
+fi
 echo "built $(cd .. && pwd)/libmsstitch.so"
