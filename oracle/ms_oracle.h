@@ -248,6 +248,10 @@ int orc_helper_sat_s16i(int v);
 int orc_helper_cv_round_f(float v);
 int orc_helper_f2i_rd(float v);
 
+
+/* number of static_cast<short>(float) evaluations whose argument left the int16 range since the last reset (see trunc_s16f in ms_oracle_prims.c) */
+long long orc_trunc_s16_range_violations(void);
+void orc_trunc_s16_range_reset(void);
 #ifdef __cplusplus
 }
 #endif

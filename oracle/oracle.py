@@ -61,7 +61,14 @@ def lib():
         _lib.orc_blender_create.restype = C.c_void_p
         _lib.orc_blender_weight_level.restype = C.c_void_p
         _lib.orc_blender_src_level.restype = C.c_void_p
+        _lib.orc_trunc_s16_range_violations.restype = C.c_longlong
     return _lib
+
+
+def trunc_s16_range_violations():
+    """How often static_cast<short>(float) saw a value outside the int16 range (where nvcc's two possible conversions would differ) since the
+    library was loaded: must stay 0 on every tested configuration (ms_oracle_prims.c: trunc_s16f)."""
+    return int(lib().orc_trunc_s16_range_violations())
 
 
 def _p(a):
