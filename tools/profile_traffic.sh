@@ -15,5 +15,5 @@ python tools/summarize_traffic.py $OUT $TAG $CFG $F
 python bench.py --config $CFG > $OUT/bench_plain.json 2> $OUT/bench_plain.err && cp $OUT/bench_plain.json profiles/${TAG}_bench.json || true
 # gpurun only merges gpurun_out/ back: park the summaries there (copy them into profiles/ and commit)
 python tools/report.py $TAG > /dev/null 2>&1 || true
-mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/traffic_latest.json gpurun_out/profiles_out/
+mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/traffic_*.json gpurun_out/profiles_out/
 rm -rf $OUT/trace $OUT/fetch $OUT/write      # the rocprofv3 databases are tens of MB each: only the summaries travel back (gpurun merges <= 64 MiB)

@@ -13,6 +13,8 @@ runs = {"cfg2_F1": ["--frames", "1", "--streams", "1", "--steps", "30", "--warmu
         "cfg3": ["--config", "cfg3"],
         "cfg3_no_recalibration": ["--config", "cfg3", "--recalib-every", "0"],
         "cfg5": ["--config", "cfg5"],
+        "shipped": ["--config", "shipped"],
+        "shipped_no_recalibration": ["--config", "shipped", "--recalib-every", "0"],
         "cfg2_egress_i420_1gpu": ["--emulate-gather"]}
 res = {}
 for k, a in runs.items():

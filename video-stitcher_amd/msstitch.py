@@ -378,6 +378,20 @@ def bgr_to_gray(src):
     return dst
 
 
+def resize_linear_batch_prepared(srcs, dsts, fx=0.0, fy=0.0):
+    """cuda::resize of every srcs[i] into dsts[i] (8UC3, one geometry) in one launch; returns a callable(stream_handle=None) with the descriptors
+    marshalled once (the per-frame compose-scale resize of stitch_online, timed.cpp:75-85, inside a timed loop)."""
+    n = len(srcs)
+    a = (Image * n)(*[img(t) for t in srcs]); b = (Image * n)(*[img(t) for t in dsts])
+    fn = load().ms_resize_linear_batch
+    cfx, cfy = C.c_double(fx), C.c_double(fy)
+
+    def run(stream=None):
+        _chk(fn(a, b, n, cfx, cfy, stream if stream is not None else _stream()))
+    run.keep = (srcs, dsts)
+    return run
+
+
 def bgr_to_i420_batch_prepared(srcs, dsts):
     """One launch converting every srcs[i] (8UC3, same geometry) into dsts[i] (contiguous I420); returns a callable(stream_handle=None)
     with the descriptors marshalled once."""
