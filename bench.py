@@ -97,39 +97,32 @@ def oracle_check(cfg, gains, comp, frame_dev, cpw):
 
 
 def _physical_cores_of_one_socket():
-    """[cpu ids]: one logical CPU per physical core of the socket this process starts on (sysfs topology); all CPUs if the topology is unreadable."""
+    """Number of physical cores of the socket CPU 0 sits on (sysfs topology of every online CPU -- NOT this thread's affinity mask: with OMP_PROC_BIND the
+    OpenMP runtime has already bound the initial thread to its first place, one core); all CPUs / 2 if the topology is unreadable."""
+    ncpu = os.cpu_count() or 1
     try:
-        allowed = sorted(os.sched_getaffinity(0))
-        pkg0 = int(open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % allowed[0]).read())
-        seen, out = set(), []
-        for c in allowed:
+        pkg0 = int(open("/sys/devices/system/cpu/cpu0/topology/physical_package_id").read())
+        cores = set()
+        for c in range(ncpu):
             base = "/sys/devices/system/cpu/cpu%d/topology/" % c
-            if int(open(base + "physical_package_id").read()) != pkg0:
-                continue
-            core = int(open(base + "core_id").read())
-            if core not in seen:
-                seen.add(core); out.append(c)
-        return out or allowed
+            if os.path.exists(base) and int(open(base + "physical_package_id").read()) == pkg0:
+                cores.add(int(open(base + "core_id").read()))
+        return max(1, len(cores))
     except (OSError, ValueError):
-        return sorted(os.sched_getaffinity(0))
+        return max(1, ncpu // 2)
 
 
 def cpu_baseline(cfg, gains, comp, frames=None, resize=None, budget_s=12.0):
     """Time the reference's CPU pipeline as the oracle restates it (oracle/ms_oracle_cpu.c + ms_oracle_prims.c: "port"): per view [cv::resize by
     compose_scale,] cv::remap in its fixed-point CPU arithmetic -> convertTo(gain) -> convertTo(16S) -> CPU MultiBandBlender::feed (Laplacian pyramid
     with cv::pyrDown / pyrUp's (x + 128) >> 8 / (x + 32) >> 6 rounding, weight pyramid rebuilt on every call: blenders.cpp:585-696), then blend
-    (:832-851).  Threads are PINNED: the process is restricted to one logical CPU per physical core of ONE socket (no SMT siblings, no cross-socket
-    traffic) with OMP_PROC_BIND=close / OMP_PLACES=cores set by main() before the OpenMP runtime starts; the thread count is the fastest median of
-    5 runs among 1 / 8 / 16 / 32 / 64 (<= the socket's cores), and the spread of those 5 runs is reported."""
+    (:832-851).  Threads are PINNED: OMP_PLACES=cores / OMP_PROC_BIND=close (set at the top of this file, before the OpenMP runtime starts) put thread i on
+    its own physical core next to the initial thread's, so up to the core count of one socket no two threads share a core and none crosses the socket;
+    the thread count is the fastest median of 5 runs among 1 / 8 / 16 / 32 / 64 (<= the socket's cores), and the spread of those 5 runs is reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     import synth
-    cores_ids = _physical_cores_of_one_socket()
-    try:
-        os.sched_setaffinity(0, cores_ids)
-    except OSError:
-        pass
-    ncpu, nphys = os.cpu_count() or 1, len(cores_ids)
+    ncpu, nphys = os.cpu_count() or 1, _physical_cores_of_one_socket()
     rois = [comp.view_geom(i).roi.tuple() for i in range(cfg["n"])]
     b = O.Blender([r[:2] for r in rois], [r[2:] for r in rois], comp.pano_geom().num_bands, cpu_flavour=True)
     maps = []
@@ -174,10 +167,6 @@ def cpu_baseline(cfg, gains, comp, frames=None, resize=None, budget_s=12.0):
             break
     fps_all = n / el
     b.close()
-    try:
-        os.sched_setaffinity(0, range(ncpu))
-    except OSError:
-        pass
     model = "?"
     try:
         for line in open("/proc/cpuinfo"):
@@ -187,7 +176,7 @@ def cpu_baseline(cfg, gains, comp, frames=None, resize=None, budget_s=12.0):
         pass
     pg = comp.pano_geom()
     return {"value": round(fps_all, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": model, "host_cpus": ncpu,
-            "physical_cores_of_the_socket_used": nphys, "pinning": "sched_setaffinity to one logical CPU per physical core of one socket; OMP_PROC_BIND=%s OMP_PLACES=%s"
+            "physical_cores_of_one_socket": nphys, "pinning": "OMP_PROC_BIND=%s OMP_PLACES=%s: one thread per physical core, consecutive cores of the initial thread's socket"
             % (os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
             "fps_by_threads_median_of_5": tried, "spread_fps_of_the_5_runs_at_best": [round(1.0 / spread[1], 2), round(1.0 / spread[0], 2)],
             "flavour": "the reference's CPU path: %scv::remap fixed-point + CPU MultiBandBlender feed/blend ((x+128)>>8 pyramids), restated in oracle/" % ("cv::resize + " if resize else ""),

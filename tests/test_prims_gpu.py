@@ -346,6 +346,25 @@ def test_resize_linear_batch_equals_single_calls(ms, cuda, oracle):
         ms.resize_linear_batch([to_dev(srcs[0]), to_dev(srcs[1][:100])], fx=s, fy=s)
 
 
+@pytest.mark.parametrize("shape,scale", [((1080, 1920), math.sqrt(1.4e6 / (1920 * 1080))), ((97, 131), 0.8217), ((64, 75), 0.99), ((50, 61), 0.63), ((33, 47), 0.7),
+                                         ((41, 19), 0.9), ((30, 40), 0.45), ((20, 24), 1.0 / 1.6)])
+def test_resize_linear_batch_four_pixel_kernel_edges(ms, cuda, oracle, shape, scale):
+    """The per-frame batch kernel handles 4 output pixels per lane out of one 24-byte source window per row (k_resize_linear3_x4): ragged right edges,
+    windows that would leave the source row, row pitches that are not multiples of 4, the last source row, scales at both ends of its range and beyond it
+    (where the launcher falls back to one pixel per lane) -- all bit-identical to the oracle's restatement of cuda::resize (resize.cu:71-106)."""
+    rng = rng_for("resize_x4", shape)
+    srcs = [rng.integers(0, 256, size=shape + (3,), dtype=np.uint8) for _ in range(3)]
+    t0, l0, l1 = [int(rng.integers(1, 9)) for _ in range(3)]           # embedded in a larger allocation: a row pitch that is no multiple of 4 (one geometry for the batch)
+    big = np.zeros((3, shape[0] + 2 * t0, shape[1] + l0 + l1, 3), np.uint8)
+    for k, x in enumerate(srcs):
+        big[k, t0:t0 + shape[0], l0:l0 + shape[1]] = x
+    dev = to_dev(big)
+    pitched = [dev[k, t0:t0 + shape[0], l0:l0 + shape[1]] for k in range(3)]
+    got = ms.resize_linear_batch(pitched, fx=scale, fy=scale)
+    for x, g in zip(srcs, got):
+        assert np.array_equal(host(g), oracle.resize_linear_8u(x, fx=scale, fy=scale)), (shape, scale)
+
+
 def test_bgr_to_i420_batch_equals_single_calls(ms, cuda):
     rng = np.random.default_rng(77)
     frames = [to_dev(rng.integers(0, 256, (46, 64, 3), dtype=np.uint8)) for _ in range(70)]      # > one launch's table of 64

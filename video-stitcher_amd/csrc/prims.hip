@@ -192,16 +192,117 @@ __global__ void __launch_bounds__(256) k_resize_linear3_batch(ResizeBatch T, siz
         d[c] = sat_u8(out);
     }
 }
+// The per-frame form of the same resize (the shipped COMPOSE_MEGAPIX puts cuda::resize of every view on the per-frame path, timed.cpp:75-85): 4 output
+// pixels x RS_ROWS rows per lane.  A lane's 4 pixels sample at most 8 consecutive source pixels for downscales up to 1.67x, so each source row is ONE
+// unaligned 24-byte window (16 + 8 byte loads: 3 lane-dwords per output pixel and row instead of 12 byte loads), the taps of a pixel are cut out of the
+// window in registers (dword select + v_alignbyte_b32), and the 12 output bytes leave as one store.  Same fp32 expressions in the same order as
+// k_resize_linear -> bit-identical (tests/test_prims_gpu.py::test_resize_linear_batch_equals_single_calls).  Lanes whose window would leave the source
+// row, ragged right edges and stronger downscales take the per-pixel path.  1.0 GB per 16-frame batch: 0.96 ms with the per-pixel kernel, see profiles/.
+constexpr int RS_ROWS = 2;
+__device__ __forceinline__ unsigned rs_sel4(unsigned a, unsigned b, unsigned c, unsigned d, int i) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
+__device__ __forceinline__ float rs_byte(unsigned lo, unsigned hi, int b) { return (float)(((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu); }
+__global__ void __launch_bounds__(256) k_resize_linear3_x4(ResizeBatch T, size_t sstep, int srows, int scols, size_t dstep, int drows, int dcols, float ify, float ifx)
+{
+    const int x0 = 4 * (int)(blockIdx.x * BX + threadIdx.x);
+    const int yb = (int)(blockIdx.y * BY + threadIdx.y) * RS_ROWS;
+    if (x0 >= dcols || yb >= drows) return;
+    const uint8_t *src = T.src[blockIdx.z];
+    uint8_t *dst = T.dst[blockIdx.z];
+    float sx[4];
+    int x1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sx[k] = (float)(x0 + k) * ifx; x1[k] = f2i_rd(sx[k]); }
+    const bool fast = x0 + 3 < dcols && x1[0] >= 0 && x1[0] + 8 <= scols && x1[3] - x1[0] <= 5 && x1[1] >= x1[0] && x1[2] >= x1[1] && x1[3] >= x1[2];
+    if (!fast) {                      // the per-pixel kernel's code for this lane's pixels
+        for (int r = 0; r < RS_ROWS && yb + r < drows; ++r) {
+            const int y = yb + r;
+            const float sy = (float)y * ify;
+            const int y1 = f2i_rd(sy), y2 = y1 + 1, y2r = min(y2, srows - 1);
+            const uint8_t *r1 = row_ptr<uint8_t>(src, sstep, y1), *r2 = row_ptr<uint8_t>(src, sstep, y2r);
+            for (int k = 0; k < 4 && x0 + k < dcols; ++k) {
+                const int x2 = x1[k] + 1, x2r = min(x2, scols - 1);
+                const float w11 = ((float)x2 - sx[k]) * ((float)y2 - sy), w12 = (sx[k] - (float)x1[k]) * ((float)y2 - sy);
+                const float w21 = ((float)x2 - sx[k]) * (sy - (float)y1), w22 = (sx[k] - (float)x1[k]) * (sy - (float)y1);
+                uint8_t *d = row_ptr<uint8_t>(dst, dstep, y) + (size_t)(x0 + k) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float out = 0.f;
+                    out = __builtin_fmaf((float)r1[(size_t)x1[k] * 3 + c], w11, out);
+                    out = __builtin_fmaf((float)r1[(size_t)x2r * 3 + c], w12, out);
+                    out = __builtin_fmaf((float)r2[(size_t)x1[k] * 3 + c], w21, out);
+                    out = __builtin_fmaf((float)r2[(size_t)x2r * 3 + c], w22, out);
+                    d[c] = sat_u8(out);
+                }
+            }
+        }
+        return;
+    }
+    int di[4], sh[4];                 // dword index and byte shift of each pixel's 6 tap bytes inside the 24-byte window
+    float wx1[4], wx2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = 3 * (x1[k] - x1[0]);
+        di[k] = o >> 2; sh[k] = o & 3;
+        wx2[k] = (float)(x1[k] + 1) - sx[k]; wx1[k] = sx[k] - (float)x1[k];
+    }
+    const size_t col0 = (size_t)x1[0] * 3;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        const int y = yb + r;
+        if (y >= drows) break;
+        const float sy = (float)y * ify;
+        const int y1 = f2i_rd(sy), y2 = y1 + 1, y2r = min(y2, srows - 1);
+        const float wy2 = (float)y2 - sy, wy1 = sy - (float)y1;
+        unsigned w[2][6];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint8_t *p = row_ptr<uint8_t>(src, sstep, q ? y2r : y1) + col0;
+            uint4 a; uint2 b;
+            __builtin_memcpy(&a, p, 16); __builtin_memcpy(&b, p + 16, 8);
+            w[q][0] = a.x; w[q][1] = a.y; w[q][2] = a.z; w[q][3] = a.w; w[q][4] = b.x; w[q][5] = b.y;
+        }
+        unsigned o3[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned lo[2], hi[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned d0 = rs_sel4(w[q][0], w[q][1], w[q][2], w[q][3], di[k]), d1 = rs_sel4(w[q][1], w[q][2], w[q][3], w[q][4], di[k]),
+                               d2 = rs_sel4(w[q][2], w[q][3], w[q][4], w[q][5], di[k]);
+                lo[q] = __builtin_amdgcn_alignbyte(d1, d0, (unsigned)sh[k]);
+                hi[q] = __builtin_amdgcn_alignbyte(d2, d1, (unsigned)sh[k]);
+            }
+            const float w11 = wx2[k] * wy2, w12 = wx1[k] * wy2, w21 = wx2[k] * wy1, w22 = wx1[k] * wy1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float out = 0.f;
+                out = __builtin_fmaf(rs_byte(lo[0], hi[0], c), w11, out);
+                out = __builtin_fmaf(rs_byte(lo[0], hi[0], 3 + c), w12, out);
+                out = __builtin_fmaf(rs_byte(lo[1], hi[1], c), w21, out);
+                out = __builtin_fmaf(rs_byte(lo[1], hi[1], 3 + c), w22, out);
+                const int i = 3 * k + c;
+                o3[i >> 2] = sat_u8_into(out, (unsigned)(i & 3), o3[i >> 2]);
+            }
+        }
+        __builtin_memcpy(row_ptr<uint8_t>(dst, dstep, y) + (size_t)x0 * 3, o3, 12);
+    }
+}
 int launch_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double fx, double fy, hipStream_t st)
 {
     if (!(fx > 0 && fy > 0)) { fx = (double)dst[0].cols / src[0].cols; fy = (double)dst[0].rows / src[0].rows; }
     const float ifx = (float)(1.0 / fx), ify = (float)(1.0 / fy);
+    const bool x4 = ifx >= 1.f && ifx <= 1.6f && src[0].cols >= 16 && getenv("MS_RESIZE_SIMPLE") == nullptr;      // downscales whose 4-pixel windows fit 24 bytes; else one pixel per lane
     for (int i0 = 0; i0 < n; i0 += RESIZE_BATCH) {
         const int m = std::min(RESIZE_BATCH, n - i0);
         ResizeBatch T{};
         for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
-        const dim3 g2 = grid2d(dst[0].cols, dst[0].rows);
-        k_resize_linear3_batch<<<dim3(g2.x, g2.y, m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx);
+        if (x4) {
+            const dim3 g(div_up(div_up(dst[0].cols, 4), BX), div_up(div_up(dst[0].rows, RS_ROWS), BY), m);
+            k_resize_linear3_x4<<<g, dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx);
+        } else {
+            const dim3 g2 = grid2d(dst[0].cols, dst[0].rows);
+            k_resize_linear3_batch<<<dim3(g2.x, g2.y, m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx);
+        }
         MS_LAUNCH_CHECK();
     }
     return MS_OK;

@@ -243,16 +243,22 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
 // One lane owns WARP_NG groups of 4 consecutive pixels (rows y and y + 16/WARP_NG of the tile): all WARP_NG*8 tap-row
 // loads are in flight together, so a wave pays the memory round trip once for 2x the pixels.
 #ifndef MS_WARP_NG
-#define MS_WARP_NG 2
+#define MS_WARP_NG 1
 #endif
 constexpr int WARP_NG = MS_WARP_NG;
 constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = WARP_BX x WARP_BY lanes
 
 // One tile of Gaussian level 0 with the taps gathered straight from global memory (unaligned 8-byte reads): lane (tx, ty) of a
-// WARP_BX x WARP_BY arrangement.  Software pipeline over the WARP_NG row groups of the lane -- the tap reads of group g+1 are in
-// flight while group g is blended.  PROJ = the context's projection (compile-time: no per-pixel branches in the coordinate code).
-template <bool CPW, int PROJ, bool AL = false>      // AL: aligned 12-byte tap reads (see Px3); chosen per tile by the caller, never per lane
-__device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
+// WARP_BX x WARP_BY arrangement.  Software pipeline over the lane's units of work -- a unit = one row group of one frame -- with the tap
+// reads of unit u+1 in flight while unit u is blended.  PROJ = the context's projection (compile-time: no per-pixel branches in the coordinate code).
+// NF = frames per lane (1 or 2): the source coordinates of a pixel do not depend on the frame (the projection tables, and with CPW the mesh
+// maps, are per context), so with NF = 2 a wave warps the same tile of frames f0 and f0 + 1 and builds each row group's coordinates ONCE --
+// a fifth of the kernel's VALU work, and with CPW half of its mesh-map reads -- while the reads in flight per lane stay what they were.
+#ifndef MS_WARP_NF_OPAQUE
+#define MS_WARP_NF_OPAQUE 0
+#endif
+template <bool CPW, int PROJ, bool AL = false, int NF = 1>      // AL: aligned 12-byte tap reads (see Px3); chosen per tile by the caller, never per lane
+__device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int nf, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
                                                  const SrcTable &src, int src_rows, int src_cols, const MeshTable &mesh,
                                                  const uint8_t *__restrict__ stage, long long stage_stride,
                                                  uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
@@ -264,19 +270,23 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
     bool active[WARP_NG];
 #pragma unroll
     for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + ty + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
-    const uint8_t *sp;
-    unsigned sstep;
+    const uint8_t *sp[NF];
+    unsigned sstep[NF];
     int srows, scols;
-    if (CPW) { sp = stage + (size_t)f * stage_stride + V.s1_off; sstep = (unsigned)V.s1_pitch; srows = V.ah; scols = V.aw; }
-    else { sp = src.p[f * n_views + v]; sstep = src.step[f * n_views + v]; srows = src_rows; scols = src_cols; }
+#pragma unroll
+    for (int fi = 0; fi < NF; ++fi) {
+        const int f = f0 + (fi < nf ? fi : 0);      // (a missing second frame of an odd batch is never sampled: its units are skipped below)
+        if (CPW) { sp[fi] = stage + (size_t)f * stage_stride + V.s1_off; sstep[fi] = (unsigned)V.s1_pitch; }
+        else { sp[fi] = src.p[f * n_views + v]; sstep[fi] = src.step[f * n_views + v]; }
+    }
+    if (CPW) { srows = V.ah; scols = V.aw; } else { srows = src_rows; scols = src_cols; }
     const LevelDesc &L = V.lv[0];
     const size_t plane = (size_t)L.h * L.pitch;
-    float xc[2][4], yc[2][4];
-    Px2 r1[2][4], r2[2][4];
-    // AL: the raw tap reads in flight are 12 aligned bytes per tap row + the 2-bit byte shifts of the group's 4 pixels
+    float xc[2][4], yc[2][4];           // coordinates of a row group (WARP_NG <= 2 with NF = 2: one buffer per group)
+    Px2 r1[2][4], r2[2][4];             // tap rows of a unit: double-buffered by unit
+    // AL: the raw tap reads in flight are 12 aligned bytes per tap row + the 2-bit byte shifts of the unit's 4 pixels
     Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];
     unsigned sh1[2] = {0u, 0u}, sh2[2] = {0u, 0u};
-    const unsigned sp_lo = (unsigned)(uintptr_t)sp;
     // the 1-D tables of the projection are read ONCE, up front (column terms of the lane's 4 pixels, row term of each row group):
     // building the coordinates of a group is then pure arithmetic, with no load between it and the tap reads
     float2 ct[4], rt[WARP_NG];
@@ -301,53 +311,67 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
         for (int g = 0; g < WARP_NG; ++g)
             if (active[g]) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[g & 1], yc[g & 1]);
     }
-    auto issue = [&](int g) {
-        const int b = g & 1;
+    // units of this lane: (frame fi, group g), u = fi * WARP_NG + g -- all groups of the first frame, then all groups of the second: the coordinates of every
+    // group are live from its first unit on (16 registers for two groups, as before), the column / row tables die after the first frame's units, and at most
+    // two units' tap reads are in flight: the register peak is the one-frame kernel's (the order g-major instead costs 40 VGPRs = a wave per SIMD)
+    constexpr int NU = WARP_NG * NF;
+    auto issue = [&](int u) {
+        const int fi = u / WARP_NG, g = u % WARP_NG, cb = g & 1, lb = u & 1;
+        if (fi == 0) {                    // the group's coordinates: built for its first frame, reused by the second
 #if defined(MS_PROBE) && MS_PROBE == 3       // roofline probe: affine coordinates instead of the projection (same gather density)
-        if (active[g]) { for (int k = 0; k < 4; ++k) { xc[b][k] = 1.55f * (float)(x + k - V.left) + 20.3f; yc[b][k] = 1.6f * (float)(ys[g] - V.top) + 10.7f; } }
+            if (active[g]) { for (int k = 0; k < 4; ++k) { xc[cb][k] = 1.55f * (float)(x + k - V.left) + 20.3f; yc[cb][k] = 1.6f * (float)(ys[g] - V.top) + 10.7f; } }
 #else
-        if (active[g]) {
-            if (CPW) {
-                if (WARP_NG > 2) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[b], yc[b]);      // (<= 2 groups: already read up front)
-            } else {
+            if (active[g]) {
+                if (CPW) {
+                    if (WARP_NG > 2) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[cb], yc[cb]);      // (<= 2 groups: already read up front)
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[b][k], yc[b][k]);
+                    for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[cb][k], yc[cb][k]);
+                }
+            }
+#endif
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xc[cb][k] = yc[cb][k] = -1.f;
             }
         }
-#endif
-        else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) xc[b][k] = yc[b][k] = -1.f;
-        }
+        if (NF > 1 && fi >= nf) return;       // (wave-uniform)
+        const uint8_t *spf = sp[fi];
+        const unsigned stf = sstep[fi];
+        const unsigned sp_lo = (unsigned)(uintptr_t)spf;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
+            float xq = xc[cb][k], yq = yc[cb][k];
+#if MS_WARP_NF_OPAQUE                        // the second frame re-derives offsets and weights from the coordinates instead of keeping the first frame's alive
+            if (fi > 0) asm volatile("" : "+v"(xq), "+v"(yq));      // (common-subexpression elimination across the two frames costs 48 VGPRs = a wave per SIMD)
+#endif
+            unsigned off = tap_offset(f2i_rd(xq), f2i_rd(yq), srows, scols, stf);
 #if defined(MS_PROBE) && MS_PROBE == 1       // roofline probe: same instructions, every tap read from one 4 KiB window (cache resident)
             off &= 0xfffu;
 #endif
 #if defined(MS_PROBE) && MS_PROBE == 10      // no-gather probe (WRONG pixels): no tap reads at all
-            r1[b][k] = Px2{off, off * 3u}; r2[b][k] = Px2{off ^ 0x55u, off + 7u};
+            r1[lb][k] = Px2{off, off * 3u}; r2[lb][k] = Px2{off ^ 0x55u, off + 7u};
 #else
             if (AL) {
-                q1[AL ? b : 0][AL ? k : 0] = load_px3(sp + off);
-                q2[AL ? b : 0][AL ? k : 0] = load_px3(sp + sstep + off);
+                q1[AL ? lb : 0][AL ? k : 0] = load_px3(spf + off);
+                q2[AL ? lb : 0][AL ? k : 0] = load_px3(spf + stf + off);
                 const unsigned a = sp_lo + off;
-                if (k == 0) { sh1[b] = a & 3u; sh2[b] = (a + sstep) & 3u; }
-                else { sh1[b] |= (a & 3u) << (2 * k); sh2[b] |= ((a + sstep) & 3u) << (2 * k); }
+                if (k == 0) { sh1[lb] = a & 3u; sh2[lb] = (a + stf) & 3u; }
+                else { sh1[lb] |= (a & 3u) << (2 * k); sh2[lb] |= ((a + stf) & 3u) << (2 * k); }
             } else {
-                r1[b][k] = load_px2(sp, off);
-                r2[b][k] = load_px2(sp + sstep, off);
+                r1[lb][k] = load_px2(spf, off);
+                r2[lb][k] = load_px2(spf + stf, off);
             }
 #endif
         }
     };
     issue(0);
 #pragma unroll
-    for (int g = 0; g < WARP_NG; ++g) {
-        const int b = g & 1;
-        if (g + 1 < WARP_NG) issue(g + 1);
+    for (int u = 0; u < NU; ++u) {
+        const int fi = u / WARP_NG, g = u % WARP_NG, cb = g & 1, lb = u & 1;
+        if (u + 1 < NU) issue(u + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (active[g]) {
+        if (active[g] && (NF == 1 || fi < nf)) {
             unsigned packed[3] = {0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 4; k += 2) {
@@ -357,17 +381,21 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
                 if (AL) {       // the pair's 8-byte windows out of the aligned reads, right before use (keeps the raw reads, not both forms, live)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        r1[b][k + j] = px3_to_px2(q1[AL ? b : 0][AL ? k + j : 0], sh1[b] >> (2 * (k + j)));
-                        r2[b][k + j] = px3_to_px2(q2[AL ? b : 0][AL ? k + j : 0], sh2[b] >> (2 * (k + j)));
+                        r1[lb][k + j] = px3_to_px2(q1[AL ? lb : 0][AL ? k + j : 0], sh1[lb] >> (2 * (k + j)));
+                        r2[lb][k + j] = px3_to_px2(q2[AL ? lb : 0][AL ? k + j : 0], sh2[lb] >> (2 * (k + j)));
                     }
                 }
 #endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
-                    if (!t[j].fast) fix_border_taps(r1[b][k + j], r2[b][k + j], t[j].x1, t[j].y1, srows, scols);
+                    float xq = xc[cb][k + j], yq = yc[cb][k + j];
+#if MS_WARP_NF_OPAQUE
+                    if (fi > 0) asm volatile("" : "+v"(xq), "+v"(yq));
+#endif
+                    t[j] = make_taps(xq, yq, srows, scols);
+                    if (!t[j].fast) fix_border_taps(r1[lb][k + j], r2[lb][k + j], t[j].x1, t[j].y1, srows, scols);
                 }
-                blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
+                blend_taps2(t[0], t[1], r1[lb][k], r2[lb][k], r1[lb][k + 1], r2[lb][k + 1], o[0], o[1]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -375,7 +403,7 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
                         packed[c] = CPW ? sat_u8_into(o[j][c], k + j, packed[c])
                                         : sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[c]);
             }
-            uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
+            uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
 #if defined(MS_PROBE) && MS_PROBE == 9       // no-store probe: the stores (almost) never execute
             if (packed[0] == 0x12345678u && packed[1] == 0x9abcdef0u && packed[2] == 0x0fedcba9u)
 #endif
@@ -391,21 +419,26 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f, int t
 
 // AL: aligned 12-byte tap reads (Px3) for the tiles that allow them -- 28 more VGPRs (4 instead of 6 waves per SIMD), so the context picks the kernel:
 // aligned where neighbouring samples share dwords (moderate minification: config 2, -6 %; the CPW mesh remap, -10 %), unaligned where every tap
-// read is isolated and occupancy matters more (config 5's 2.7x minification: +17 % with AL).
+// read is isolated and occupancy matters more (config 5's 2.7x minification: +17 % with AL).  blockIdx.z = a PAIR of frames (WARP_NF = 2): see NF above.
+#ifndef MS_WARP_NF
+#define MS_WARP_NF 2
+#endif
+constexpr int WARP_NF = MS_WARP_NF;
 template <bool CPW, bool AL, int PROJ>
 __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
-                                                         uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
+                                                         uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs, int n_frames)
 {
     const WarpTile T = tiles[blockIdx.x];
+    const int f0 = (int)blockIdx.z * WARP_NF, nf = min(WARP_NF, n_frames - f0);
     // aligned tap reads unless a sample of the tile reads the last row of a caller's image (flags bit 3, k_tile_bbox); the CPW stage buffer is ours and padded
     if (AL && (CPW || (T.flags & 8)))
-        warp_tile_direct<CPW, PROJ, true>(T, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
-                                          g0, g0_stride, tabs);
+        warp_tile_direct<CPW, PROJ, true, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                                   g0, g0_stride, tabs);
     else
-        warp_tile_direct<CPW, PROJ, false>(T, (int)blockIdx.z, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
-                                           g0, g0_stride, tabs);
+        warp_tile_direct<CPW, PROJ, false, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                                    g0, g0_stride, tabs);
 }
 
 // ---- the same tiles with the source staged in LDS by asynchronous LDS-DMA: persistent, self-pipelined waves -------------------
@@ -510,7 +543,7 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
         advance(tnn, fnn);
         const WarpTile Tnn = tiles[fnn < n_frames ? tnn : t];
         if (!(T.flags & 1)) {
-            warp_tile_direct<false, PROJ>(T, f, tx, ty, views, n_views, src, srows, scols, none, nullptr, 0, g0, g0_stride, tabs);
+            warp_tile_direct<false, PROJ>(T, f, 1, tx, ty, views, n_views, src, srows, scols, none, nullptr, 0, g0, g0_stride, tabs);
             __builtin_amdgcn_s_waitcnt(0x0F70);               // the staging copy of the next tile has landed
         } else {
             const int v = T.view;
@@ -599,19 +632,29 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
 }
 
 // ---- CPW stage 1: images[i] = gain(remap(full_img, x_map, y_map)) (timed.cpp:90-94), 4 px per lane --------------
-// Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).
+// Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).  One row of 4 pixels per lane,
+// S1_NF frames per lane: the projection coordinates and bilinear weights are built once and used for both frames (as in warp_tile_direct), the tap
+// reads of frame fi + 1 are in flight while frame fi is blended.
+#ifndef MS_S1_NF
+#define MS_S1_NF 2
+#endif
+constexpr int S1_NF = MS_S1_NF;
+constexpr int S1_BY = WARP_TH;          // lane rows of the block (the launch uses the same): one tile row per lane
 template <int PROJ, bool AL>
-__device__ __forceinline__ void stage1_tile(const WarpTile &T, int f, const ViewDesc *__restrict__ views, int n_views,
+__device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, const ViewDesc *__restrict__ views, int n_views,
                                             const SrcTable &src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
 {
     const int v = T.view;
     const ViewDesc &V = views[v];
-    const int x = T.x0 + 4 * (int)threadIdx.x;
-    if (x >= V.aw) return;
-    const uint8_t *sp = src.p[f * n_views + v];
-    const unsigned sstep = src.step[f * n_views + v];
-    // column terms once per lane (as in k_warp_t); the rows of the tile are walked as a software pipeline: the tap reads of the next
-    // row are in flight while the current one is blended
+    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
+    if (x >= V.aw || y >= V.ah) return;
+    const uint8_t *sp[S1_NF];
+    unsigned sstep[S1_NF];
+#pragma unroll
+    for (int fi = 0; fi < S1_NF; ++fi) {
+        const int f = f0 + (fi < nf ? fi : 0);
+        sp[fi] = src.p[f * n_views + v]; sstep[fi] = src.step[f * n_views + v];
+    }
     float2 ct[4];
     if (x + 3 < V.aw) {
         float4 a, b;
@@ -622,38 +665,39 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f, const View
 #pragma unroll
         for (int k = 0; k < 4; ++k) ct[k] = V.coltab[min(x + k, V.aw - 1)];
     }
-    constexpr int S1_BY = (WARP_TH / 2 < 256 / WARP_BX) ? WARP_TH / 2 : 256 / WARP_BX;      // lane rows of the block (launch uses the same)
-    constexpr int S1_NG = WARP_TH / S1_BY;                                                 // row groups per lane
-    float xc[2][4], yc[2][4];
+    const float2 rt = V.rowtab[y];
+    float xc[4], yc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
     Px2 r1[2][4], r2[2][4];
     Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];      // AL: aligned 12-byte tap reads, as in warp_tile_direct
     unsigned sh1[2] = {0u, 0u}, sh2[2] = {0u, 0u};
-    const unsigned sp_lo = (unsigned)(uintptr_t)sp;
-    auto issue = [&](int y, int b) {
-        if (y >= V.ah) return;
-        const float2 rt = V.rowtab[y];
+    auto issue = [&](int fi) {
+        if (fi >= nf) return;
+        const int b = fi & 1;
+        const uint8_t *spf = sp[fi];
+        const unsigned stf = sstep[fi], sp_lo = (unsigned)(uintptr_t)spf;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            warp_combine(PROJ, ct[k], rt, V.wp, xc[b][k], yc[b][k]);
-            const unsigned off = tap_offset(f2i_rd(xc[b][k]), f2i_rd(yc[b][k]), srows, scols, sstep);
+            const unsigned off = tap_offset(f2i_rd(xc[k]), f2i_rd(yc[k]), srows, scols, stf);
             if (AL) {
-                q1[AL ? b : 0][AL ? k : 0] = load_px3(sp + off);
-                q2[AL ? b : 0][AL ? k : 0] = load_px3(sp + sstep + off);
+                q1[AL ? b : 0][AL ? k : 0] = load_px3(spf + off);
+                q2[AL ? b : 0][AL ? k : 0] = load_px3(spf + stf + off);
                 const unsigned a = sp_lo + off;
-                if (k == 0) { sh1[b] = a & 3u; sh2[b] = (a + sstep) & 3u; }
-                else { sh1[b] |= (a & 3u) << (2 * k); sh2[b] |= ((a + sstep) & 3u) << (2 * k); }
+                if (k == 0) { sh1[b] = a & 3u; sh2[b] = (a + stf) & 3u; }
+                else { sh1[b] |= (a & 3u) << (2 * k); sh2[b] |= ((a + stf) & 3u) << (2 * k); }
             } else {
-                r1[b][k] = load_px2(sp, off);
-                r2[b][k] = load_px2(sp + sstep, off);
+                r1[b][k] = load_px2(spf, off);
+                r2[b][k] = load_px2(spf + stf, off);
             }
         }
     };
-    issue(T.y0 + (int)threadIdx.y, 0);
+    issue(0);
 #pragma unroll
-    for (int g = 0; g < S1_NG; ++g) {
-        const int b = g & 1, y = T.y0 + (int)threadIdx.y + g * S1_BY;
-        if (g + 1 < S1_NG) issue(y + S1_BY, b ^ 1);
-        if (y >= V.ah) continue;
+    for (int fi = 0; fi < S1_NF; ++fi) {
+        const int b = fi & 1;
+        if (fi + 1 < S1_NF) issue(fi + 1);
+        if (fi >= nf) continue;
         unsigned w[3] = {0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 4; k += 2) {
@@ -668,7 +712,7 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f, const View
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                t[j] = make_taps(xc[b][k + j], yc[b][k + j], srows, scols);
+                t[j] = make_taps(xc[k + j], yc[k + j], srows, scols);
                 if (!t[j].fast) fix_border_taps(r1[b][k + j], r2[b][k + j], t[j].x1, t[j].y1, srows, scols);
             }
             blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
@@ -680,7 +724,7 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f, const View
                     w[i >> 2] = sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), i & 3, w[i >> 2]);
                 }
         }
-        uint8_t *d = stage + (size_t)f * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
+        uint8_t *d = stage + (size_t)(f0 + fi) * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
         if (x + 3 < V.aw) __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
         else {
             for (int k = 0; k < 4 && x + k < V.aw; ++k)
@@ -690,14 +734,15 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f, const View
 }
 
 template <int PROJ, bool AL>
-__global__ void __launch_bounds__(256) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
-                                                  SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp)
+__global__ void __launch_bounds__(WARP_BX * S1_BY) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                             SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp, int n_frames)
 {
     const WarpTile T = tiles[blockIdx.x];
     // the mesh of this view moves no sample further than the bound the plan assumed: stage 2 never reads this tile
     if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;
-    if (AL && (T.flags & 8)) stage1_tile<PROJ, true>(T, (int)blockIdx.z, views, n_views, src, srows, scols, stage, stage_stride);
-    else stage1_tile<PROJ, false>(T, (int)blockIdx.z, views, n_views, src, srows, scols, stage, stage_stride);
+    const int f0 = (int)blockIdx.z * S1_NF, nf = min(S1_NF, n_frames - f0);
+    if (AL && (T.flags & 8)) stage1_tile<PROJ, true>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+    else stage1_tile<PROJ, false>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
 }
 
 // ---- pyrDown, tile list, DOWN_ROWS (4) rows x 4 cols per lane (block 32 x 8): 11 input rows for 4 output rows (2 rows per lane: 7 for 2, 16 % slower) ----
