@@ -50,7 +50,7 @@ def main(tag):
         occ = c.get("SQ_WAVE_CYCLES", 0) * 4 / (c.get("_us", us) * 1e-6 * clk) / 1024 if c.get("SQ_WAVE_CYCLES") else None
         rows.append((us * v["launches"], k, v["launches"], us, v["hbm_bytes_per_launch"], waves, valu / waves if waves else None, busy, occ))
     rows.sort(reverse=True)
-    lines = ["# Per-kernel report (%s): config 2, %d frames per launch, one context / one stream" % (tag, F), "",
+    lines = ["# Per-kernel report (%s): %s, %d frames per launch, one context / one stream" % (tag, traffic.get("config", "cfg2"), F), "",
              "Sources: `%s_kernel_trace.txt`/`%s_traffic.json` (rocprofv3 kernel trace; FETCH_SIZE x2.0 + WRITE_SIZE x1.0, calibrated on a 1 GiB copy),"
              " `%s_counters.txt` (SQ counters), `%s_bench.json` (bench.py line).  VALU busy = VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.33 GHz)." % (tag, tag, tag, tag), "",
              "| kernel | mean launch µs | µs / frame | HBM MB / launch | HBM TB/s | waves | VALU / wave | VALU busy | waves / SIMD |", "|---|---|---|---|---|---|---|---|---|"]
@@ -59,9 +59,10 @@ def main(tag):
             k, us, us / F, hb / 1e6, hb / (us * 1e-6) / 1e12, "%d" % waves if waves else "-", "%.0f" % vpw if vpw else "-",
             "%.2f" % busy if busy is not None else "-", "%.1f" % occ if occ is not None else "-"))
     r = bench["roofline"]
-    lines += ["", "bench.py: **%.0f frames/s** (%s); dominant kernel `%s`: %.0f MB algorithmic / %.1f µs = %.0f GB/s = **%.3f of 8 TB/s**; PMC traffic of that "
-              "launch %.0f MB." % (bench["value"], bench["config"]["workload"], r["kernel"], r["alg_bytes_per_launch"] / 1e6, r["mean_launch_ms"] * 1e3,
-                                   r["achieved"], r["frac"], (r["traffic"] or 0) / 1e6),
+    lines += ["", "bench.py: **%.0f frames/s** (%s); dominant kernel `%s`: %.0f MB of PMC-measured HBM traffic / %.1f µs = %.0f GB/s = **%.3f of 8 TB/s** (physical; %s); "
+              "by SURVEY 8(d)'s algorithmic bytes (%.0f MB per launch) %.3f." % (bench["value"], bench["config"]["workload"], r["kernel"], (r["traffic"] or 0) / 1e6, r["mean_launch_ms"] * 1e3,
+                                                                                   r["achieved"], r["frac"], r.get("basis", "?"), r["alg_bytes_per_launch"] / 1e6, r.get("frac_contract", 0.0)),
+              "ceiling measured in the same run: tuned copy %.2f TB/s, read %.2f TB/s." % (bench["ceiling"]["copy_TBps"], bench["ceiling"]["read_TBps"]) if bench.get("ceiling") and "copy_TBps" in bench["ceiling"] else "",
               "cpu_baseline: %.1f frames/s on %d threads of %s (%s)." % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["cores"],
                                                                           bench["cpu_baseline"].get("cpu", "?"), bench["cpu_baseline"]["kind"]) if "cpu_baseline" in bench else ""]
     out = os.path.join(prof, "%s_report.md" % tag)

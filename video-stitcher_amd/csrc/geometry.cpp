@@ -60,28 +60,30 @@ struct Box {
     }
 };
 
-void map_forward(int proj, const Projector &p, float x, float y, float &u, float &v)
+// Source pixel -> panorama coordinates: the viewing ray of the pixel (R K^-1 applied to (x, y, 1)) projected onto the plane / cylinder / sphere.
+// The formulas are the projectors' of detail/warpers_inl.hpp:244-307; what is pinned here is the fp32 evaluation order, because the ROI corners are
+// integer truncations of these values and must land on the reference's (SURVEY App. C known answers, tests/test_geometry_kats.py).
+struct Ray { float x, y, z; };
+inline Ray pixel_ray(const Projector &p, float px, float py)
 {
-    const float *r = p.r_kinv;
-    float x_ = r[0] * x + r[1] * y + r[2];
-    float y_ = r[3] * x + r[4] * y + r[5];
-    float z_ = r[6] * x + r[7] * y + r[8];
-    switch (proj) {
-    case MS_PROJ_PLANE:
-        x_ = p.t[0] + x_ / z_ * (1 - p.t[2]);
-        y_ = p.t[1] + y_ / z_ * (1 - p.t[2]);
-        u = p.scale * x_;
-        v = p.scale * y_;
-        break;
-    case MS_PROJ_SPHERICAL: {
-        u = p.scale * atan2f(x_, z_);
-        float w = y_ / sqrtf(x_ * x_ + y_ * y_ + z_ * z_);
-        v = p.scale * (static_cast<float>(kPi) - acosf(w == w ? w : 0));
-        break;
+    const float *m = p.r_kinv;
+    return Ray{m[0] * px + m[1] * py + m[2], m[3] * px + m[4] * py + m[5], m[6] * px + m[7] * py + m[8]};
+}
+void map_forward(int proj, const Projector &p, float px, float py, float &u, float &v)
+{
+    const Ray d = pixel_ray(p, px, py);
+    if (proj == MS_PROJ_PLANE) {            // perspective division onto the plane z = 1 - t_z, shifted by the translation
+        const float depth = 1 - p.t[2];
+        u = p.scale * (p.t[0] + d.x / d.z * depth);
+        v = p.scale * (p.t[1] + d.y / d.z * depth);
+        return;
     }
-    default:
-        u = p.scale * atan2f(x_, z_);
-        v = p.scale * y_ / sqrtf(x_ * x_ + z_ * z_);
+    u = p.scale * atan2f(d.x, d.z);          // longitude: shared by the cylinder and the sphere
+    if (proj == MS_PROJ_SPHERICAL) {
+        const float cos_polar = d.y / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+        v = p.scale * (static_cast<float>(kPi) - acosf(std::isnan(cos_polar) ? 0.f : cos_polar));      // a zero ray (0 / 0) counts as the equator
+    } else {
+        v = p.scale * d.y / sqrtf(d.x * d.x + d.z * d.z);
     }
 }
 

@@ -240,8 +240,8 @@ __global__ void __launch_bounds__(256) k_tile_bbox(WarpTile *__restrict__ tiles,
     }
 }
 
-// One lane owns WARP_NG groups of 4 consecutive pixels (rows y and y + 16/WARP_NG of the tile): all WARP_NG*8 tap-row
-// loads are in flight together, so a wave pays the memory round trip once for 2x the pixels.
+// One lane owns WARP_NG row groups of 4 consecutive pixels (rows y, y + WARP_TH / WARP_NG, ..) of WARP_NF frames.  Round 3 default: ONE row group, TWO frames
+// (same 16 tap-row reads in flight per lane as two row groups of one frame, but the coordinates and weights are built once: see warp_tile_direct).
 #ifndef MS_WARP_NG
 #define MS_WARP_NG 1
 #endif
@@ -257,7 +257,7 @@ constexpr int WARP_BY = WARP_TH / WARP_NG;    // block = WARP_BX x WARP_BY lanes
 #ifndef MS_WARP_NF_OPAQUE
 #define MS_WARP_NF_OPAQUE 0
 #endif
-template <bool CPW, int PROJ, bool AL = false, int NF = 1>      // AL: aligned 12-byte tap reads (see Px3); chosen per tile by the caller, never per lane
+template <bool CPW, int PROJ, bool AL = false, int NF = 1, int NG = WARP_NG>      // NG: row groups per lane (block = WARP_BX x WARP_TH / NG lanes); AL: aligned 12-byte tap reads (see Px3); chosen per tile by the caller, never per lane
 __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int nf, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
                                                  const SrcTable &src, int src_rows, int src_cols, const MeshTable &mesh,
                                                  const uint8_t *__restrict__ stage, long long stage_stride,
@@ -266,10 +266,10 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
     const int v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * tx;
-    int ys[WARP_NG];
-    bool active[WARP_NG];
+    int ys[NG];
+    bool active[NG];
 #pragma unroll
-    for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + ty + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
+    for (int g = 0; g < NG; ++g) { ys[g] = T.y0 + ty + g * (WARP_TH / NG); active[g] = x < V.pw && ys[g] < V.ph; }
     const uint8_t *sp[NF];
     unsigned sstep[NF];
     int srows, scols;
@@ -282,14 +282,14 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
     if (CPW) { srows = V.ah; scols = V.aw; } else { srows = src_rows; scols = src_cols; }
     const LevelDesc &L = V.lv[0];
     const size_t plane = (size_t)L.h * L.pitch;
-    float xc[2][4], yc[2][4];           // coordinates of a row group (WARP_NG <= 2 with NF = 2: one buffer per group)
+    float xc[2][4], yc[2][4];           // coordinates of a row group (NG <= 2 with NF = 2: one buffer per group)
     Px2 r1[2][4], r2[2][4];             // tap rows of a unit: double-buffered by unit
     // AL: the raw tap reads in flight are 12 aligned bytes per tap row + the 2-bit byte shifts of the unit's 4 pixels
     Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];
     unsigned sh1[2] = {0u, 0u}, sh2[2] = {0u, 0u};
     // the 1-D tables of the projection are read ONCE, up front (column terms of the lane's 4 pixels, row term of each row group):
     // building the coordinates of a group is then pure arithmetic, with no load between it and the tap reads
-    float2 ct[4], rt[WARP_NG];
+    float2 ct[4], rt[NG];
     if (!CPW) {
         if (T.flags & 4) {            // interior tile: table addresses come from the tile entry alone, so these loads do not wait for
                                       // the view descriptor (one round trip less on the wave's critical path)
@@ -299,31 +299,31 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
             __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
             ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g) rt[g] = tabs[T.rtab + ty + g * WARP_BY];
+            for (int g = 0; g < NG; ++g) rt[g] = tabs[T.rtab + ty + g * (WARP_TH / NG)];
         } else {
             warp_coltab4(V, min(x, V.pw - 4), ct);
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
+            for (int g = 0; g < NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
         }
     }
-    if (CPW && WARP_NG <= 2) {        // the dense mesh maps of both row groups are read up front too (one round trip, not one per group)
+    if (CPW && NG <= 2) {        // the dense mesh maps of both row groups are read up front too (one round trip, not one per group)
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g)
+        for (int g = 0; g < NG; ++g)
             if (active[g]) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[g & 1], yc[g & 1]);
     }
-    // units of this lane: (frame fi, group g), u = fi * WARP_NG + g -- all groups of the first frame, then all groups of the second: the coordinates of every
+    // units of this lane: (frame fi, group g), u = fi * NG + g -- all groups of the first frame, then all groups of the second: the coordinates of every
     // group are live from its first unit on (16 registers for two groups, as before), the column / row tables die after the first frame's units, and at most
     // two units' tap reads are in flight: the register peak is the one-frame kernel's (the order g-major instead costs 40 VGPRs = a wave per SIMD)
-    constexpr int NU = WARP_NG * NF;
+    constexpr int NU = NG * NF;
     auto issue = [&](int u) {
-        const int fi = u / WARP_NG, g = u % WARP_NG, cb = g & 1, lb = u & 1;
+        const int fi = u / NG, g = u % NG, cb = g & 1, lb = u & 1;
         if (fi == 0) {                    // the group's coordinates: built for its first frame, reused by the second
 #if defined(MS_PROBE) && MS_PROBE == 3       // roofline probe: affine coordinates instead of the projection (same gather density)
             if (active[g]) { for (int k = 0; k < 4; ++k) { xc[cb][k] = 1.55f * (float)(x + k - V.left) + 20.3f; yc[cb][k] = 1.6f * (float)(ys[g] - V.top) + 10.7f; } }
 #else
             if (active[g]) {
                 if (CPW) {
-                    if (WARP_NG > 2) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[cb], yc[cb]);      // (<= 2 groups: already read up front)
+                    if (NG > 2) warp_coords4<CPW, PROJ>(V, mesh, v, x, ys[g], xc[cb], yc[cb]);      // (<= 2 groups: already read up front)
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[cb][k], yc[cb][k]);
@@ -368,7 +368,7 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
     issue(0);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int fi = u / WARP_NG, g = u % WARP_NG, cb = g & 1, lb = u & 1;
+        const int fi = u / NG, g = u % NG, cb = g & 1, lb = u & 1;
         if (u + 1 < NU) issue(u + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (active[g] && (NF == 1 || fi < nf)) {
@@ -482,9 +482,10 @@ __device__ __forceinline__ Px2 lds_px2(const uint8_t *lds, unsigned off)
     return px;
 }
 
+constexpr int WA_NG = 2, WA_BY = WARP_TH / WA_NG;      // k_warp_a: one 64-lane wave per tile = WARP_BX x WA_BY lanes, two row groups per lane
 // column terms of the lane's 4 pixels and row terms of its row groups, for tile T (loads only: consumed one iteration later)
 __device__ __forceinline__ void wa_tables(const WarpTile &T, const ViewDesc *__restrict__ views, const float2 *__restrict__ tabs, int tx, int ty,
-                                          float2 ct[4], float2 rt[WARP_NG])
+                                          float2 ct[4], float2 rt[WA_NG])
 {
     if (T.flags & 4) {
         float4 a, b;
@@ -493,12 +494,12 @@ __device__ __forceinline__ void wa_tables(const WarpTile &T, const ViewDesc *__r
         __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
         ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g) rt[g] = tabs[T.rtab + ty + g * WARP_BY];
+        for (int g = 0; g < WA_NG; ++g) rt[g] = tabs[T.rtab + ty + g * WA_BY];
     } else {
         const ViewDesc &V = views[T.view];
         warp_coltab4(V, min(T.x0 + 4 * tx, V.pw - 4), ct);
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(T.y0 + ty + g * WARP_BY, V.ph - 1) - V.top, V.ah)];
+        for (int g = 0; g < WA_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(T.y0 + ty + g * WA_BY, V.ph - 1) - V.top, V.ah)];
     }
 }
 
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
     int tn = t, fn = f;
     advance(tn, fn);
     WarpTile T = tiles[t], Tn = tiles[fn < n_frames ? tn : t];
-    float2 ct[4], rt[WARP_NG];
+    float2 ct[4], rt[WA_NG];
     wa_tables(T, views, tabs, tx, ty, ct, rt);
     int buf = 0;
     if (T.flags & 1) wa_stage(T, src.p[f * n_views + T.view], src.step[f * n_views + T.view], lds0, lane);
@@ -529,7 +530,7 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
         // the NEXT tile of this wave: its tables (ordinary loads, consumed one iteration later) and then its staging copy into the other
         // buffer, in flight while this tile is sampled.  Nothing issued after the copy is waited for before the s_waitcnt below.
         const bool more = fn < n_frames;
-        float2 ctn[4], rtn[WARP_NG];
+        float2 ctn[4], rtn[WA_NG];
         if (more) {
             wa_tables(Tn, views, tabs, tx, ty, ctn, rtn);
             if (Tn.flags & 1) wa_stage(Tn, src.p[fn * n_views + Tn.view], src.step[fn * n_views + Tn.view], lds0 + (unsigned)((buf ^ 1) * WA_BUF_BYTES), lane);
@@ -537,13 +538,13 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
 #pragma unroll
             for (int k = 0; k < 4; ++k) ctn[k] = ct[k];
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g) rtn[g] = rt[g];
+            for (int g = 0; g < WA_NG; ++g) rtn[g] = rt[g];
         }
         int tnn = tn, fnn = fn;                                // descriptor two tiles ahead (scalar load: its latency hides behind this tile)
         advance(tnn, fnn);
         const WarpTile Tnn = tiles[fnn < n_frames ? tnn : t];
         if (!(T.flags & 1)) {
-            warp_tile_direct<false, PROJ>(T, f, 1, tx, ty, views, n_views, src, srows, scols, none, nullptr, 0, g0, g0_stride, tabs);
+            warp_tile_direct<false, PROJ, false, 1, WA_NG>(T, f, 1, tx, ty, views, n_views, src, srows, scols, none, nullptr, 0, g0, g0_stride, tabs);
             __builtin_amdgcn_s_waitcnt(0x0F70);               // the staging copy of the next tile has landed
         } else {
             const int v = T.view;
@@ -554,15 +555,15 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
             const uint8_t *lb = lds + buf * WA_BUF_BYTES;
             const unsigned pitch = 16u * (unsigned)warp_lds_np(T.sw);
             const unsigned a0 = (unsigned)(((uintptr_t)sp + (size_t)T.sy0 * sstep + 3u * (unsigned)T.sx0) & 15u), astep = sstep & 15u;
-            int ys[WARP_NG];
-            bool active[WARP_NG];
+            int ys[WA_NG];
+            bool active[WA_NG];
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g) { ys[g] = T.y0 + ty + g * WARP_BY; active[g] = x < V.pw && ys[g] < V.ph; }
-            float xc[WARP_NG][4], yc[WARP_NG][4];
-            Px2 r1[WARP_NG][4], r2[WARP_NG][4];
+            for (int g = 0; g < WA_NG; ++g) { ys[g] = T.y0 + ty + g * WA_BY; active[g] = x < V.pw && ys[g] < V.ph; }
+            float xc[WA_NG][4], yc[WA_NG][4];
+            Px2 r1[WA_NG][4], r2[WA_NG][4];
             bool slow = false;
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g)
+            for (int g = 0; g < WA_NG; ++g)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (active[g]) warp_combine(PROJ, ct[k], rt[g], V.wp, xc[g][k], yc[g][k]);
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
                 }
             if (__builtin_amdgcn_ballot_w64(slow)) {            // a tap outside the image somewhere in the wave: those samples re-read from global memory
 #pragma unroll
-                for (int g = 0; g < WARP_NG; ++g)
+                for (int g = 0; g < WA_NG; ++g)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const Taps tt = make_taps(xc[g][k], yc[g][k], srows, scols);
@@ -593,9 +594,9 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
             }
             const LevelDesc &L = V.lv[0];
             const size_t plane = (size_t)L.h * L.pitch;
-            unsigned packed[WARP_NG][3];
+            unsigned packed[WA_NG][3];
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g) {
+            for (int g = 0; g < WA_NG; ++g) {
                 packed[g][0] = packed[g][1] = packed[g][2] = 0u;
 #pragma unroll
                 for (int k = 0; k < 4; k += 2) {
@@ -614,7 +615,7 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
             // in flight across the next iteration.
             __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-            for (int g = 0; g < WARP_NG; ++g)
+            for (int g = 0; g < WA_NG; ++g)
                 if (active[g]) {
                     uint8_t *d = g0 + (size_t)f * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
                     *reinterpret_cast<unsigned *>(d) = packed[g][0];
@@ -627,7 +628,7 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
 #pragma unroll
         for (int k = 0; k < 4; ++k) ct[k] = ctn[k];
 #pragma unroll
-        for (int g = 0; g < WARP_NG; ++g) rt[g] = rtn[g];
+        for (int g = 0; g < WA_NG; ++g) rt[g] = rtn[g];
     }
 }
 
