@@ -132,6 +132,16 @@ MS_API int ms_add_src_weight_32f(const ms_image *src, const ms_image *src_weight
 MS_API int ms_normalize_using_weight_32f(const ms_image *weight, ms_image *src, int width, int height,
                                          ms_stream stream);
 
+/* The fixed-point flavour of the same two launchers -- MultiBandBlender(weight_type = CV_16S): weights 0..256 (8 fractional bits, blenders.cpp:414-418).
+ * device::blend::addSrcWeightGpu16S / normalizeUsingWeightMapGpu16S  blenders.cpp:52-53,56-57 -> cuda/multiband_blend.cu:10-34, 62-83:
+ * dst += short((src * w) >> 8), dst_weight += w;  src = short((src << 8) / w).  The app never selects this flavour (weight_type_ stays CV_32F,
+ * blenders.hpp:129); provided per-op for completeness of the blender's launcher surface.  A zero weight in the normalise step is an integer division
+ * by zero in the reference (undefined); here the result is 0. */
+MS_API int ms_add_src_weight_16s(const ms_image *src, const ms_image *src_weight, ms_image *dst,
+                                 ms_image *dst_weight, int rc_width, int rc_height, ms_stream stream);
+MS_API int ms_normalize_using_weight_16s(const ms_image *weight, ms_image *src, int width, int height,
+                                         ms_stream stream);
+
 /* cuda::compare(src32F, eps, dst8U, CMP_GT) / cuda::compare(src8U, 0, dst8U, CMP_EQ)
  * OCV/cudaarithm/src/element_operations.cpp:292 -> cuda/cmp_scalar.cu:59-82 (blenders.cpp:803,808). */
 MS_API int ms_compare_gt_32f(const ms_image *src, float thr, ms_image *dst, ms_stream stream);

@@ -107,6 +107,10 @@ void orc_add_src_weight_32f(const int16_t *src, size_t sstep, const float *w, si
                             int rows, int cols);
 /* K10 normalizeUsingWeightMapGpu32F. */
 void orc_normalize_32f(const float *w, size_t wstep, int16_t *src, size_t sstep, int rows, int cols);
+/* the CV_16S-weight flavour of the two (multiband_blend.cu:10-34, 62-83) */
+void orc_add_src_weight_16s(const int16_t *src, size_t sstep, const int16_t *w, size_t wstep,
+                            int16_t *dst, size_t dstep, int16_t *dst_w, size_t dwstep, int rows, int cols);
+void orc_normalize_16s(const int16_t *w, size_t wstep, int16_t *src, size_t sstep, int rows, int cols);
 /* K12 compare(w > eps) -> 255/0 ; K12b compare(m == 0) -> 255/0. */
 void orc_compare_gt_32f(const float *src, size_t sstep, float thr, uint8_t *dst, size_t dstep, int rows, int cols);
 void orc_compare_eq_8u(const uint8_t *src, size_t sstep, uint8_t val, uint8_t *dst, size_t dstep, int rows, int cols);

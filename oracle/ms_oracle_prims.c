@@ -558,6 +558,38 @@ void orc_add_src_weight_32f(const int16_t *src, size_t sstep, const float *w, si
     }
 }
 
+/* K9': addSrcWeightKernel16S  OCV/stitching/src/cuda/multiband_blend.cu:10-24 (weight_type CV_16S: weights 0..256).  int promotion, arithmetic shift,
+ * short(...) = low 16 bits, `+=` on short wraps. */
+void orc_add_src_weight_16s(const int16_t *src, size_t sstep, const int16_t *w, size_t wstep,
+                            int16_t *dst, size_t dstep, int16_t *dst_w, size_t dwstep, int rows, int cols)
+{
+    for (int y = 0; y < rows; ++y) {
+        const int16_t *s = CROWP(int16_t, src, sstep, y), *pw = CROWP(int16_t, w, wstep, y);
+        int16_t *d = ROWP(int16_t, dst, dstep, y), *dw = ROWP(int16_t, dst_w, dwstep, y);
+        for (int x = 0; x < cols; ++x) {
+            const int ww = pw[x];
+            for (int c = 0; c < 3; ++c) {
+                const int prod = (int)s[3 * x + c] * ww;
+                const int sh = prod >= 0 ? prod >> 8 : -((-prod + 255) >> 8);          /* arithmetic shift = floor division by 256, spelled portably */
+                d[3 * x + c] = (int16_t)(uint16_t)((unsigned)d[3 * x + c] + (unsigned)sh);
+            }
+            dw[x] = (int16_t)(uint16_t)((unsigned)dw[x] + (unsigned)ww);
+        }
+    }
+}
+/* K10': normalizeUsingWeightKernel16S  multiband_blend.cu:62-74: short((v << 8) / w), C division (toward zero).  w == 0 is a division by zero in the
+ * reference (undefined on the device); convention here and in the product: 0. */
+void orc_normalize_16s(const int16_t *w, size_t wstep, int16_t *src, size_t sstep, int rows, int cols)
+{
+    for (int y = 0; y < rows; ++y) {
+        const int16_t *pw = CROWP(int16_t, w, wstep, y);
+        int16_t *s = ROWP(int16_t, src, sstep, y);
+        for (int x = 0; x < cols; ++x)
+            for (int c = 0; c < 3; ++c)
+                s[3 * x + c] = pw[x] ? (int16_t)(uint16_t)(unsigned)(((int)s[3 * x + c] * 256) / (int)pw[x]) : (int16_t)0;
+    }
+}
+
 /* K10: normalizeUsingWeightKernel32F  multiband_blend.cu:85-100 */
 void orc_normalize_32f(const float *w, size_t wstep, int16_t *src, size_t sstep, int rows, int cols)
 {

@@ -228,6 +228,14 @@ def add_src_weight_32f(src, w, dst, dst_w):
                                  dst.shape[0], dst.shape[1])
 
 
+def add_src_weight_16s(src, w, dst, dst_w):
+    lib().orc_add_src_weight_16s(_p(src), _st(src), _p(w), _st(w), _p(dst), _st(dst), _p(dst_w), _st(dst_w), src.shape[0], src.shape[1])
+
+
+def normalize_16s(w, src):
+    lib().orc_normalize_16s(_p(w), _st(w), _p(src), _st(src), src.shape[0], src.shape[1])
+
+
 def normalize_32f(w, src):
     lib().orc_normalize_32f(_p(w), _st(w), _p(src), _st(src), src.shape[0], src.shape[1])
 

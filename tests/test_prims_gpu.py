@@ -156,6 +156,38 @@ def test_add_src_weight_and_normalize(ms, cuda, oracle):
     assert np.array_equal(host(d_dst), dst)
 
 
+def test_add_src_weight_and_normalize_16s_weights(ms, cuda, oracle):
+    """MultiBandBlender(weight_type = CV_16S): the fixed-point launchers (multiband_blend.cu:10-34, 62-83) -- (v * w) >> 8 with an arithmetic shift for negative
+    Laplacians, wrapping short accumulation, truncating (v << 8) / w, zero weights.  Also the blender's own use: weights 0 / 256 through a 16SC1 pyrDown."""
+    rng = rng_for("asw16")
+    src = rng.integers(-600, 600, size=(64, 96, 3), dtype=np.int16)
+    w = rng.integers(0, 257, size=(64, 96), dtype=np.int16)
+    w[rng.random(w.shape) < 0.2] = 0
+    dst = rng.integers(-32768, 32768, size=(128, 160, 3), dtype=np.int16)
+    dw = rng.integers(0, 2000, size=(128, 160), dtype=np.int16)
+    d_dst, d_dw = to_dev(dst), to_dev(dw)
+    dst0, dw0 = dst.copy(), dw.copy()
+    ms.add_src_weight_16s(to_dev(src), to_dev(w), d_dst[32:96, 16:112], d_dw[32:96, 16:112])
+    oracle.add_src_weight_16s(src, w, dst[32:96, 16:112], dw[32:96, 16:112])
+    assert np.array_equal(host(d_dst), dst) and np.array_equal(host(d_dw), dw)
+    # independent statement of the accumulate: floor division by 256 (arithmetic shift), int16 wrap-around
+    term = ((np.int64(src) * np.int64(w)[..., None]) // 256).astype(np.int16)
+    assert np.array_equal(dst[32:96, 16:112], (np.int64(dst0[32:96, 16:112]) + np.int64(term)).astype(np.int16))
+    assert np.array_equal(dw[32:96, 16:112], (np.int64(dw0[32:96, 16:112]) + np.int64(w)).astype(np.int16))
+    dw[::7, ::5] = 0
+    d_dw = to_dev(dw)
+    ms.normalize_using_weight_16s(d_dw, d_dst)
+    before = dst.copy()
+    oracle.normalize_16s(dw, dst)
+    assert np.array_equal(host(d_dst), dst)
+    nz = dw != 0
+    q = np.trunc(np.float64(before) * 256.0 / np.where(nz, dw, 1)[..., None]).astype(np.int64).astype(np.int16)      # C division truncates toward zero
+    assert np.array_equal(dst[nz], q[nz]) and not dst[~nz].any()
+    # the blender's weight maps in this flavour: mask 0 / 255 -> 16S, + 1 where set (= 256), 16SC1 pyrDown (blenders.cpp:414-423)
+    mask = (rng.random((40, 56)) < 0.6).astype(np.int16) * 256
+    assert np.array_equal(host(ms.pyr_down(to_dev(mask))), oracle.pyr_down_16s(mask))
+
+
 def test_mask_ops(ms, cuda, oracle):
     rng = rng_for("mask")
     w = rng.random((40, 77), dtype=np.float32) * 2e-5

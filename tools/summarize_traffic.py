@@ -62,13 +62,15 @@ def main(out, tag, cfg, frames):
             alias["k_blend_l0"] = v
         if k.startswith("k_stage1_t"):
             alias["k_remap_gain"] = v          # bench.py's name of the first CPW remap (timed.cpp:90-94)
+        if k.startswith("k_resize_linear3"):
+            alias["k_resize_batch"] = v        # bench.py's name of the per-frame cuda::resize launch (shipped configuration)
         if k.startswith("k_warp_t<true"):
             alias["k_warp"] = v                # CPW contexts: the level-0 kernel is the mesh remap of the stage image
         if k.startswith("k_down_t<unsigned char>") or k.startswith("k_down_t<true>"):
             alias["k_down_l0"] = v
     res["kernels"].update(alias)
     # HBM bytes of one ms_stitch call (all per-frame kernels): what bench.py's frame_roofline.frac_traffic divides by the GPU time
-    per_frame = ("k_warp_t", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
+    per_frame = ("k_resize_linear3", "k_warp_t", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
                  "k_blend<", "k_blend_top", "k_single_band")
     steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t", "k_warp_a", "k_warp<"))] or [1])
     res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()

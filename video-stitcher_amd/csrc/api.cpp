@@ -181,6 +181,23 @@ int ms_normalize_using_weight_32f(const ms_image *w, ms_image *src, int width, i
     return launch_normalize(*w, *src, width, height, as_stream(s));
 }
 
+int ms_add_src_weight_16s(const ms_image *src, const ms_image *w, ms_image *dst, ms_image *dstw, int rcw, int rch, ms_stream s)
+{
+    PRE() IMG(src, "ms_add_src_weight_16s src") IMG(w, "ms_add_src_weight_16s weight") IMG(dst, "ms_add_src_weight_16s dst") IMG(dstw, "ms_add_src_weight_16s dst_weight")
+    MS_CHECK(src->type == MS_16SC3 && dst->type == MS_16SC3 && w->type == MS_16SC1 && dstw->type == MS_16SC1, "ms_add_src_weight_16s: 16SC3 / 16SC1 required");
+    MS_CHECK(rcw > 0 && rch > 0 && rcw <= src->cols && rch <= src->rows && rcw <= w->cols && rch <= w->rows &&
+             rcw <= dst->cols && rch <= dst->rows && rcw <= dstw->cols && rch <= dstw->rows, "ms_add_src_weight_16s: rect exceeds an operand");
+    return launch_add_src_weight_16s(*src, *w, *dst, *dstw, rcw, rch, as_stream(s));
+}
+
+int ms_normalize_using_weight_16s(const ms_image *w, ms_image *src, int width, int height, ms_stream s)
+{
+    PRE() IMG(w, "ms_normalize_using_weight_16s weight") IMG(src, "ms_normalize_using_weight_16s src")
+    MS_CHECK(src->type == MS_16SC3 && w->type == MS_16SC1, "ms_normalize_using_weight_16s: 16SC3 / 16SC1 required");
+    MS_CHECK(width > 0 && height > 0 && width <= src->cols && height <= src->rows && width <= w->cols && height <= w->rows, "ms_normalize_using_weight_16s: extent exceeds an operand");
+    return launch_normalize_16s(*w, *src, width, height, as_stream(s));
+}
+
 int ms_compare_gt_32f(const ms_image *src, float thr, ms_image *dst, ms_stream s)
 {
     PRE() IMG(src, "ms_compare_gt_32f src") IMG(dst, "ms_compare_gt_32f dst") SAME(src, dst, "ms_compare_gt_32f")

@@ -20,6 +20,8 @@ int launch_copy_make_border(const ms_image &src, ms_image &dst, int top, int lef
 int launch_pyr_down(const ms_image &src, ms_image &dst, hipStream_t st);
 int launch_pyr_up(const ms_image &src, ms_image &dst, hipStream_t st);
 int launch_add_src_weight(const ms_image &src, const ms_image &w, ms_image &dst, ms_image &dstw, int rcw, int rch, hipStream_t st);
+int launch_add_src_weight_16s(const ms_image &src, const ms_image &w, ms_image &dst, ms_image &dstw, int rcw, int rch, hipStream_t st);
+int launch_normalize_16s(const ms_image &w, ms_image &src, int width, int height, hipStream_t st);
 int launch_normalize(const ms_image &w, ms_image &src, int width, int height, hipStream_t st);
 int launch_zero_masked(ms_image &img, const ms_image &mask, hipStream_t st);
 int launch_dilate3(const ms_image &src, ms_image &dst, hipStream_t st);

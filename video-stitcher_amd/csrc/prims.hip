@@ -593,6 +593,44 @@ __global__ void __launch_bounds__(256) k_normalize(const float *__restrict__ w, 
     for (int c = 0; c < 3; ++c) s[c] = trunc_s16((float)s[c] / den);
 }
 
+// addSrcWeightKernel16S / normalizeUsingWeightKernel16S  [multiband_blend.cu:10-34, 62-83]: the fixed-point flavour of the blender (weight_type CV_16S:
+// weights are 0..256 = 8 fractional bits, blenders.cpp:414-418).  int arithmetic exactly as written there: (v * w) >> 8 is an arithmetic shift,
+// short(...) keeps the low 16 bits, `+=` on short wraps.  (v << 8) / w truncates toward zero; w == 0 (a pixel no view covers) is integer division by
+// zero, undefined in the reference -- defined here as 0 and stated in ms_stitch.h.
+__global__ void __launch_bounds__(256) k_add_src_weight_16s(const int16_t *__restrict__ src, size_t sstep, const int16_t *__restrict__ w, size_t wstep,
+                                                            int16_t *dst, size_t dstep, int16_t *dstw, size_t dwstep, int rows, int cols)
+{
+    XY_GUARD(cols, rows)
+    const int16_t *s = row_ptr<int16_t>(src, sstep, y) + 3 * x;
+    const int ww = row_ptr<int16_t>(w, wstep, y)[x];
+    int16_t *d = row_ptr<int16_t>(dst, dstep, y) + 3 * x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = (int16_t)(d[c] + (int16_t)(((int)s[c] * ww) >> 8));
+    int16_t *dw = row_ptr<int16_t>(dstw, dwstep, y) + x;
+    *dw = (int16_t)(*dw + ww);
+}
+__global__ void __launch_bounds__(256) k_normalize_16s(const int16_t *__restrict__ w, size_t wstep, int16_t *src, size_t sstep, int rows, int cols)
+{
+    XY_GUARD(cols, rows)
+    const int ww = row_ptr<int16_t>(w, wstep, y)[x];
+    int16_t *s = row_ptr<int16_t>(src, sstep, y) + 3 * x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s[c] = ww ? (int16_t)(((int)s[c] * 256) / ww) : (int16_t)0;
+}
+int launch_add_src_weight_16s(const ms_image &src, const ms_image &w, ms_image &dst, ms_image &dstw, int rcw, int rch, hipStream_t st)
+{
+    k_add_src_weight_16s<<<grid2d(rcw, rch), dim3(BX, BY), 0, st>>>((const int16_t *)src.data, src.step, (const int16_t *)w.data, w.step,
+                                                                    (int16_t *)dst.data, dst.step, (int16_t *)dstw.data, dstw.step, rch, rcw);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+int launch_normalize_16s(const ms_image &w, ms_image &src, int width, int height, hipStream_t st)
+{
+    k_normalize_16s<<<grid2d(width, height), dim3(BX, BY), 0, st>>>((const int16_t *)w.data, w.step, (int16_t *)src.data, src.step, height, width);
+    MS_LAUNCH_CHECK();
+    return MS_OK;
+}
+
 __global__ void __launch_bounds__(256) k_zero_masked(int16_t *img, size_t step, const uint8_t *__restrict__ mask, size_t mstep, int rows, int cols)
 {
     XY_GUARD(cols, rows)

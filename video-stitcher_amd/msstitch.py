@@ -85,7 +85,7 @@ class MeshInfo(C.Structure):
 EXPORTS = [
     "ms_last_error", "ms_version", "ms_device_count", "ms_remap", "ms_resize_linear", "ms_convert_scale_8u", "ms_convert",
     "ms_copy_make_border", "ms_pyr_down", "ms_pyr_up", "ms_subtract_16s", "ms_add_16s", "ms_add_src_weight_32f",
-    "ms_normalize_using_weight_32f", "ms_compare_gt_32f", "ms_compare_eq_8u", "ms_set_zero_masked_16sc3",
+    "ms_normalize_using_weight_32f", "ms_add_src_weight_16s", "ms_normalize_using_weight_16s", "ms_compare_gt_32f", "ms_compare_eq_8u", "ms_set_zero_masked_16sc3",
     "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
     "ms_calibrate_cameras", "ms_num_bands_rule", "ms_orb_default_params", "ms_orb_detect_and_compute", "ms_find_homography_ransac", "ms_feature_mask",
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
@@ -289,6 +289,16 @@ def add_src_weight_32f(src, weight, dst_roi, dst_weight_roi):
     """dst_roi / dst_weight_roi: views (tensor slices) of the pano level, i.e. dst(rc)."""
     _chk(load().ms_add_src_weight_32f(C.byref(img(src)), C.byref(img(weight)), C.byref(img(dst_roi)), C.byref(img(dst_weight_roi)),
                                       dst_roi.shape[1], dst_roi.shape[0], _stream()))
+
+
+def add_src_weight_16s(src, weight, dst_roi, dst_weight_roi):
+    """addSrcWeightGpu16S: 16SC3 src, 16SC1 fixed-point weights (0..256) accumulated into dst(rc) / dst_weight(rc)."""
+    _chk(load().ms_add_src_weight_16s(C.byref(img(src)), C.byref(img(weight)), C.byref(img(dst_roi)), C.byref(img(dst_weight_roi)),
+                                      src.shape[1], src.shape[0], _stream()))
+
+
+def normalize_using_weight_16s(weight, src):
+    _chk(load().ms_normalize_using_weight_16s(C.byref(img(weight)), C.byref(img(src)), src.shape[1], src.shape[0], _stream()))
 
 
 def normalize_using_weight_32f(weight, src):

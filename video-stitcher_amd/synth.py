@@ -1,4 +1,5 @@
-"""Synthetic rig, frames and CPW meshes of SURVEY.md 8(d) -- shared by tests/ and bench.py.
+"""BENCH / TEST SUPPORT, not part of the product (nothing in csrc/, host/ or shim/ depends on it; it sits next to msstitch.py only so that tests/
+and bench.py import it from one place): the synthetic rig, frames and CPW meshes of SURVEY.md 8(d).
 
 Pure numpy; produces host arrays.  No oracle and no GPU code in here.
 Rig model = the reference's calibrateCameras (APP/calibration.cpp:28-68): view i yaw = 2*pi*i/N about +y,
