@@ -4,9 +4,9 @@
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" = --passes (default 20) passes over a batch of F frames (F = --frames, default 48: 6 views x F frames, inputs already
-resident in HBM; 20 x 48 = 960 frames = 32 s of 30 fps video per step), each pass issued as --streams (default 3) ms_stitch calls of
-F/streams frames on separate HIP streams / contexts.  Weak scaling: every rank stitches its own F frames per step (frame-parallel,
+A "step" = --passes (default 20) passes over a batch of F frames (F = --frames, default 96: 6 views x F frames, inputs already
+resident in HBM; 20 x 96 = 1920 frames = 64 s of 30 fps video per step), each pass issued as --streams (default 3) ms_stitch calls of
+F/streams = 32 frames on separate HIP streams / contexts.  Weak scaling: every rank stitches its own F frames per step (frame-parallel,
 round-robin ownership); with N>1 the finished pano slabs are gathered on rank 0 over RCCL, overlapped with
 the next step.  value = N*F*K / max-over-ranks wall time.
 
@@ -464,7 +464,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gather-every", type=int, default=1, help="N>1: the main timed region gathers the slabs of every k-th pass (default 1: EVERY frame of every rank reaches "
                     "the sink inside the timed region -- the conservative `value`; `value_live_rate_gather` and `value_no_gather` are measured beside it)")
-    ap.add_argument("--frames", type=int, default=None, help="frames per step, split evenly over --streams contexts (default 48 = 3 x 16; cfg3: 16 on one context; cfg5: 24; 1 = live mode)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per pass, split evenly over --streams contexts (default 96 = 3 x 32; cfg3 / shipped: 32 on one context; cfg5: 48 = 3 x 16; 1 = live mode)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5", "shipped"],
                     help="cfg2 / cfg3 / cfg5 = BASELINE configs[1] / [2] / [4] geometry; shipped = the configuration the reference ships (defs.h:25-27,51-55,65-66, "
                          "calibration.cpp:100,147-194): cylindrical warper, COMPOSE_MEGAPIX 1.4 (every frame through cuda::resize INSIDE the timed region), "
@@ -486,6 +486,7 @@ def main():
     ap.add_argument("--recalib-every", type=int, default=60,
                     help="cfg3 only: re-expand new CPW meshes (ms_set_mesh x views) every this many frames, inside the timed region "
                          "(BASELINE configs[2]: recalibrate every 60 f); 0 = never")
+    ap.add_argument("--independent-streams", action="store_true", help="do not fork-join the streams around every pass (A/B: 1 % slower than the joined default)")
     ap.add_argument("--streams", type=int, default=None,
                     help="contexts / HIP streams a step's frames are split over (default 3 x 16 frames: the small coarse-level kernels of one "
                          "batch overlap the large kernels of another: +13 % over one stream)")
@@ -498,8 +499,8 @@ def main():
         args.passes = 1 if (args.calib or args.view_shards > 1 or args.col_shards > 1) else 20
     if args.streams is None:        # cfg3 / shipped re-expand the CPW meshes on every context: one context there, three elsewhere
         args.streams = 1 if args.config in ("cfg3", "shipped") else 3
-    if args.frames is None:
-        args.frames = {"cfg5": 8}.get(args.config, 16) * args.streams
+    if args.frames is None:      # 32 frames per ms_stitch call (the ABI's per-call limit; cfg5: 16): +2 % (cfg2) to +15 % (cfg3, shipped) over 16 (8), profiles/r03_batch_sweep.txt
+        args.frames = {"cfg5": 16}.get(args.config, 32) * args.streams
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -642,17 +643,24 @@ def main():
     egress_done = [torch.cuda.Event(), torch.cuda.Event()] if to_i420 else None
     egress_used = [False, False]
 
+    # The S contexts are independent pipelines (own tables, own per-frame buffers, own output slots), so the passes need not be fork-joined on the caller's
+    # stream.  Measured (profiles/r03_batch_sweep.txt): keeping the join is 1 % FASTER (34.24 k against 33.89 k frames/s, three alternating runs each) -- the
+    # contexts stay in step and share the tables in L2 --, so the join stays the default; --independent-streams is the A/B.  An egress needs the join anyway.
+    join_passes = (not args.independent_streams) or egress
+
     def make_run(b):
         def run():
             if S > 1:
                 cur = torch.cuda.current_stream()
                 for k in range(S):
-                    streams[k].wait_stream(cur)
+                    if join_passes:
+                        streams[k].wait_stream(cur)
                     if resize_runs:
                         resize_runs[k](handles[k])
                     subruns[b][k](handles[k])
-                for k in range(S):
-                    cur.wait_stream(streams[k])
+                if join_passes:
+                    for k in range(S):
+                        cur.wait_stream(streams[k])
             else:
                 if resize_runs:
                     resize_runs[0](handles[0])

@@ -109,6 +109,13 @@ __device__ __forceinline__ void blend_taps(const Taps &t, const Px2 &r1, const P
         out[c] = o;
     }
 }
+// gain * x for two values at once: fma(gain, x, 0) per half, exactly the scalar __builtin_fmaf(gain, x, 0.f)
+__device__ __forceinline__ f32x2 gain_pair(float gain, float a, float b)
+{
+    f32x2 g, x, z = {0.f, 0.f};
+    g.x = gain; g.y = gain; x.x = a; x.y = b;
+    return __builtin_elementwise_fma(g, x, z);
+}
 // two samples at once: the same four fmas per channel, issued as v_pk_fma_f32 (two fp32 lanes per instruction)
 __device__ __forceinline__ void blend_taps2(const Taps ta, const Taps tb, const Px2 r1a, const Px2 r2a, const Px2 r1b, const Px2 r2b,
                                             float oa[3], float ob[3])
@@ -397,11 +404,16 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
                 }
                 blend_taps2(t[0], t[1], r1[lb][k], r2[lb][k], r1[lb][k + 1], r2[lb][k + 1], o[0], o[1]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        packed[c] = CPW ? sat_u8_into(o[j][c], k + j, packed[c])
-                                        : sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), k + j, packed[c]);
+                for (int c = 0; c < 3; ++c) {
+                    if (CPW) {
+                        packed[c] = sat_u8_into(o[0][c], k, packed[c]);
+                        packed[c] = sat_u8_into(o[1][c], k + 1, packed[c]);
+                    } else {      // convertTo(gain) of the rounded remap result (timed.cpp:94), both pixels of the pair in one v_pk_fma_f32 (fma(gain, x, 0) per half)
+                        const f32x2 r = gain_pair(V.gain, (float)sat_u8(o[0][c]), (float)sat_u8(o[1][c]));
+                        packed[c] = sat_u8_into(r.x, k, packed[c]);
+                        packed[c] = sat_u8_into(r.y, k + 1, packed[c]);
+                    }
+                }
             }
             uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)ys[g] * L.pitch + x;
 #if defined(MS_PROBE) && MS_PROBE == 9       // no-store probe: the stores (almost) never execute
@@ -718,12 +730,12 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, c
             }
             blend_taps2(t[0], t[1], r1[b][k], r2[b][k], r1[b][k + 1], r2[b][k + 1], o[0], o[1]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int i = 3 * (k + j) + c;          // byte i of the 12 interleaved output bytes
-                    w[i >> 2] = sat_u8_into(__builtin_fmaf(V.gain, (float)sat_u8(o[j][c]), 0.f), i & 3, w[i >> 2]);
-                }
+            for (int c = 0; c < 3; ++c) {
+                const f32x2 r = gain_pair(V.gain, (float)sat_u8(o[0][c]), (float)sat_u8(o[1][c]));
+                const int i0 = 3 * k + c, i1 = 3 * (k + 1) + c;          // bytes of the 12 interleaved output bytes
+                w[i0 >> 2] = sat_u8_into(r.x, i0 & 3, w[i0 >> 2]);
+                w[i1 >> 2] = sat_u8_into(r.y, i1 & 3, w[i1 >> 2]);
+            }
         }
         uint8_t *d = stage + (size_t)(f0 + fi) * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
         if (x + 3 < V.aw) __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
