@@ -14,9 +14,12 @@ Observed on MI355X (profiles/r03_from_inputs.txt; MS_FROM_INPUTS_LOG=<file> appe
   shipped rig at 480 x 270 (cylindrical, 4 bands)         max |diff| 2 on 4 px, 1 on 419 of 390 k; gains equal to 4 digits
   shipped rig at 1080p (1578 x 887 compose, 6 bands)      max |diff| 3 on 1 px, 2 on 58, 1 on 3 960 of 4.2 M; gains equal to 4 digits
 """
+import os
+
 import numpy as np
 import pytest
 import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
 from scipy import ndimage
 
 import synth
@@ -57,7 +60,7 @@ def oracle_from_inputs(O, proj, Ks, Rs, scale, w, h, frames, gains, num_bands, m
     return rois, maps, masks, out, mask
 
 
-def compare(name, got16, got_mask, ref16, ref_mask, view_mask_diffs, halo, extra=None):
+def compare(name, got16, got_mask, ref16, ref_mask, view_mask_diffs, halo, extra=None, max_excluded=0.02):
     """the statistics + the reference's own criterion"""
     assert got16.shape == ref16.shape and got_mask.shape == ref_mask.shape
     mask_diff = got_mask != ref_mask
@@ -76,7 +79,7 @@ def compare(name, got16, got_mask, ref16, ref_mask, view_mask_diffs, halo, extra
     record(name, stats)
     assert stats["max_diff_far"] <= 3, stats                                        # test_blenders.cuda.cpp:90
     assert stats["result_mask_diff_px"] <= 2e-4 * common.size, stats                # masks equal except a few border / seam pixels
-    assert stats["excluded_px"] <= 0.02 * common.size, stats
+    assert stats["excluded_px"] <= max_excluded * common.size, stats
     assert stats["exact_fraction"] > 0.9, stats                                     # and the overwhelming majority is bit-equal anyway
     return stats
 
@@ -119,6 +122,36 @@ def test_spherical_rig_from_camera_parameters(ms, cuda, oracle, rig):
     assert worst < (1e-3 if w <= 640 else 2.5e-3), worst
     vdiff = view_mask_diff_in_pano(rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
     compare(rig + "_spherical", host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb, extra={"max_map_diff_px": worst})
+    comp.close()
+
+
+@settings(max_examples=int(os.environ.get("MS_TEST_EXAMPLES_FROM_INPUTS", 8)), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(n=st.integers(3, 6), w=st.integers(160, 480), h=st.integers(120, 320), spread=st.floats(1.3, 1.8), out_w=st.sampled_from([768, 1024, 1536]),
+       bands=st.integers(2, 5), cyl=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_random_rigs_from_camera_parameters(ms, cuda, oracle, n, w, h, spread, out_w, bands, cyl, seed):
+    """The same comparison on random rigs (views, sizes, field of view, bands, spherical / cylindrical): here a border or seam pixel of a mask MAY flip (the
+    device's sinf / cosf against glibc's), so the criterion is the general one -- |diff| <= 3 outside the blend support of the pixels whose masks differ,
+    few such pixels, the overwhelming majority bit-equal."""
+    hfov = min(130.0, 360.0 / n * spread)
+    proj = ms.PROJ_CYLINDRICAL if cyl else ms.PROJ_SPHERICAL
+    scale = synth.warp_scale(out_w)
+    rng = np.random.default_rng(seed)
+    cams = [synth.camera(n, w, h, hfov, i) for i in range(n)]
+    gains = [float(g) for g in rng.uniform(0.92, 1.08, n)]
+    frames = [synth.frame(w, h, i, int(seed % 7)) for i in range(n)]
+    comp = ms.Compositor(n, (w, h), proj, scale, num_bands=bands, out_size=(0, 0))
+    for i in range(n):
+        comp.set_camera(i, *cams[i]); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    rois, maps, masks, ref16, ref_mask = oracle_from_inputs(oracle, proj, [c[0] for c in cams], [c[1] for c in cams], scale, w, h, frames, gains, pg.num_bands)
+    assert rois == [comp.view_geom(i).roi.tuple() for i in range(n)]
+    vdiff = view_mask_diff_in_pano(rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
+    compare("random_%s_n%d_%dx%d_b%d_seed%d" % ("cyl" if cyl else "sph", n, w, h, pg.num_bands, seed), host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff,
+            halo=3 * 2 ** pg.num_bands, max_excluded=0.6)      # (one flipped border pixel excludes its whole blend support: up to a 193 x 193 window at 5 bands)
     comp.close()
 
 

@@ -165,11 +165,21 @@ void rank_main(const Options &o, int rank, Shared &sh)
     auto black = [&](unsigned char *p) {
         for (int f = 0; f < F; ++f) { HIPC(hipMemsetAsync(p + f * frame_bytes, 16, y_bytes, st)); HIPC(hipMemsetAsync(p + f * frame_bytes + y_bytes, 128, y_bytes / 2, st)); }
     };
-    unsigned char *mine = nullptr;
-    HIPC(hipMalloc((void **)&mine, slab_bytes));
-    black(mine);
-    std::vector<unsigned char *> from_group(groups, nullptr);       // sink: slabs of the other groups' leaders
-    if (rank == 0) for (int g = 1; g < groups; ++g) HIPC(hipMalloc((void **)&from_group[g], slab_bytes));
+    // double-buffered: the slabs of batch k travel to the sink on a stream of their own while batch k + 1 is stitched
+    unsigned char *mine2[2] = {nullptr, nullptr};
+    std::vector<unsigned char *> from_group2[2];                    // sink: slabs of the other groups' leaders
+    hipStream_t cs;
+    HIPC(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipEvent_t stitched[2], sent[2];
+    bool sent_used[2] = {false, false};
+    for (int b = 0; b < 2; ++b) {
+        HIPC(hipMalloc((void **)&mine2[b], slab_bytes));
+        black(mine2[b]);
+        from_group2[b].assign(groups, nullptr);
+        if (rank == 0) for (int g = 1; g < groups; ++g) HIPC(hipMalloc((void **)&from_group2[b][g], slab_bytes));
+        HIPC(hipEventCreateWithFlags(&stitched[b], hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&sent[b], hipEventDisableTiming));
+    }
     // column windows of every shard (a pure function of the panorama width: ms_get_col_window documents the rule)
     const int fw = pg.dst_roi_final.width;
     auto bound = [&](int i) { return i <= 0 ? 0 : (i >= S ? fw : (int)((long long)i * fw / S) / 16 * 16); };
@@ -250,6 +260,10 @@ void rank_main(const Options &o, int rank, Shared &sh)
             if (have) { if (have_pending) throw Fail("a second mesh update arrived before the first was applied"); have_pending = true; }
         }
         // 3. this group's F frames of the batch: t = first + j * groups + group
+        const int b = (int)(k & 1);
+        unsigned char *mine = mine2[b];
+        std::vector<unsigned char *> &from_group = from_group2[b];
+        if (sent_used[b]) HIPC(hipStreamWaitEvent(st, sent[b], 0));      // the slab this buffer held two batches ago has left
         std::vector<ms_image> views((size_t)F * N), outs(F);
         for (int j = 0; j < F; ++j) {
             const long long t = first + (long long)j * groups + group;
@@ -272,27 +286,35 @@ void rank_main(const Options &o, int rank, Shared &sh)
                 for (int s2 = 1; s2 < S; ++s2) move_window(mine, from_shard[s2], bound(s2), bound(s2 + 1), false);
             }
         }
-        // 5. frame-parallel gather: the leaders' slabs to the sink (rank 0)
-        if (groups > 1) {
+        // 5. frame-parallel gather: the leaders' slabs to the sink (rank 0), on the communication stream behind this batch's kernels
+        HIPC(hipEventRecord(stitched[b], st));
+        if (groups > 1 && (rank == 0 || rank == leader)) {
+            HIPC(hipStreamWaitEvent(cs, stitched[b], 0));
             if (rank == 0) {
                 MSC(ms_dist_group_begin(dist));
-                for (int g = 1; g < groups; ++g) MSC(ms_dist_recv(dist, from_group[g], slab_bytes, g * S, MS_DIST_MEM_DEVICE, st));
+                for (int g = 1; g < groups; ++g) MSC(ms_dist_recv(dist, from_group[g], slab_bytes, g * S, MS_DIST_MEM_DEVICE, cs));
                 MSC(ms_dist_group_end(dist));
-            } else if (rank == leader)
-                MSC(ms_dist_send(dist, mine, slab_bytes, 0, MS_DIST_MEM_DEVICE, st));
+            } else
+                MSC(ms_dist_send(dist, mine, slab_bytes, 0, MS_DIST_MEM_DEVICE, cs));
+            HIPC(hipEventRecord(sent[b], cs));
+            sent_used[b] = true;
         }
         // 6. consume() on the sink: the frames of the batch in display order
-        if (rank == 0 && o.checksum)
+        if (rank == 0 && o.checksum) {
+            HIPC(hipStreamSynchronize(st));
+            HIPC(hipStreamSynchronize(cs));
             for (int j = 0; j < F; ++j)
                 for (int g = 0; g < groups; ++g) {
                     if (first + (long long)j * groups + g >= o.frames) continue;
                     const unsigned char *p = (g == 0 ? mine : from_group[g]) + j * frame_bytes;
-                    HIPC(hipMemcpyAsync(host_frame.data(), p, frame_bytes, hipMemcpyDeviceToHost, st));
-                    HIPC(hipStreamSynchronize(st));
+                    HIPC(hipMemcpyAsync(host_frame.data(), p, frame_bytes, hipMemcpyDeviceToHost, cs));
+                    HIPC(hipStreamSynchronize(cs));
                     sums.push_back(fnv(host_frame.data(), frame_bytes));
                 }
+        }
     }
     HIPC(hipStreamSynchronize(st));
+    HIPC(hipStreamSynchronize(cs));
     MSC(ms_dist_barrier(dist, st));
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     running.store(false);
@@ -305,9 +327,13 @@ void rank_main(const Options &o, int rank, Shared &sh)
     ms_dist_destroy(dist);
     ms_destroy(ctx);
     for (unsigned char *p : src) if (p) (void)hipFree(p);
-    for (unsigned char *p : from_group) if (p) (void)hipFree(p);
+    for (int b = 0; b < 2; ++b) {
+        for (unsigned char *p : from_group2[b]) if (p) (void)hipFree(p);
+        (void)hipFree(mine2[b]);
+        (void)hipEventDestroy(stitched[b]); (void)hipEventDestroy(sent[b]);
+    }
     for (unsigned char *p : from_shard) if (p) (void)hipFree(p);
-    (void)hipFree(mine);
+    (void)hipStreamDestroy(cs);
     (void)hipStreamDestroy(st);
 }
 
