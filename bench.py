@@ -490,6 +490,7 @@ def main():
     ap.add_argument("--recalib-every", type=int, default=60,
                     help="cfg3 only: re-expand new CPW meshes (ms_set_mesh x views) every this many frames, inside the timed region "
                          "(BASELINE configs[2]: recalibrate every 60 f); 0 = never")
+    ap.add_argument("--join-every", type=int, default=1, help="fork-join the streams around groups of this many passes (1 = every pass)")
     ap.add_argument("--independent-streams", action="store_true", help="do not fork-join the streams around every pass (A/B: 1 % slower than the joined default)")
     ap.add_argument("--streams", type=int, default=None,
                     help="contexts / HIP streams a step's frames are split over (default 3 x 16 frames: the small coarse-level kernels of one "
@@ -651,18 +652,23 @@ def main():
     # stream.  Measured (profiles/r03_batch_sweep.txt): keeping the join is 1 % FASTER (34.24 k against 33.89 k frames/s, three alternating runs each) -- the
     # contexts stay in step and share the tables in L2 --, so the join stays the default; --independent-streams is the A/B.  An egress needs the join anyway.
     join_passes = (not args.independent_streams) or egress
+    join_every = 1 if egress else max(1, args.join_every)      # fork at the first pass of a group of `join_every`, join after its last one
+    join_state = {"n": 0}
 
     def make_run(b):
         def run():
             if S > 1:
                 cur = torch.cuda.current_stream()
+                first_of_group = join_state["n"] % join_every == 0
+                join_state["n"] += 1
+                last_of_group = join_state["n"] % join_every == 0
                 for k in range(S):
-                    if join_passes:
+                    if join_passes and first_of_group:
                         streams[k].wait_stream(cur)
                     if resize_runs:
                         resize_runs[k](handles[k])
                     subruns[b][k](handles[k])
-                if join_passes:
+                if join_passes and last_of_group:
                     for k in range(S):
                         cur.wait_stream(streams[k])
             else:
