@@ -124,6 +124,7 @@ struct Op {                 // one point-to-point transfer of a group
     size_t bytes, done = 0;
     int peer, mem;
     hipStream_t st;
+    bool finished = false;  // every byte moved (an empty message: its one empty piece moved)
 };
 
 }  // namespace
@@ -150,12 +151,14 @@ namespace {
 
 int copy_in(void *dst_host, const void *src, size_t n, int mem)      // user buffer -> mailbox slot
 {
+    if (n == 0) return MS_OK;
     if (mem == MS_DIST_MEM_HOST) memcpy(dst_host, src, n);
     else MS_HIP(hipMemcpy(dst_host, src, n, hipMemcpyDeviceToHost));
     return MS_OK;
 }
 int copy_out(void *dst, const void *src_host, size_t n, int mem)     // mailbox slot -> user buffer
 {
+    if (n == 0) return MS_OK;
     if (mem == MS_DIST_MEM_HOST) memcpy(dst, src_host, n);
     else MS_HIP(hipMemcpy(dst, src_host, n, hipMemcpyHostToDevice));
     return MS_OK;
@@ -165,7 +168,7 @@ int copy_out(void *dst, const void *src_host, size_t n, int mem)     // mailbox 
 int host_step(ms_dist *d, Op &op, bool *moved)
 {
     *moved = false;
-    if (op.done == op.bytes && op.bytes != 0) return MS_OK;
+    if (op.finished) return MS_OK;
     Channel *c = op.send ? d->chan(d->rank, op.peer) : d->chan(op.peer, d->rank);
     const unsigned long long h = c->head.load(std::memory_order_acquire), t = c->tail.load(std::memory_order_acquire);
     if (op.send) {
@@ -184,7 +187,7 @@ int host_step(ms_dist *d, Op &op, bool *moved)
         op.done += n;
     }
     *moved = true;
-    if (op.bytes == 0) op.done = 0, op.bytes = (size_t)-1, op.done = op.bytes;      // zero-byte message: one empty piece, now complete
+    op.finished = op.done == op.bytes;          // (an empty message is one empty piece)
     return MS_OK;
 }
 
@@ -196,11 +199,11 @@ int host_run(ms_dist *d, std::vector<Op> &ops)
     for (;;) {
         bool all = true, any = false;
         for (Op &op : ops) {
-            if (op.done == op.bytes && !(op.bytes == 0)) continue;
+            if (op.finished) continue;
             bool moved = false;
             if (int e = host_step(d, op, &moved)) return e;
             any |= moved;
-            all &= (op.done == op.bytes);
+            all &= op.finished;
         }
         if (all) return MS_OK;
         if (any) { bo = Backoff(); continue; }
@@ -442,18 +445,22 @@ int ms_dist_group_end(ms_dist *d)
     std::vector<Op> ops;
     ops.swap(d->ops);
     for (size_t i = 0; i < ops.size(); ++i) {
-        if (ops[i].peer != d->rank || !ops[i].send || ops[i].done == ops[i].bytes) continue;
+        if (ops[i].peer != d->rank || !ops[i].send || ops[i].finished) continue;
         for (size_t j = 0; j < ops.size(); ++j)
-            if (!ops[j].send && ops[j].peer == d->rank && ops[j].done != ops[j].bytes && ops[j].bytes == ops[i].bytes) {
+            if (!ops[j].send && ops[j].peer == d->rank && !ops[j].finished && ops[j].bytes == ops[i].bytes) {
                 if (ops[i].mem == MS_DIST_MEM_HOST && ops[j].mem == MS_DIST_MEM_HOST) memcpy(ops[j].buf, ops[i].buf, ops[i].bytes);
                 else MS_HIP(hipMemcpy(ops[j].buf, ops[i].buf, ops[i].bytes, hipMemcpyDefault));
-                ops[i].done = ops[i].bytes; ops[j].done = ops[j].bytes;
+                ops[i].finished = ops[j].finished = true;
                 break;
             }
-        if (ops[i].done != ops[i].bytes) return fail(MS_ERR_INVALID, "ms_dist_group_end: a send to oneself has no matching receive in the group");
+        if (!ops[i].finished) return fail(MS_ERR_INVALID, "ms_dist_group_end: a send to oneself has no matching receive in the group");
     }
     std::vector<Op> rest;
-    for (const Op &o : ops) if (o.done != o.bytes || o.bytes == 0) { if (o.peer != d->rank) rest.push_back(o); }
+    for (const Op &o : ops) {
+        if (o.finished) continue;
+        if (o.peer == d->rank) return fail(MS_ERR_INVALID, "ms_dist_group_end: a receive from oneself has no matching send in the group");
+        rest.push_back(o);
+    }
     return host_run(d, rest);
 }
 
@@ -513,8 +520,13 @@ int ms_dist_gather_slabs(ms_dist *d, const void *slab, size_t bytes, void *const
         if (!slab) err = fail(MS_ERR_INVALID, "ms_dist_gather_slabs: null slab");
         else err = ms_dist_send(d, slab, bytes, sink, MS_DIST_MEM_DEVICE, stream);
     }
-    const int e2 = err ? (d->grouping = false, d->ops.clear(), (d->transport == MS_DIST_RCCL ? (void)rccl().GroupEnd() : (void)0), MS_OK) : ms_dist_group_end(d);
-    return err ? err : e2;
+    if (err) {                  // close the group without running it (RCCL: end the group so the communicator stays usable), report the first error
+        d->grouping = false;
+        d->ops.clear();
+        if (d->transport == MS_DIST_RCCL) (void)rccl().GroupEnd();
+        return err;
+    }
+    return ms_dist_group_end(d);
 }
 
 namespace {
