@@ -436,8 +436,14 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
 #define MS_WARP_NF 2
 #endif
 constexpr int WARP_NF = MS_WARP_NF;
+// lane rows per WORKGROUP: a tile's WARP_BY lane rows are split over WARP_BY / WARP_WY workgroups (blockIdx.y).  MS_WARP_ONE_WAVE: 64-lane workgroups
+// (the waves of a tile share nothing but the tile record), as k_blend8 got in round 2.
+#ifndef MS_WARP_ONE_WAVE
+#define MS_WARP_ONE_WAVE 0
+#endif
+constexpr int WARP_WY = (MS_WARP_ONE_WAVE && WARP_BY * WARP_BX > 64) ? 64 / WARP_BX : WARP_BY;
 template <bool CPW, bool AL, int PROJ>
-__global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+__global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
                                                          uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs, int n_frames)
@@ -446,10 +452,10 @@ __global__ void __launch_bounds__(WARP_BX * WARP_BY) k_warp_t(const WarpTile *__
     const int f0 = (int)blockIdx.z * WARP_NF, nf = min(WARP_NF, n_frames - f0);
     // aligned tap reads unless a sample of the tile reads the last row of a caller's image (flags bit 3, k_tile_bbox); the CPW stage buffer is ours and padded
     if (AL && (CPW || (T.flags & 8)))
-        warp_tile_direct<CPW, PROJ, true, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+        warp_tile_direct<CPW, PROJ, true, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
                                                    g0, g0_stride, tabs);
     else
-        warp_tile_direct<CPW, PROJ, false, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+        warp_tile_direct<CPW, PROJ, false, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
                                                     g0, g0_stride, tabs);
 }
 
