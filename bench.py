@@ -713,9 +713,8 @@ def main():
             recal["frames"] += F
             if recal["frames"] >= args.recalib_every:
                 recal["frames"] -= args.recalib_every
-                for cc in comps:
-                    for i in range(cfg["n"]):
-                        cc.set_mesh(i, *mesh_pool[recal["count"] % 4][i])
+                for cc in comps:      # convertMeshesToMap for every view: one call, two launches (ms_set_meshes)
+                    cc.set_meshes(mesh_pool[recal["count"] % 4])
                 recal["count"] += 1
         if to_i420 and egress_used[b]:
             torch.cuda.current_stream().wait_event(egress_done[b])      # the canvases / slabs of buffer b are free again

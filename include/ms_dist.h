@@ -77,7 +77,8 @@ typedef struct ms_dist_mesh_update {
 } ms_dist_mesh_update;
 MS_API int ms_dist_mesh_exchange(ms_dist *d, int root, const ms_dist_mesh_update *upd, ms_dist_mesh_update *out, size_t cap_floats, int *have,
                                  ms_stream stream);
-/* ms_set_mesh for every view of `upd` on this rank's context if `next_frame` >= upd->swap_frame; *applied = 1 then (the caller drops the update). */
+/* ms_set_meshes (every view of `upd`, which must cover all views of the context) on this rank's context if `next_frame` >= upd->swap_frame; *applied = 1 then
+ * (the caller drops the update). */
 MS_API int ms_dist_apply_meshes(ms_ctx *ctx, const ms_dist_mesh_update *upd, long long next_frame, int *applied, ms_stream stream);
 
 #ifdef __cplusplus

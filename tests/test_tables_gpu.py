@@ -190,6 +190,42 @@ def test_mesh_to_map_vs_oracle(ms, cuda, oracle, nm):
     comp.close()
 
 
+@pytest.mark.parametrize("rig,nm", [("mini6", (10, 10)), ("mini4", (7, 12)), ("cfg2", (40, 40))])
+def test_set_meshes_all_views_in_two_launches(ms, cuda, oracle, rig, nm):
+    """ms_set_meshes = convertMeshesToMap for every image at once (meshwarper.cpp:823-886), blockIdx.z = view: bit-identical to the per-view ms_set_mesh and to
+    the oracle, over repeated calls (its accumulators ping-pong and clear each other), interleaved with per-view updates, with the measured displacements and a
+    stitched frame equal too."""
+    comp, cfg, _ = make_rig(ms, rig, enable_cpw=True)
+    ref, _, _ = make_rig(ms, rig, enable_cpw=True)
+    n = cfg["n"]
+    rois = [comp.view_geom(i).roi for i in range(n)]
+    for rnd, amp in enumerate((6.0, 11.0, 3.0, 25.0)):
+        meshes = [synth.mesh(rois[i].width, rois[i].height, nm[0], nm[1], phase=0.3 * i + 0.9 * rnd, amp=amp) for i in range(n)]
+        comp.set_meshes(meshes)
+        if rnd == 2:      # a per-view update in between must not disturb the batched scratch (and vice versa)
+            comp.set_mesh(1, *meshes[1])
+        for i in range(n):
+            ref.set_mesh(i, *meshes[i])
+        for i in range(n):
+            got = [host(t) for t in comp.mesh_maps(i)]
+            want = [host(t) for t in ref.mesh_maps(i)]
+            assert np.array_equal(got[0], want[0], equal_nan=True) and np.array_equal(got[1], want[1], equal_nan=True), (rnd, i)
+            assert comp.mesh_displacement(i) == ref.mesh_displacement(i)
+            if rig != "cfg2" or i in (0, 3):
+                ox, oy = oracle.convert_mesh_to_map(meshes[i][0], meshes[i][1], rois[i].width, rois[i].height)
+                assert np.array_equal(got[0], ox, equal_nan=True) and np.array_equal(got[1], oy, equal_nan=True)
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 1)) for i in range(n)]]
+    pg = comp.pano_geom()
+    a = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    b = torch.zeros_like(a)
+    comp.stitch(frames, out16s=[a]); ref.stitch(frames, out16s=[b]); torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    with pytest.raises(ms.MsError):
+        plain, _, _ = make_rig(ms, "mini4")
+        plain.set_meshes([synth.mesh(50, 40, 5, 5)] * 4)          # a context without enable_cpw
+    comp.close(); ref.close()
+
+
 def test_mesh_interpolation_equals_host_lerp(ms, cuda):
     """ms_set_mesh_interp = interpolateMesh (meshwarper.cpp:337-354: start + (end - start) * progress in fp32) + ms_set_mesh."""
     comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)

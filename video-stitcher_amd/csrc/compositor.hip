@@ -1285,16 +1285,29 @@ __device__ __forceinline__ float custom_resize_at(int tx, int ty, int cols, int 
 // (ping-pong: no memset call between updates) and the displacement word of this update.
 constexpr int MESH_SR = 4;                         // rows per lane: a workgroup scatters a 64 x 16 pixel block
 constexpr int MESH_WW = 48, MESH_WH = 20, MESH_WMX = 6, MESH_WMY = 4;   // LDS window (half-resolution cells) around where the block's first pixel lands
-__global__ void __launch_bounds__(256) k_mesh_expand_scatter(const float *__restrict__ smx, const float *__restrict__ smy, int N, int M, int aw, int ah,
-                                                             unsigned long long *ax, unsigned long long *ay, int hw, int hh,
-                                                             unsigned long long *__restrict__ clear, size_t n_clear, unsigned *disp_word)
+// one view's update: what both launches of convertMeshesToMap need (ms_set_meshes runs all views of a context in ONE pair of launches, blockIdx.z = view)
+struct MeshJob {
+    const float *smx, *smy;                    // N x M vertex mesh (device)
+    unsigned long long *ax, *ay;               // half-resolution accumulators of this update
+    unsigned long long *clear; size_t n_clear; // what the previous update dirtied in the other accumulator
+    unsigned *disp_word;
+    float *dx, *dy;                            // dense maps being written (the view's inactive buffer)
+    int aw, ah, hw, hh, pitch, tiles_x, n_tiles;
+};
+struct MeshJobs { MeshJob j[MAX_VIEWS]; };
+__device__ __forceinline__ void mesh_expand_scatter_block(const MeshJob &J, int N, int M, int bx, int by, int gx, int gy)
 {
+    const float *__restrict__ smx = J.smx, *__restrict__ smy = J.smy;
+    const int aw = J.aw, ah = J.ah, hw = J.hw, hh = J.hh;
+    unsigned long long *ax = J.ax, *ay = J.ay, *__restrict__ clear = J.clear;
+    const size_t n_clear = J.n_clear;
+    unsigned *disp_word = J.disp_word;
     // The pixels of a block land in a compact patch of the half-resolution grid (the mesh is a smooth deformation), and four of them share a
     // cell: accumulate the patch in LDS and send one pair of global atomics per touched cell instead of one per pixel (device-scope atomics
     // were 60 % of the update's GPU time); pixels landing outside the window go to memory directly.
     __shared__ unsigned long long wx[MESH_WH * MESH_WW], wy[MESH_WH * MESH_WW];
     const int lt = threadIdx.y * 64 + threadIdx.x;
-    const size_t tid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + lt, nthreads = (size_t)gridDim.x * gridDim.y * 256;
+    const size_t tid = ((size_t)by * gx + bx) * 256 + lt, nthreads = (size_t)gx * gy * 256;
     for (size_t k = tid; k < n_clear; k += nthreads) clear[k] = 0ull;
     if (tid == 0) *disp_word = 0u;
     for (int k = lt; k < MESH_WH * MESH_WW; k += 256) { wx[k] = 0ull; wy[k] = 0ull; }
@@ -1313,13 +1326,13 @@ __global__ void __launch_bounds__(256) k_mesh_expand_scatter(const float *__rest
     };
     auto finite_i32 = [](float v) { return v > -2147483648.f && v < 2147483648.f; };
     float ox, oy;
-    forward(blockIdx.x * 64, blockIdx.y * (4 * MESH_SR), ox, oy);          // the same for every lane: the window's anchor
+    forward(bx * 64, by * (4 * MESH_SR), ox, oy);          // the same for every lane: the window's anchor
     const int wx0 = (finite_i32(ox) ? (int)ox / 2 : 0) - MESH_WMX, wy0 = (finite_i32(oy) ? (int)oy / 2 : 0) - MESH_WMY;
     __syncthreads();
-    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int x = bx * 64 + threadIdx.x;
 #pragma unroll
     for (int r = 0; r < MESH_SR; ++r) {
-        const int y = blockIdx.y * (4 * MESH_SR) + r * 4 + threadIdx.y;
+        const int y = by * (4 * MESH_SR) + r * 4 + threadIdx.y;
         if (x >= aw || y >= ah) continue;
         float fx, fy;
         forward(x, y, fx, fy);
@@ -1349,12 +1362,29 @@ __global__ void __launch_bounds__(256) k_mesh_expand_scatter(const float *__rest
         atomicAdd(&ay[g], wy[k]);
     }
 }
+__global__ void __launch_bounds__(256) k_mesh_expand_scatter(const float *__restrict__ smx, const float *__restrict__ smy, int N, int M, int aw, int ah,
+                                                             unsigned long long *ax, unsigned long long *ay, int hw, int hh,
+                                                             unsigned long long *__restrict__ clear, size_t n_clear, unsigned *disp_word)
+{
+    MeshJob J{smx, smy, ax, ay, clear, n_clear, disp_word, nullptr, nullptr, aw, ah, hw, hh, 0, 0, 0};
+    mesh_expand_scatter_block(J, N, M, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+}
+__global__ void __launch_bounds__(256) k_mesh_expand_scatter_all(MeshJobs T, int N, int M)
+{
+    const MeshJob &J = T.j[blockIdx.z];
+    const int gx = (J.aw + 63) / 64, gy = (J.ah + 4 * MESH_SR - 1) / (4 * MESH_SR);
+    if ((int)blockIdx.x >= gx || (int)blockIdx.y >= gy) return;          // (the grid is sized for the largest view)
+    mesh_expand_scatter_block(J, N, M, (int)blockIdx.x, (int)blockIdx.y, gx, gy);
+}
 // second half (meshwarper.cpp:870-883): mean (0/0 -> NaN hole) + custom_resize back to the view size for both maps, and the largest
 // displacement of the new maps (see k_mesh_disp)
 constexpr int MESH_FW = 72, MESH_FH = 8;       // LDS footprint (cells) of a 64 x 4 output block: <= 64 * (hw - 1) / aw + 2 columns, likewise rows
-__global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long long *__restrict__ ax, const unsigned long long *__restrict__ ay, int hw, int hh,
-                                                          float *__restrict__ dx, float *__restrict__ dy, int pitch, int aw, int ah, int tiles_x, int n_tiles, unsigned *disp_word)
+__device__ __forceinline__ void mesh_mean_resize_blocks(const MeshJob &J, int first_tile, int tile_stride)
 {
+    const unsigned long long *__restrict__ ax = J.ax, *__restrict__ ay = J.ay;
+    const int hw = J.hw, hh = J.hh, pitch = J.pitch, aw = J.aw, ah = J.ah, tiles_x = J.tiles_x, n_tiles = J.n_tiles;
+    float *__restrict__ dx = J.dx, *__restrict__ dy = J.dy;
+    unsigned *disp_word = J.disp_word;
     __shared__ float mxs[MESH_FH][MESH_FW], mys[MESH_FH][MESH_FW];
     __shared__ float wmax[4];
     const bool ex = resize_axis_exact(hw, aw), ey = resize_axis_exact(hh, ah);
@@ -1362,7 +1392,7 @@ __global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long lo
     float d = 0.f;
     // a workgroup walks 64 x 4 output tiles grid-stride: one atomic on the displacement word per workgroup, not per tile (thousands of
     // same-address atomics serialise: they were most of this kernel's time)
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = first_tile; tile < n_tiles; tile += tile_stride) {
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
         const int x = txi * 64 + threadIdx.x, y = tyi * 4 + threadIdx.y;
         // footprint of the tile in the half-resolution maps
@@ -1418,6 +1448,16 @@ __global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long lo
         d = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
         if (d > 0.f) atomicMax(disp_word, __float_as_uint(d));
     }
+}
+__global__ void __launch_bounds__(256) k_mesh_mean_resize(const unsigned long long *__restrict__ ax, const unsigned long long *__restrict__ ay, int hw, int hh,
+                                                          float *__restrict__ dx, float *__restrict__ dy, int pitch, int aw, int ah, int tiles_x, int n_tiles, unsigned *disp_word)
+{
+    MeshJob J{nullptr, nullptr, const_cast<unsigned long long *>(ax), const_cast<unsigned long long *>(ay), nullptr, 0, disp_word, dx, dy, aw, ah, hw, hh, pitch, tiles_x, n_tiles};
+    mesh_mean_resize_blocks(J, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ void __launch_bounds__(256) k_mesh_mean_resize_all(MeshJobs T)
+{
+    mesh_mean_resize_blocks(T.j[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1520,6 +1560,10 @@ struct ms_ctx {
     DevBuf mesh_tmp;                   // scratch for convertMeshesToMap: vertex mesh x|y, two half-resolution accumulators ([count:24|sum_x:40], [sum_y]) used in turn
     size_t mesh_small_cap = 0, mesh_half_cap = 0, mesh_dirty = 0;   // capacities (floats / cells); 64-bit words the previous update dirtied in its accumulator
     int mesh_parity = 0;
+    DevBuf mesh_all;                   // scratch of ms_set_meshes (all views in one pair of launches): every view's vertex meshes, then per view two accumulator pairs used in turn
+    size_t mesh_all_small = 0;         // floats per vertex map the block was sized for
+    int mesh_all_parity = 0;
+    bool mesh_all_dirty = false;       // the accumulators of the other parity hold the previous call's sums (cleared by the next scatter launch)
     std::mutex mesh_mu;                // guards the active indices / events shared with ms_stitch: held only across enqueues, never across a host wait
     std::mutex mesh_update_mu;         // serialises mesh updates among themselves (shared scratch, staging slots); taken BEFORE mesh_mu
     // Held by ms_stitch for the length of its enqueue and by everything that REBUILDS the static tables (ms_init_blender, and through it the synchronous
@@ -2606,6 +2650,90 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     c->mesh_dirty = 2 * n_half;
     c->mesh_parity ^= 1;
     return mesh_end_update(c, view, tgt, st, false);
+}
+
+// MeshWarper::convertMeshesToMap as the reference calls it -- for ALL views at once (meshwarper.cpp:823-886 loops over the images): the same two kernels
+// with blockIdx.z / .y = view, i.e. two launches per recalibration instead of two per view.  The per-view launches are latency-bound (47 us each for a
+// 960 x 627 view): six views cost 0.3 ms of GPU time one after the other, about a third of that together.  Same arithmetic, bit-identical maps.
+// mesh_x / mesh_y: HOST, num_views meshes of N x M back to back.
+int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, int M, ms_stream stream)
+{
+    if (!c) return fail(MS_ERR_INVALID, "null context");
+    MS_CHECK(mesh_x && mesh_y && N >= 2 && M >= 2, "ms_set_meshes: need N x M (>= 2x2) vertex meshes");
+    if (!c->blender_ready || !c->cfg.enable_cpw) return fail(MS_ERR_STATE, "ms_set_meshes needs enable_cpw and ms_init_blender");
+    std::lock_guard<std::mutex> lk(c->mesh_update_mu);
+    hipStream_t st = as_stream(stream);
+    const int NV = c->N;
+    const size_t n_small = (size_t)N * M;
+    std::vector<size_t> acc_off(NV + 1, 0);                  // 64-bit words: per view [ax | ay] x two parities
+    int max_aw = 0, max_ah = 0, max_tiles = 0;
+    for (int v = 0; v < NV; ++v) {
+        const int aw = c->roi[v].width, ah = c->roi[v].height, hw = aw / 2, hh = ah / 2;
+        MS_CHECK(hw >= 2 && hh >= 2, "ms_set_meshes: view %d too small", v);
+        MS_CHECK((long long)aw * ah < (1ll << 24) && aw < 65536 && ah < 65536, "ms_set_meshes: view %dx%d exceeds the scatter accumulators ([count:24 | sum:40])", aw, ah);
+        acc_off[v + 1] = acc_off[v] + 4 * (size_t)hw * hh;
+        max_aw = std::max(max_aw, aw); max_ah = std::max(max_ah, ah);
+        max_tiles = std::max(max_tiles, div_up(aw, 64) * div_up(ah, 4));
+    }
+    const size_t sm_floats = 2 * n_small * NV, sm_bytes = (sm_floats * sizeof(float) + 15) & ~(size_t)15;
+    if (!c->mesh_all.p || c->mesh_all_small != n_small || c->mesh_stage_floats < 2 * n_small) {      // first call or another mesh size: drain earlier updates, (re)allocate
+        if (c->mesh_chain_set) MS_HIP(hipEventSynchronize(c->mesh_chain));
+        const size_t bytes = sm_bytes + acc_off[NV] * sizeof(unsigned long long);
+        if (int e = c->mesh_all.alloc(bytes)) return e;
+        MS_HIP(hipMemset(c->mesh_all.p, 0, bytes));
+        c->mesh_all_small = n_small; c->mesh_all_parity = 0; c->mesh_all_dirty = false;
+        if (c->mesh_stage_floats < 2 * n_small) {
+            if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
+            c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
+            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, 2 * n_small * sizeof(float) * MAX_VIEWS, hipHostMallocDefault));
+            c->mesh_stage_floats = 2 * n_small;
+        }
+    }
+    if (!c->disp_dev.p) {
+        if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
+        MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));
+    }
+    int tgt[MAX_VIEWS];
+    for (int v = 0; v < NV; ++v) if (int e = mesh_begin_update(c, v, &tgt[v], st)) return e;
+    // stage the caller's arrays in pinned memory (the view's slot is free once its previous update's copy has run: checked on its event), one copy for all views
+    float *sm = (float *)c->mesh_all.p;
+    unsigned long long *acc0 = (unsigned long long *)((char *)c->mesh_all.p + sm_bytes);
+    MeshJobs T{};
+    const int p = c->mesh_all_parity;
+    for (int v = 0; v < NV; ++v) {
+        bool slot_busy;
+        { std::lock_guard<std::mutex> mk(c->mesh_mu); slot_busy = c->mesh_ready[v] && (c->mesh_wait[v] || c->mesh_set[v]); }
+        if (slot_busy) MS_HIP(hipEventSynchronize(c->mesh_ready[v]));
+        float *stg = c->mesh_stage + (size_t)v * c->mesh_stage_floats;
+        memcpy(stg, mesh_x + (size_t)v * n_small, n_small * 4);
+        memcpy(stg + n_small, mesh_y + (size_t)v * n_small, n_small * 4);
+        const int aw = c->roi[v].width, ah = c->roi[v].height, hw = aw / 2, hh = ah / 2;
+        const size_t n_half = (size_t)hw * hh;
+        unsigned long long *mine = acc0 + acc_off[v] + (size_t)p * 2 * n_half, *other = acc0 + acc_off[v] + (size_t)(1 - p) * 2 * n_half;
+        ms_image dx = mesh_image(c, tgt[v], v, 0), dy = mesh_image(c, tgt[v], v, 1);
+        MeshJob &J = T.j[v];
+        J.smx = sm + (size_t)v * 2 * n_small; J.smy = J.smx + n_small;
+        J.ax = mine; J.ay = mine + n_half;
+        J.clear = other; J.n_clear = c->mesh_all_dirty ? 2 * n_half : 0;
+        J.disp_word = (unsigned *)c->disp_dev.p + 2 * v + tgt[v];
+        J.dx = (float *)dx.data; J.dy = (float *)dy.data;
+        J.aw = aw; J.ah = ah; J.hw = hw; J.hh = hh; J.pitch = c->map_pitch[v];
+        J.tiles_x = div_up(aw, 64); J.n_tiles = J.tiles_x * div_up(ah, 4);
+    }
+    if (c->mesh_stage_floats == 2 * n_small)
+        MS_HIP(hipMemcpyAsync(sm, c->mesh_stage, sm_floats * sizeof(float), hipMemcpyHostToDevice, st));        // the slots are back to back
+    else
+        for (int v = 0; v < NV; ++v)
+            MS_HIP(hipMemcpyAsync(sm + (size_t)v * 2 * n_small, c->mesh_stage + (size_t)v * c->mesh_stage_floats, 2 * n_small * sizeof(float), hipMemcpyHostToDevice, st));
+    const dim3 blk(64, 4);
+    k_mesh_expand_scatter_all<<<dim3(div_up(max_aw, 64), div_up(max_ah, 4 * MESH_SR), NV), blk, 0, st>>>(T, N, M);         // meshwarper.cpp:838-869, every view
+    MS_LAUNCH_CHECK();
+    k_mesh_mean_resize_all<<<dim3(std::min(max_tiles, 512), NV), blk, 0, st>>>(T);                                           // :870-883
+    MS_LAUNCH_CHECK();
+    c->mesh_all_dirty = true;
+    c->mesh_all_parity ^= 1;
+    for (int v = 0; v < NV; ++v) if (int e = mesh_end_update(c, v, tgt[v], st, false)) return e;
+    return MS_OK;
 }
 
 // MeshWarper::interpolateMesh (meshwarper.cpp:337-354) + convertMeshesToMap: the RECALIB_INTERP branch of the recalibration thread

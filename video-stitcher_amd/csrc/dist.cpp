@@ -563,9 +563,11 @@ int ms_dist_apply_meshes(ms_ctx *ctx, const ms_dist_mesh_update *upd, long long 
     MS_CHECK(ctx && upd && applied, "ms_dist_apply_meshes: null argument");
     *applied = 0;
     if (next_frame < upd->swap_frame) return MS_OK;
-    const size_t per = (size_t)upd->rows * upd->cols;
-    for (int v = 0; v < upd->n_views; ++v)
-        if (int e = ms_set_mesh(ctx, v, upd->mesh_x + v * per, upd->mesh_y + v * per, upd->rows, upd->cols, stream)) return e;
+    // convertMeshesToMap for every view in one call (two launches): the update carries the meshes of all views back to back
+    ms_view_geom g;
+    MS_CHECK(upd->n_views >= 1 && ms_get_view_geom(ctx, upd->n_views - 1, &g) == MS_OK && ms_get_view_geom(ctx, upd->n_views, &g) != MS_OK,
+             "ms_dist_apply_meshes: the update holds %d meshes, not one per view of the context", upd->n_views);
+    if (int e = ms_set_meshes(ctx, upd->mesh_x, upd->mesh_y, upd->rows, upd->cols, stream)) return e;
     *applied = 1;
     return MS_OK;
 }

@@ -89,7 +89,7 @@ EXPORTS = [
     "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
     "ms_calibrate_cameras", "ms_num_bands_rule", "ms_orb_default_params", "ms_orb_detect_and_compute", "ms_find_homography_ransac", "ms_feature_mask",
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
-    "ms_init_blender", "ms_set_mesh", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
+    "ms_init_blender", "ms_set_mesh", "ms_set_meshes", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
@@ -657,6 +657,15 @@ class Compositor:
     def set_mesh(self, view, mesh_x, mesh_y):
         ax, px = _fa(mesh_x, mesh_x.size); ay, py = _fa(mesh_y, mesh_y.size)
         _chk(load().ms_set_mesh(self._ctx, view, px, py, mesh_x.shape[0], mesh_x.shape[1], _stream()))
+
+    def set_meshes(self, meshes):
+        """convertMeshesToMap for every view in one call: meshes = [(mesh_x, mesh_y)] * num_views, all N x M float32 host arrays."""
+        import numpy as np
+        mx = np.ascontiguousarray(np.stack([m[0] for m in meshes]), np.float32)
+        my = np.ascontiguousarray(np.stack([m[1] for m in meshes]), np.float32)
+        assert mx.shape[0] == self.n and mx.shape == my.shape
+        fp = C.POINTER(C.c_float)
+        _chk(load().ms_set_meshes(self._ctx, mx.ctypes.data_as(fp), my.ctypes.data_as(fp), mx.shape[1], mx.shape[2], _stream()))
 
     def set_mesh_maps(self, view, xm, ym):
         _chk(load().ms_set_mesh_maps(self._ctx, view, C.byref(img(xm)), C.byref(img(ym)), _stream()))

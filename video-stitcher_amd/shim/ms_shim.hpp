@@ -102,6 +102,8 @@ public:
     // MeshWarper::convertMeshesToMap (meshwarper.cpp:823): callable from the recalibration thread
     void convertMeshToMap(int i, const float *mesh_x, const float *mesh_y, int N, int M, ms_stream s = nullptr)
     { check(ms_set_mesh(ctx_, i, mesh_x, mesh_y, N, M, s)); }
+    // ... and for all views at once, as MeshWarper::convertMeshesToMap itself loops over the images: num_views meshes of N x M back to back, two launches in all
+    void convertMeshesToMap(const float *mesh_x, const float *mesh_y, int N, int M, ms_stream s = nullptr) { check(ms_set_meshes(ctx_, mesh_x, mesh_y, N, M, s)); }
 
     // stitch_one (timed.cpp:123-152): full_imgs = the NUM_IMAGES uploaded frames; out = caller-owned ring slot
     template <class Mat> void stitch_one(const std::vector<Mat> &full_imgs, Mat *out8u, Mat *out16s, ms_stream s = nullptr)
