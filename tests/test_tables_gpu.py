@@ -226,6 +226,43 @@ def test_set_meshes_all_views_in_two_launches(ms, cuda, oracle, rig, nm):
     comp.close(); ref.close()
 
 
+@pytest.mark.parametrize("batched", [True, False])
+def test_first_mesh_update_is_ordered_on_its_own_stream(ms, cuda, batched):
+    """The first mesh update of a context allocates and clears its scratch (accumulators, displacement words).  That has to happen ON THE UPDATE'S STREAM: a plain
+    hipMemset runs on the NULL stream, asynchronously to the host, and a non-blocking stream does not wait for it -- with the NULL stream busy (here: a queue of large
+    fills; in stitch_dist: the other ranks' host-transport copies) the scatter kernels ran on uncleared accumulators and the clear landed afterwards: 5 of 30
+    four-rank runs delivered wrong frames for the batch after the first recalibration (tools/dist_repeat.py)."""
+    quiet, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)
+    n = cfg["n"]
+    rois = [quiet.view_geom(i).roi for i in range(n)]
+    meshes = [synth.mesh(rois[i].width, rois[i].height, 9, 11, phase=0.4 * i, amp=7.0) for i in range(n)]
+    for i in range(n):
+        quiet.set_mesh(i, *meshes[i])
+    torch.cuda.synchronize()
+    want = [[host(t).copy() for t in quiet.mesh_maps(i)] for i in range(n)]
+    busy = torch.zeros(1 << 29, dtype=torch.uint8, device=cuda)
+    for trial in range(3):
+        comp, _, _ = make_rig(ms, "mini6", enable_cpw=True)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        for _ in range(40):
+            busy.add_(1)                                  # tens of milliseconds of work queued on the NULL stream
+        with torch.cuda.stream(side):
+            if batched:
+                comp.set_meshes(meshes)
+            else:
+                for i in range(n):
+                    comp.set_mesh(i, *meshes[i])
+        side.synchronize()
+        torch.cuda.synchronize()
+        for i in range(n):
+            got = [host(t) for t in comp.mesh_maps(i)]
+            assert np.array_equal(got[0], want[i][0], equal_nan=True) and np.array_equal(got[1], want[i][1], equal_nan=True), (trial, i)
+            assert comp.mesh_displacement(i) == quiet.mesh_displacement(i)
+        comp.close()
+    quiet.close()
+
+
 def test_mesh_interpolation_equals_host_lerp(ms, cuda):
     """ms_set_mesh_interp = interpolateMesh (meshwarper.cpp:337-354: start + (end - start) * progress in fp32) + ms_set_mesh."""
     comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)

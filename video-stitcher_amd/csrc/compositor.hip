@@ -248,16 +248,16 @@ __global__ void __launch_bounds__(1024) k_down_tail(const ViewDesc *__restrict__
 // One input row contributes columns [8t-2, 8t+8]: a 16-byte (int16) / 8-byte (u8) aligned body plus a
 // 2-pixel left and 1-pixel right halo; BORDER_REFLECT_101 only touches the first/last thread of a row,
 // where the mirrored columns are already inside the body (col -2 -> 2, -1 -> 1, w -> w-2).
-// Raw row fetch for columns [8t-2, 8t+8] of one input row, issued unconditionally (clamped addresses) so that the
-// 7 rows' loads are in flight together; the reflect selection happens after, in registers.
+// Raw row fetch for columns [8t-2, 8t+8] of one input row, issued unconditionally so that the
+// rows' loads are in flight together; the reflect selection happens after, in registers.
 //   ONE 16-byte load at byte 8t-4 (dword aligned) covers bytes 8t-4 .. 8t+11
 // (wave-wide gathers cost per instruction, so fewer, wider loads win).  Reads may run a few bytes past the end of
 // the last row of a plane: planes are contiguous and the buffers carry 64 bytes of slack.
 struct Row11u8 { uint4 b; };
 __device__ __forceinline__ Row11u8 fetch_row11(const uint8_t *__restrict__ row, int t, int w)
 {
-    Row11u8 o;
-    __builtin_memcpy(&o.b, __builtin_assume_aligned(row + max(8 * t - 4, 0), 4), 16);
+    Row11u8 o;      // at t == 0 the first dword lies before the row (the previous row's padding, the previous plane, or the buffer's lead): down_row replaces it
+    __builtin_memcpy(&o.b, __builtin_assume_aligned(row + (8 * t - 4), 4), 16);
     return o;
 }
 
@@ -590,9 +590,9 @@ __device__ __forceinline__ unsigned rne6_pk(unsigned s)
 __device__ __forceinline__ void up_rows_load(const int16_t *__restrict__ cs, int cpitch, int ch, int i, int j0, uint4 raw[3])
 {
     const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
-    const int jb = max(j0 - 2, 0);
+    // columns j0-2 .. j0+5 unconditionally: at j0 == 0 the first dword lies before the row (padding / previous plane / the buffer's lead) and is replaced below
 #pragma unroll
-    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (mul24(rr[r], cpitch) + (unsigned)jb));
+    for (int r = 0; r < 3; ++r) raw[r] = load16_a4((cs - 2) + (mul24(rr[r], cpitch) + (unsigned)j0));
 }
 __device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
 {
@@ -600,7 +600,7 @@ __device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, un
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         unsigned w0 = raw[r].x, w1 = raw[r].y, w2 = raw[r].z, w3 = raw[r].w;
-        if (j0 == 0) { w3 = w2; w2 = w1; w1 = w0; }      // window starts at column 0: tap -1 mirrors to column 1 = hi(w0)
+        if (j0 == 0) w0 = w1;                            // tap -1 mirrors to column 1 = hi(w1)
         if (j0 + 4 >= cw) w3 = w2 >> 16;                 // tap j0+4 clamps to cw-1
         // taps t0 = hi(w0), (t1,t2) = w1, (t3,t4) = w2, t5 = lo(w3)
         const unsigned t01 = __builtin_amdgcn_alignbyte(w1, w0, 2), t23 = __builtin_amdgcn_alignbyte(w2, w1, 2),
@@ -624,9 +624,8 @@ __device__ __forceinline__ void up_2x8_pk(const uint4 raw[3], int cw, int j0, un
 __device__ __forceinline__ void up_rows_load(const uint8_t *__restrict__ cs, int cpitch, int ch, int i, int j0, uint2 raw[3])
 {
     const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
-    const int jb = max(j0 - 2, 0);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) __builtin_memcpy(&raw[r], cs + (mul24(rr[r], cpitch) + (unsigned)jb), 8);
+    for (int r = 0; r < 3; ++r) __builtin_memcpy(&raw[r], (cs - 2) + (mul24(rr[r], cpitch) + (unsigned)j0), 8);      // columns j0-2 .. j0+5 (see the int16 form)
 }
 __device__ __forceinline__ void up_2x8_pk(const uint2 raw8[3], int cw, int j0, unsigned ue[4], unsigned uo[4])
 {
@@ -679,7 +678,7 @@ __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, u
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         unsigned w0 = add_pk_u16(raw[r].x, bias), w1 = add_pk_u16(raw[r].y, bias), w2 = add_pk_u16(raw[r].z, bias), w3 = add_pk_u16(raw[r].w, bias);
-        if (j0 == 0) { w3 = w2; w2 = w1; w1 = w0; }
+        if (j0 == 0) w0 = w1;
         if (j0 + 4 >= cw) w3 = w2 >> 16;
         bad |= (w0 & 0xfc000000u) | (w1 & 0xfc00fc00u) | (w2 & 0xfc00fc00u) | (w3 & 0x0000fc00u);   // taps: hi(w0), w1, w2, lo(w3)
         const unsigned t01 = __builtin_amdgcn_alignbyte(w1, w0, 2), t23 = __builtin_amdgcn_alignbyte(w2, w1, 2),
@@ -2213,7 +2212,8 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     // ---- layout of every per-view level -------------------------------------------------------
     c->h_views.assign(N, ViewDesc{});
     size_t w_total = 0;
-    long long g0_total = 0, gl_total = 0, stage_total = 0;
+    // (64 bytes of lead in front of each frame's view pyramids: fetch_row11 reads the 4 bytes before a row's first pixel unconditionally)
+    long long g0_total = 64, gl_total = 64, stage_total = 0;
     c->max_pw = c->max_ph = c->max_aw = c->max_ah = 0;
     for (int v = 0; v < N; ++v) {
         ViewDesc &V = c->h_views[v];
@@ -2316,7 +2316,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     P = PanoDesc{};
     P.nb = nb; P.n_views = N;
     size_t den_total = 0;
-    long long cl_total = 0, pacc_total = 0;
+    long long cl_total = 32, pacc_total = 0;       // (int16 elements: 64 bytes of lead, as for the view pyramids -- up_rows_load)
     {
         int w = c->bg.dst_roi.width, h = c->bg.dst_roi.height;
         for (int l = 0; l <= nb; ++l) {
@@ -2474,11 +2474,11 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
         }
         for (int v = 0; v < N; ++v)      // the effective mask of a view that has no re-warped one is the mask itself
             if (!c->use_eff[v])
-                MS_HIP(hipMemcpy((uint8_t *)c->masks_eff.p + c->mask_off[v], (const uint8_t *)c->masks.p + c->mask_off[v], (size_t)c->roi[v].width * c->roi[v].height, hipMemcpyDeviceToDevice));
+                MS_HIP(hipMemcpyAsync((uint8_t *)c->masks_eff.p + c->mask_off[v], (const uint8_t *)c->masks.p + c->mask_off[v], (size_t)c->roi[v].width * c->roi[v].height, hipMemcpyDeviceToDevice, st));
         if (!c->tab_ready) MS_HIP(hipEventCreateWithFlags(&c->tab_ready, hipEventDisableTiming));
         if (!c->disp_dev.p) {
             if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
-            MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));      // "unbounded" until measured
+            MS_HIP(hipMemsetAsync(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned), st));      // "unbounded" until measured
         }
     }
     if (const char *chk = getenv("MS_CHECK_DIVIDE")) if (atoi(chk) != 0) {
@@ -2530,7 +2530,7 @@ static int measure_mesh_disp(ms_ctx *c, int view, int tgt, hipStream_t st)
 {
     if (!c->disp_dev.p) {
         if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
-        MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));      // "unbounded" until measured
+        MS_HIP(hipMemsetAsync(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned), st));      // "unbounded" until measured
     }
     const int aw = c->roi[view].width, ah = c->roi[view].height;
     const float *base = (const float *)c->mesh[tgt].p + c->mesh_off[view];
@@ -2612,7 +2612,7 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
         if (c->mesh_chain_set) MS_HIP(hipEventSynchronize(c->mesh_chain));
         const size_t bytes = 2 * n_small * sizeof(float) + 4 * half_cap * sizeof(unsigned long long) + 16;
         if (int e = c->mesh_tmp.alloc(bytes)) return e;
-        MS_HIP(hipMemset(c->mesh_tmp.p, 0, bytes));
+        MS_HIP(hipMemsetAsync(c->mesh_tmp.p, 0, bytes, st));      // on the update's own stream: a plain hipMemset runs on the NULL stream, asynchronously to the host, and non-blocking streams do not wait for it
         c->mesh_small_cap = n_small; c->mesh_half_cap = half_cap; c->mesh_dirty = 0; c->mesh_parity = 0;
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
@@ -2623,7 +2623,7 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     }
     if (!c->disp_dev.p) {
         if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
-        MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));      // "unbounded" until measured
+        MS_HIP(hipMemsetAsync(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned), st));      // "unbounded" until measured
     }
     if (int e = mesh_begin_update(c, view, &tgt, st)) return e;
     float *sm_x = (float *)c->mesh_tmp.p, *sm_y = sm_x + n_small;
@@ -2680,7 +2680,7 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
         if (c->mesh_chain_set) MS_HIP(hipEventSynchronize(c->mesh_chain));
         const size_t bytes = sm_bytes + acc_off[NV] * sizeof(unsigned long long);
         if (int e = c->mesh_all.alloc(bytes)) return e;
-        MS_HIP(hipMemset(c->mesh_all.p, 0, bytes));
+        MS_HIP(hipMemsetAsync(c->mesh_all.p, 0, bytes, st));      // (stream-ordered: see ms_set_mesh)
         c->mesh_all_small = n_small; c->mesh_all_parity = 0; c->mesh_all_dirty = false;
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
@@ -2691,7 +2691,7 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
     }
     if (!c->disp_dev.p) {
         if (int e = c->disp_dev.alloc(2 * MAX_VIEWS * sizeof(unsigned))) return e;
-        MS_HIP(hipMemset(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned)));
+        MS_HIP(hipMemsetAsync(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned), st));
     }
     int tgt[MAX_VIEWS];
     for (int v = 0; v < NV; ++v) if (int e = mesh_begin_update(c, v, &tgt[v], st)) return e;
@@ -2844,7 +2844,7 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
     if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
     if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
         if (int e = c->masks_eff.alloc(c->masks.bytes)) return e;
-        MS_HIP(hipMemcpy(c->masks_eff.p, c->masks.p, c->masks.bytes, hipMemcpyDeviceToDevice));
+        MS_HIP(hipMemcpyAsync(c->masks_eff.p, c->masks.p, c->masks.bytes, hipMemcpyDeviceToDevice, st));
     }
     const int aw = c->roi[view].width, ah = c->roi[view].height;
     ms_image src{(uint8_t *)c->masks.p + c->mask_off[view], (size_t)aw, aw, ah, MS_8UC1};

@@ -193,18 +193,29 @@ __global__ void __launch_bounds__(256) k_resize_linear3_batch(ResizeBatch T, siz
     }
 }
 // The per-frame form of the same resize (the shipped COMPOSE_MEGAPIX puts cuda::resize of every view on the per-frame path, timed.cpp:75-85): 4 output
-// pixels x RS_ROWS rows per lane.  A lane's 4 pixels sample at most 8 consecutive source pixels for downscales up to 1.67x, so each source row is ONE
-// unaligned 24-byte window (16 + 8 byte loads: 3 lane-dwords per output pixel and row instead of 12 byte loads), the taps of a pixel are cut out of the
-// window in registers (dword select + v_alignbyte_b32), and the 12 output bytes leave as one store.  Same fp32 expressions in the same order as
-// k_resize_linear -> bit-identical (tests/test_prims_gpu.py::test_resize_linear_batch_equals_single_calls).  Lanes whose window would leave the source
-// row, ragged right edges and stronger downscales take the per-pixel path.  1.0 GB per 16-frame batch: 0.96 ms with the per-pixel kernel, see profiles/.
-constexpr int RS_ROWS = 2;
-__device__ __forceinline__ unsigned rs_sel4(unsigned a, unsigned b, unsigned c, unsigned d, int i) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
+// pixels x RS_ROWS rows per lane.  A lane's 4 pixels sample at most 8 consecutive source pixels for downscales up to 1.6x, so each source row is ONE
+// 24-byte window (read as the 7 aligned dwords around it: 3.5 lane-dwords per output pixel and row instead of 12 byte loads), the taps of a pixel are cut out of
+// the window in registers (a two- or three-way dword select + v_alignbyte_b32), a source row shared by the lane's two output rows is read once, and the 12
+// output bytes leave as one store.  Same fp32 expressions in the same order as k_resize_linear -> bit-identical
+// (tests/test_prims_gpu.py::test_resize_linear_batch_equals_single_calls).  Lanes whose window would leave the source row, ragged right edges and stronger
+// downscales take the per-pixel path.  192 images 1080p -> 1578 x 887 (32 frames of the shipped rig): 3.1 ms with the per-pixel kernel, 0.755 ms with a generic
+// 4-way select (which the compiler turned into divergent branches), 0.57-0.62 ms now; with the source reads removed 0.43-0.46 (the VALU floor: 24 byte->float
+// conversions and 24 fmas per pixel pair): profiles/r03_resize_ab.txt.  v_pk_fma_f32 for pixel pairs was 6 % SLOWER (packed fp32 is no faster per flop here).
+#ifndef MS_RS_ROWS
+#define MS_RS_ROWS 2
+#endif
+constexpr int RS_ROWS = MS_RS_ROWS;
 __device__ __forceinline__ float rs_byte(unsigned lo, unsigned hi, int b) { return (float)(((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu); }
-__global__ void __launch_bounds__(256) k_resize_linear3_x4(ResizeBatch T, size_t sstep, int srows, int scols, size_t dstep, int drows, int dcols, float ify, float ifx)
+// lanes are numbered row-major over (row group, 4-pixel column group) of an image and cut into 256-lane workgroups regardless of the row length (no idle
+// lanes at the right edge: 1578 columns are 395 lanes = 6.2 waves); lpr = lanes per row, lpr_magic = floor(2^32 / lpr) for the division
+__global__ void __launch_bounds__(256) k_resize_linear3_x4(ResizeBatch T, size_t sstep, int srows, int scols, size_t dstep, int drows, int dcols, float ify, float ifx,
+                                                           unsigned lpr, unsigned lpr_magic, unsigned n_lanes)
 {
-    const int x0 = 4 * (int)(blockIdx.x * BX + threadIdx.x);
-    const int yb = (int)(blockIdx.y * BY + threadIdx.y) * RS_ROWS;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_lanes) return;
+    unsigned rg = __umulhi(idx, lpr_magic), lx = idx - rg * lpr;
+    if (lx >= lpr) { ++rg; lx -= lpr; }
+    const int x0 = 4 * (int)lx, yb = (int)rg * RS_ROWS;
     if (x0 >= dcols || yb >= drows) return;
     const uint8_t *src = T.src[blockIdx.z];
     uint8_t *dst = T.dst[blockIdx.z];
@@ -212,7 +223,8 @@ __global__ void __launch_bounds__(256) k_resize_linear3_x4(ResizeBatch T, size_t
     int x1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { sx[k] = (float)(x0 + k) * ifx; x1[k] = f2i_rd(sx[k]); }
-    const bool fast = x0 + 3 < dcols && x1[0] >= 0 && x1[0] + 8 <= scols && x1[3] - x1[0] <= 5 && x1[1] >= x1[0] && x1[2] >= x1[1] && x1[3] >= x1[2];
+    auto step12 = [](int d) { return d == 1 || d == 2; };
+    const bool fast = x0 + 3 < dcols && x1[0] >= 0 && x1[0] + 10 <= scols && step12(x1[1] - x1[0]) && step12(x1[2] - x1[1]) && step12(x1[3] - x1[2]);
     if (!fast) {                      // the per-pixel kernel's code for this lane's pixels
         for (int r = 0; r < RS_ROWS && yb + r < drows; ++r) {
             const int y = yb + r;
@@ -237,42 +249,74 @@ __global__ void __launch_bounds__(256) k_resize_linear3_x4(ResizeBatch T, size_t
         }
         return;
     }
-    int di[4], sh[4];                 // dword index and byte shift of each pixel's 6 tap bytes inside the 24-byte window
+    // Pixel k's 6 tap bytes start at byte o_k = 3 (x1[k] - x1[0]) of the window, and consecutive pixels advance by one or two source pixels (checked above), so
+    // o_1 is 3 or 6, o_2 is 6, 9 or 12, o_3 is 9, 12 or 15: the dwords around pixel k are one of two or three candidates (8 v_cndmask per window instead of a
+    // generic 4-way select of every dword), pixel 0 needs none, and the third dword matters only for a byte shift of 3 -- where it is a fixed one.
+    const int e1 = x1[1] - x1[0], e2 = x1[2] - x1[0], e3 = x1[3] - x1[0];
+    const bool s1 = e1 == 2, s2a = e2 == 2, s2b = e2 == 3, s3 = e3 == 3;
+    const unsigned sh1 = s1 ? 2u : 3u, sh2 = (unsigned)(4 - e2), sh3 = (unsigned)(3 * e3) & 3u;
     float wx1[4], wx2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int o = 3 * (x1[k] - x1[0]);
-        di[k] = o >> 2; sh[k] = o & 3;
-        wx2[k] = (float)(x1[k] + 1) - sx[k]; wx1[k] = sx[k] - (float)x1[k];
-    }
-    const size_t col0 = (size_t)x1[0] * 3;
+    for (int k = 0; k < 4; ++k) { wx2[k] = (float)(x1[k] + 1) - sx[k]; wx1[k] = sx[k] - (float)x1[k]; }
+    const unsigned col0 = (unsigned)x1[0] * 3u;
+    auto load_win = [&](int yy, unsigned (&w)[6]) {
+        const uint8_t *p = src + ((unsigned)yy * (unsigned)sstep + col0);      // (32-bit offsets: the launcher checks rows * step < 2^32)
+        // 7 aligned dwords around the window + a byte shift (the 4 bytes past the window stay inside the row: see the fast-path condition); unaligned 16 + 8 byte
+        // reads of the window itself cost 12 % more (the texture-address path works per aligned dword)
+        const unsigned sh0 = (unsigned)(uintptr_t)p & 3u;
+        const unsigned *q = reinterpret_cast<const unsigned *>(p - sh0);
+        uint4 a; unsigned b0, b1, b2;
+        __builtin_memcpy(&a, __builtin_assume_aligned(q, 4), 16);
+        b0 = q[4]; b1 = q[5]; b2 = q[6];
+        w[0] = __builtin_amdgcn_alignbyte(a.y, a.x, sh0); w[1] = __builtin_amdgcn_alignbyte(a.z, a.y, sh0); w[2] = __builtin_amdgcn_alignbyte(a.w, a.z, sh0);
+        w[3] = __builtin_amdgcn_alignbyte(b0, a.w, sh0); w[4] = __builtin_amdgcn_alignbyte(b1, b0, sh0); w[5] = __builtin_amdgcn_alignbyte(b2, b1, sh0);
+    };
+    // (the window's dwords by value: selects between array elements would be turned into indexed reads of a scratch copy)
+    auto taps = [&](unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned w4, unsigned w5, int k, unsigned &lo, unsigned &hi) {
+        if (k == 0) { lo = w0; hi = w1; }
+        else if (k == 1) {
+            const unsigned d0 = s1 ? w1 : w0, d1 = s1 ? w2 : w1;
+            lo = __builtin_amdgcn_alignbyte(d1, d0, sh1); hi = __builtin_amdgcn_alignbyte(w2, d1, sh1);
+        } else if (k == 2) {
+            const unsigned d0 = s2a ? w1 : (s2b ? w2 : w3), d1 = s2a ? w2 : (s2b ? w3 : w4);
+            lo = __builtin_amdgcn_alignbyte(d1, d0, sh2); hi = d1 >> (8u * sh2);
+        } else {
+            const unsigned d0 = s3 ? w2 : w3, d1 = s3 ? w3 : w4;
+            lo = __builtin_amdgcn_alignbyte(d1, d0, sh3); hi = __builtin_amdgcn_alignbyte(w5, d1, sh3);
+        }
+    };
+    // all source rows of the lane's output rows are read first (the second output row usually starts on the row the first one ends on: read once)
+    int y1[RS_ROWS], y2r[RS_ROWS];
+    float wy1[RS_ROWS], wy2[RS_ROWS];
+    bool live[RS_ROWS];
 #pragma unroll
     for (int r = 0; r < RS_ROWS; ++r) {
-        const int y = yb + r;
-        if (y >= drows) break;
+        const int y = min(yb + r, drows - 1);
+        live[r] = yb + r < drows;
         const float sy = (float)y * ify;
-        const int y1 = f2i_rd(sy), y2 = y1 + 1, y2r = min(y2, srows - 1);
-        const float wy2 = (float)y2 - sy, wy1 = sy - (float)y1;
-        unsigned w[2][6];
+        y1[r] = f2i_rd(sy);
+        y2r[r] = min(y1[r] + 1, srows - 1);
+        wy2[r] = (float)(y1[r] + 1) - sy; wy1[r] = sy - (float)y1[r];
+    }
+    unsigned W[RS_ROWS][2][6];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint8_t *p = row_ptr<uint8_t>(src, sstep, q ? y2r : y1) + col0;
-            uint4 a; uint2 b;
-            __builtin_memcpy(&a, p, 16); __builtin_memcpy(&b, p + 16, 8);
-            w[q][0] = a.x; w[q][1] = a.y; w[q][2] = a.z; w[q][3] = a.w; w[q][4] = b.x; w[q][5] = b.y;
-        }
+    for (int r = 0; r < RS_ROWS; ++r) {
+        if (r > 0 && y1[r] == y2r[r - 1]) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) W[r][0][i] = W[r - 1][1][i];
+        } else load_win(y1[r], W[r][0]);
+        load_win(y2r[r], W[r][1]);
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        if (!live[r]) break;
         unsigned o3[3] = {0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned lo[2], hi[2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const unsigned d0 = rs_sel4(w[q][0], w[q][1], w[q][2], w[q][3], di[k]), d1 = rs_sel4(w[q][1], w[q][2], w[q][3], w[q][4], di[k]),
-                               d2 = rs_sel4(w[q][2], w[q][3], w[q][4], w[q][5], di[k]);
-                lo[q] = __builtin_amdgcn_alignbyte(d1, d0, (unsigned)sh[k]);
-                hi[q] = __builtin_amdgcn_alignbyte(d2, d1, (unsigned)sh[k]);
-            }
-            const float w11 = wx2[k] * wy2, w12 = wx1[k] * wy2, w21 = wx2[k] * wy1, w22 = wx1[k] * wy1;
+            for (int q = 0; q < 2; ++q) taps(W[r][q][0], W[r][q][1], W[r][q][2], W[r][q][3], W[r][q][4], W[r][q][5], k, lo[q], hi[q]);
+            const float w11 = wx2[k] * wy2[r], w12 = wx1[k] * wy2[r], w21 = wx2[k] * wy1[r], w22 = wx1[k] * wy1[r];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float out = 0.f;
@@ -284,21 +328,25 @@ __global__ void __launch_bounds__(256) k_resize_linear3_x4(ResizeBatch T, size_t
                 o3[i >> 2] = sat_u8_into(out, (unsigned)(i & 3), o3[i >> 2]);
             }
         }
-        __builtin_memcpy(row_ptr<uint8_t>(dst, dstep, y) + (size_t)x0 * 3, o3, 12);
+        __builtin_memcpy(dst + ((unsigned)(yb + r) * (unsigned)dstep + (unsigned)x0 * 3u), o3, 12);
     }
 }
 int launch_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double fx, double fy, hipStream_t st)
 {
     if (!(fx > 0 && fy > 0)) { fx = (double)dst[0].cols / src[0].cols; fy = (double)dst[0].rows / src[0].rows; }
     const float ifx = (float)(1.0 / fx), ify = (float)(1.0 / fy);
-    const bool x4 = ifx >= 1.f && ifx <= 1.6f && src[0].cols >= 16 && getenv("MS_RESIZE_SIMPLE") == nullptr;      // downscales whose 4-pixel windows fit 24 bytes; else one pixel per lane
+    const unsigned lpr = (unsigned)div_up(dst[0].cols, 4);
+    const unsigned long long n_lanes = (unsigned long long)lpr * (unsigned)div_up(dst[0].rows, RS_ROWS);
+    // downscales whose 4-pixel windows fit 24 bytes (and images whose lane index times the row length fits 32 bits: the kernel's division); else one pixel per lane
+    const bool x4 = ifx >= 1.f && ifx <= 1.6f && src[0].cols >= 16 && n_lanes * lpr < 0x100000000ull &&
+                    (unsigned long long)src[0].rows * src[0].step < 0x100000000ull && (unsigned long long)dst[0].rows * dst[0].step < 0x100000000ull && getenv("MS_RESIZE_SIMPLE") == nullptr;
     for (int i0 = 0; i0 < n; i0 += RESIZE_BATCH) {
         const int m = std::min(RESIZE_BATCH, n - i0);
         ResizeBatch T{};
         for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
         if (x4) {
-            const dim3 g(div_up(div_up(dst[0].cols, 4), BX), div_up(div_up(dst[0].rows, RS_ROWS), BY), m);
-            k_resize_linear3_x4<<<g, dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx);
+            k_resize_linear3_x4<<<dim3(div_up((int)n_lanes, 256), 1, m), 256, 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx,
+                                                                                    lpr, (unsigned)(0x100000000ull / lpr), (unsigned)n_lanes);
         } else {
             const dim3 g2 = grid2d(dst[0].cols, dst[0].rows);
             k_resize_linear3_batch<<<dim3(g2.x, g2.y, m), dim3(BX, BY), 0, st>>>(T, src[0].step, src[0].rows, src[0].cols, dst[0].step, dst[0].rows, dst[0].cols, ify, ifx);

@@ -109,17 +109,49 @@ __device__ __forceinline__ void blend_taps(const Taps &t, const Px2 &r1, const P
         out[c] = o;
     }
 }
+// MS_PK_F32 = 0: the scalar forms, each fma kept a single v_fma_f32 (inline asm: plain -O3 would SLP-pack adjacent fmas back into v_pk_fma_f32)
+#ifndef MS_PK_F32
+#define MS_PK_F32 0      // measured (same box, 4 pairs of runs): k_warp_t 221.6 us packed, 219.7 us scalar per 16 frames -- v_pk_fma_f32 buys nothing per flop on this part
+#endif
+__device__ __forceinline__ float fma_single(float a, float b, float c)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void blend_taps_single(const Taps &t, const Px2 &r1, const Px2 &r2, float out[3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float o = fma_single(px_ch(r1, 0, c), t.w11, 0.f);
+        o = fma_single(px_ch(r1, 1, c), t.w12, o);
+        o = fma_single(px_ch(r2, 0, c), t.w21, o);
+        o = fma_single(px_ch(r2, 1, c), t.w22, o);
+        out[c] = o;
+    }
+}
 // gain * x for two values at once: fma(gain, x, 0) per half, exactly the scalar __builtin_fmaf(gain, x, 0.f)
 __device__ __forceinline__ f32x2 gain_pair(float gain, float a, float b)
 {
+#if MS_PK_F32
     f32x2 g, x, z = {0.f, 0.f};
     g.x = gain; g.y = gain; x.x = a; x.y = b;
     return __builtin_elementwise_fma(g, x, z);
+#else
+    f32x2 r;
+    r.x = fma_single(gain, a, 0.f); r.y = fma_single(gain, b, 0.f);
+    return r;
+#endif
 }
 // two samples at once: the same four fmas per channel, issued as v_pk_fma_f32 (two fp32 lanes per instruction)
 __device__ __forceinline__ void blend_taps2(const Taps ta, const Taps tb, const Px2 r1a, const Px2 r2a, const Px2 r1b, const Px2 r2b,
                                             float oa[3], float ob[3])
 {
+#if !MS_PK_F32
+    blend_taps_single(ta, r1a, r2a, oa);
+    blend_taps_single(tb, r1b, r2b, ob);
+    return;
+#endif
     f32x2 w11, w12, w21, w22;
     w11.x = ta.w11; w11.y = tb.w11; w12.x = ta.w12; w12.y = tb.w12;
     w21.x = ta.w21; w21.y = tb.w21; w22.x = ta.w22; w22.y = tb.w22;
@@ -775,11 +807,9 @@ struct Down7 { unsigned a[7]; };     // one input row (or a vertical sum of rows
 // u8 row, window bytes 8t-4 .. 8t+11 (d0..d3): a0 = (x,E0) a1 = (E1,E2) a2 = (E3,E4) a3 = (E5,x) a4 = (x,O0) a5 = (O1,O2) a6 = (O3,O4)
 __device__ __forceinline__ Down7 down_row(const Row11u8 &o, int t, int w)
 {
-    unsigned d0 = o.b.x, d1 = o.b.y, d2 = o.b.z, d3 = o.b.w;
-    if (t == 0) {                     // window starts at column 0: taps v0, v1 mirror to columns 2, 1 (BORDER_REFLECT_101)
-        d3 = d2; d2 = d1; d1 = d0;
-        d0 = __builtin_amdgcn_perm(0u, d1, 0x01020c0cu);     // byte2 <- col 2, byte3 <- col 1
-    }
+    unsigned d0 = o.b.x;
+    const unsigned d1 = o.b.y, d2 = o.b.z, d3 = o.b.w;
+    if (t == 0) d0 = __builtin_amdgcn_perm(0u, d1, 0x01020c0cu);     // columns -2, -1 (taps v0, v1) mirror to columns 2, 1 (BORDER_REFLECT_101): byte2 <- col 2, byte3 <- col 1
     Down7 r;
     r.a[0] = d0 & 0x00ff00ffu; r.a[1] = d1 & 0x00ff00ffu; r.a[2] = d2 & 0x00ff00ffu; r.a[3] = d3 & 0x00ff00ffu;
     r.a[4] = (d0 >> 8) & 0x00ff00ffu; r.a[5] = (d1 >> 8) & 0x00ff00ffu; r.a[6] = (d2 >> 8) & 0x00ff00ffu;
@@ -805,7 +835,7 @@ __device__ __forceinline__ unsigned down_hpass(const Down7 &v)
 // Input and output are both byte planes (level 0 = the gained warp output, levels >= 1 = the view's Gaussian levels: all in [0, 255]).
 // L0 only names the launch (level 0 vs the coarser levels) so that kernel traces tell them apart; the code is the same.
 template <bool L0>
-__global__ void __launch_bounds__(256) k_down_t(const DownTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int l,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) k_down_t(const DownTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int l,
                                                 const uint8_t *__restrict__ gin, long long in_stride,
                                                 uint8_t *__restrict__ gout, long long out_stride)
 {

@@ -47,6 +47,7 @@ struct Options {
     int recalib_every = 0, mesh_rows = 10, mesh_cols = 10, transport = MS_DIST_AUTO;
     double hfov = 90.0;
     bool share_gpu = false, cpw = false, checksum = true;
+    bool frame_sums = false;          // --frame-sums: print every frame's checksum on stderr (diagnostic)
 };
 
 // the pattern of video-stitcher_amd/synth.py (noise off), `variant` shifts the phase so that consecutive frames differ
@@ -360,6 +361,7 @@ int main(int argc, char **argv)
         else if (k == "--recalib-every") { o.cpw = true; o.recalib_every = atoi(next()); }
         else if (k == "--mesh") sscanf(next(), "%dx%d", &o.mesh_rows, &o.mesh_cols);
         else if (k == "--no-checksum") o.checksum = false;
+        else if (k == "--frame-sums") o.frame_sums = true;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     int ndev = 0;
@@ -382,6 +384,7 @@ int main(int argc, char **argv)
     if (!sh.failure.empty()) { fprintf(stderr, "stitch_dist: %s\n", sh.failure.c_str()); return 1; }
     unsigned long long all = 1469598103934665603ull;
     for (unsigned long long s : sh.frame_sums) all = fnv(reinterpret_cast<const unsigned char *>(&s), sizeof(s), all);
+    if (o.frame_sums) { for (size_t i = 0; i < sh.frame_sums.size(); ++i) fprintf(stderr, "frame %zu %016llx\n", i, sh.frame_sums[i]); }
     std::string devs = "[", pcis = "[", reads = "[";
     for (int r = 0; r < o.gpus; ++r) {
         devs += (r ? ", " : "") + std::to_string(sh.info.device[r]);
