@@ -366,6 +366,12 @@ MS_API int ms_stitch_finish(ms_ctx *ctx, int n_frames, const void *const *partia
 /* gpu_dst_mask_ (blenders.cpp:803): frame-invariant; 8UC1 pano-ROI sized DEVICE image owned by ctx. */
 MS_API int ms_get_result_mask(ms_ctx *ctx, ms_image *mask);
 
+/* Diagnostics of the band kernels' work classification (no reference counterpart: the reference runs the general arithmetic everywhere).  The 64 x 16 pixel cells
+ * of band `level` by class -- owned: one view with weight exactly 1 everywhere (no multiply, no division); exclusive (level 0 only): several views meet but every
+ * pixel has one contributing view with weight exactly 1 (binary seam masks) -- the same integer arithmetic, selected by the mask bytes; general: the reference's
+ * float multiply + divide.  Results are identical in every class (tests/test_compositor_gpu.py); bands without a map report every cell as general. */
+MS_API int ms_get_band_cells(ms_ctx *ctx, int level, unsigned *owned, unsigned *exclusive, unsigned *general);
+
 /* geometry read-back (top_/left_/bottom_/right_, x_tl_.., dst_roi_: blenders.hpp:143-175) */
 typedef struct ms_view_geom {
     ms_rect roi;                        /* corner + size of the warped view (warpRoi)        */

@@ -56,6 +56,44 @@ def test_stitch_matches_oracle(ms, cuda, oracle, rig, mask_mode):
     comp.close()
 
 
+def test_band_cell_classes_and_their_parity(ms, cuda, oracle):
+    """k_blend8 picks its arithmetic per 64 x 16 cell (ms_get_band_cells): owned cells (one view, weight 1) and, at level 0, exclusive cells (a seam runs through the
+    cell but every pixel has one contributing view with weight exactly 1: binary seam masks) use integers only; everything else the reference's float multiply and
+    divide.  All three classes must occur in these rigs and give the oracle's pixels: Voronoi seam masks (owned + exclusive), overlapping all-255 masks (two views
+    with weight 1 at a pixel: weight sum 2.00001 -> general) and masks with grey values (general)."""
+    rng = np.random.default_rng(11)
+    seen = {"owned": 0, "exclusive": 0, "general": 0}
+    for variant in ("voronoi", "overlap", "grey"):
+        comp, cfg, gains = make_rig(ms, "mini6", mask_mode=1 if variant == "voronoi" else 0)
+        if variant == "grey":
+            for i in range(cfg["n"]):
+                r = comp.view_geom(i).roi
+                m = np.full((r.height, r.width), 255, np.uint8)
+                m[:, : r.width // 3] = 0
+                m[::7, r.width // 2:] = 90                   # non-binary weights on some rows
+                comp.set_mask(i, m)
+            comp.init_blender()
+        o, e, g = comp.band_cells(0)
+        pg = comp.pano_geom()
+        assert o + e + g == -(-pg.dst_roi.width // 64) * -(-pg.dst_roi.height // 16)
+        if variant == "voronoi":
+            assert o > 0 and e > 0, (o, e, g)
+            inner = sum(comp.band_cells(l)[1] for l in range(1, pg.num_bands))
+            assert inner == 0, "exclusive cells exist at level 0 only (the coarser weights are fractional along the seams)"
+        else:
+            assert g > 0, (variant, o, e, g)
+        seen["owned"] += o; seen["exclusive"] += e; seen["general"] += g
+        frames_np = [synth.frame(cfg["w"], cfg["h"], i, 4) for i in range(cfg["n"])]
+        frames_np[0] = rng.integers(0, 256, frames_np[0].shape, dtype=np.uint8)      # noise: Laplacians of both signs and full range in every cell
+        out16 = torch.full((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), 5, dtype=torch.int16, device=cuda)
+        comp.stitch([[to_dev(f) for f in frames_np]], out16s=[out16])
+        torch.cuda.synchronize()
+        ref16, refmask = run_oracle(oracle, comp, cfg, gains, frames_np)
+        assert np.array_equal(host(out16), ref16), variant
+        comp.close()
+    assert all(v > 0 for v in seen.values()), seen
+
+
 def test_stitch_cpw_matches_oracle(ms, cuda, oracle):
     comp, cfg, gains = make_rig(ms, "mini6", enable_cpw=True)
     frames_np = [synth.frame(cfg["w"], cfg["h"], i, 3) for i in range(cfg["n"])]

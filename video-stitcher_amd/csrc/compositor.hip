@@ -717,6 +717,10 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
     // is exactly 1.00001f; 255 = general case.  Wave-uniform by construction (one byte per 64 x 16 cell).
     int owner = 255;
     if (MODE == 0 && P.pure[l]) owner = __builtin_amdgcn_readfirstlane((int)P.pure[l][(size_t)(y0 >> 4) * P.ppitch[l] + (x0 >> 6)]);
+    // 254 (level 0): a seam runs through the cell, but every pixel has exactly one contributing view with weight exactly 1 (binary masks): the owner
+    // arithmetic per pixel -- the Laplacian of each view ANDed with its mask bytes, no float multiply, no division (k_owner_map)
+    if (!L0 && owner == 254) owner = 255;                 // (never written for l > 0)
+    const bool excl = L0 && owner == 254, pure = owner < 254, integer_cell = owner != 255;
     // The accumulators are the reference's int16 `dst += (short)(v * w)` themselves: two pixels per register, added with the packed 16-bit
     // add (wraps per half exactly like `short +=`).  Pixel order of the four registers of a row: (0,2) (1,3) (4,6) (5,7), the order
     // the packed pyrUp produces.  Half as many accumulator registers = more waves in flight (the kernel waits on memory, not on VALU).
@@ -740,19 +744,26 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                     accp[c][r][3] = add_pk_u16(accp[c][r][3], __builtin_amdgcn_perm(b.w, b.z, 0x07060302u));
                 }
     }
-    for (unsigned vm = (MODE == 2) ? 0u : (MODE == 1 ? (T.view_mask & S.own_mask) : (owner != 255 ? (1u << owner) : T.view_mask)); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
+    for (unsigned vm = (MODE == 2) ? 0u : (MODE == 1 ? (T.view_mask & S.own_mask) : (pure ? (1u << owner) : T.view_mask)); vm; vm &= vm - 1) {   // views with a non-zero weight in this tile
         const int v = __builtin_ctz(vm);
         const LevelDesc &L = views[v].lv[l];
         const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
         if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
         float w[2][8];
-        if (owner != 255) {
+        unsigned mq[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};       // exclusive cells: 0xffff / 0 per pixel, in the accumulators' pixel order
+        if (pure) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[0][k] = w[1][k] = 1.f;       // (unused: the owner path adds L itself)
         } else if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
             const uint8_t *mp = views[v].wm0 + (mul24(ly, views[v].wm0_pitch) + (unsigned)lx);
             const uint2 ma = *reinterpret_cast<const uint2 *>(mp), mb = *reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch);
             if ((ma.x | ma.y | mb.x | mb.y) == 0u) continue;          // all 16 weights zero: (short)(L * 0) == 0
+            if (excl) {                                               // mask bytes are 0 / 255 here
+                mq[0][0] = __builtin_amdgcn_perm(0u, ma.x, 0x02020000u); mq[0][1] = __builtin_amdgcn_perm(0u, ma.x, 0x03030101u);
+                mq[0][2] = __builtin_amdgcn_perm(0u, ma.y, 0x02020000u); mq[0][3] = __builtin_amdgcn_perm(0u, ma.y, 0x03030101u);
+                mq[1][0] = __builtin_amdgcn_perm(0u, mb.x, 0x02020000u); mq[1][1] = __builtin_amdgcn_perm(0u, mb.x, 0x03030101u);
+                mq[1][2] = __builtin_amdgcn_perm(0u, mb.y, 0x02020000u); mq[1][3] = __builtin_amdgcn_perm(0u, mb.y, 0x03030101u);
+            }
             int m0[8], m1[8];
             unpack8(ma, m0); unpack8(mb, m1);
 #pragma unroll
@@ -805,7 +816,8 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                     // Laplacian L = g - up in [-255,255], formed as 256 + L per half (no borrow between the halves);
                     // |L*w| <= 255: neither saturate_cast of the reference chain (sub_mat.cu:59-65, multiband_blend.cu:46-49) can trigger
                     const unsigned d = (g[r][q] | 0x01000100u) - up[r][q];
-                    if (owner != 255) { accp[c][r][q] = sub_pk_u16(d, 0x01000100u); continue; }     // weight exactly 1: (short)(L * 1.f) == L
+                    if (pure) { accp[c][r][q] = sub_pk_u16(d, 0x01000100u); continue; }             // weight exactly 1: (short)(L * 1.f) == L
+                    if (excl) { accp[c][r][q] |= sub_pk_u16(d, 0x01000100u) & mq[r][q]; continue; }  // ... or exactly 0, per pixel; one view per pixel
                     const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
                     const int t0 = (int)((float)((int)(d & 0xffffu) - 256) * w[r][k0]);
                     const int t1 = (int)((float)((int)(d >> 16) - 256) * w[r][k1]);
@@ -845,7 +857,7 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rcp[r][k] = owner == 255 ? DivBy(den[r][k]).r : 1.f;
+        for (int k = 0; k < 8; ++k) rcp[r][k] = !integer_cell ? DivBy(den[r][k]).r : 1.f;
     // Results as int16 pairs in the accumulators' pixel order (register q of a row holds px (0,2) (1,3) (4,6) (5,7)): normalise, collapse and the
     // output conversion stay packed (v_pk_*_i16), two pixels per instruction.
     unsigned resq[3][2][4];
@@ -877,8 +889,8 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
             for (int q = 0; q < 4; ++q) {   // int16 accumulation wraps: (short)(sum) == successive `short +=`
                 const unsigned a = accp[c][r][q];
                 unsigned n;
-                if (owner != 255) {
-                    // owner cells: a / 1.00001f for an integer |a| <= 255 lies strictly between a - sign(a) and a, further than half an ulp from a,
+                if (integer_cell) {
+                    // owner (and exclusive) cells: a / 1.00001f for an integer |a| <= 255 lies strictly between a - sign(a) and a, further than half an ulp from a,
                     // so the correctly rounded quotient truncates to a - sign(a): the division is an integer subtraction there
                     n = sub_pk_u16(a, min_pk_i16(max_pk_i16(a, 0xffffffffu), 0x00010001u));
                 } else {
@@ -1198,7 +1210,8 @@ __global__ void __launch_bounds__(64) k_owner_map(const ViewDesc *__restrict__ v
     const int x0 = cx * 64, y0 = cy * 16;
     const int px = x0 + 16 * (lane & 3), py = y0 + (lane >> 2);      // 16 pixels of one row per lane
     int owner = -1, cnt = 0;
-    bool ones = false;
+    bool ones = false, binary = true, clash = false;
+    unsigned taken = 0u;                                     // pixels of this lane some view has claimed with a non-zero weight
     for (int v = 0; v < n_views; ++v) {
         const LevelDesc &L = views[v].lv[l];
         bool nz = false, one = true;
@@ -1210,10 +1223,19 @@ __global__ void __launch_bounds__(64) k_owner_map(const ViewDesc *__restrict__ v
             const float w = L.wgt[(size_t)ly * L.wpitch + lx];
             nz = nz || w != 0.f;
             one = one && w == 1.0f;
+            if (w != 0.f) {
+                binary = binary && w == 1.0f;
+                clash = clash || ((taken >> k) & 1u);
+                taken |= 1u << k;
+            }
         }
         if (__ballot(nz) != 0ull) { owner = v; ++cnt; ones = __ballot(!one) == 0ull; }
     }
-    if (lane == 0) pure[(size_t)cy * ppitch + cx] = (cnt == 1 && ones && x0 + 64 <= qw && y0 + 16 <= qh) ? (uint8_t)owner : (uint8_t)255;
+    const bool inside = x0 + 64 <= qw && y0 + 16 <= qh;
+    // 254 (level 0 only, where k_blend8 has the 8-bit masks): several views meet in the cell but every PIXEL has at most one non-zero weight and it is exactly 1.0f
+    // (binary seam masks: mask * (1/255) is 0 or 1) -- per pixel the same arithmetic as an owned cell, with the owner picked by the mask bytes
+    const bool exclusive = l == 0 && inside && __ballot(!binary || clash) == 0ull;
+    if (lane == 0) pure[(size_t)cy * ppitch + cx] = (cnt == 1 && ones && inside) ? (uint8_t)owner : (exclusive ? (uint8_t)254 : (uint8_t)255);
 }
 // ms_update_mask: the re-warped mask replaces the view's effective mask only while the mesh displaces by no more than the margin the work lists were
 // planned for (measured on the device by ms_set_mesh); otherwise the effective mask -- and with it every table derived from it -- stays as it was.
@@ -3307,6 +3329,25 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
     { std::lock_guard<std::mutex> mk(c->mesh_mu); active = c->tab_active; wait = c->tab_wait; }
     if (wait) MS_HIP(hipEventSynchronize(c->tab_ready));
     *m = ms_image{active == 1 ? c->alt.result_mask.p : c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
+    return MS_OK;
+}
+
+int ms_get_band_cells(ms_ctx *c, int level, unsigned *owned, unsigned *exclusive, unsigned *general)
+{
+    if (!c || !owned || !exclusive || !general) return fail(MS_ERR_INVALID, "null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_band_cells: call ms_init_blender first");
+    MS_CHECK(level >= 0 && level < c->pano.nb, "ms_get_band_cells: band %d not in [0, %d)", level, c->pano.nb);
+    int active; bool wait;
+    { std::lock_guard<std::mutex> mk(c->mesh_mu); active = c->tab_active; wait = c->tab_wait; }
+    if (wait) MS_HIP(hipEventSynchronize(c->tab_ready));
+    const int pw_ = div_up(c->pano.qw[level], 64), ph_ = div_up(c->pano.qh[level], 16);
+    *owned = *exclusive = 0; *general = (unsigned)(pw_ * ph_);
+    if (!c->pure_off[level]) return MS_OK;
+    std::vector<uint8_t> h((size_t)pw_ * ph_);
+    const uint8_t *src = (const uint8_t *)(active == 1 ? c->alt.pure_maps.p : c->pure_maps.p) + (c->pure_off[level] - 1);
+    MS_HIP(hipMemcpy(h.data(), src, h.size(), hipMemcpyDeviceToHost));
+    *general = 0;
+    for (uint8_t b : h) { if (b == 255) ++*general; else if (b == 254) ++*exclusive; else ++*owned; }
     return MS_OK;
 }
 

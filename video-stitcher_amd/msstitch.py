@@ -89,7 +89,7 @@ EXPORTS = [
     "ms_bitwise_and_8u", "ms_dilate3x3_8u", "ms_build_warp_maps", "ms_custom_resize_32f", "ms_warp_roi", "ms_result_roi",
     "ms_calibrate_cameras", "ms_num_bands_rule", "ms_orb_default_params", "ms_orb_detect_and_compute", "ms_find_homography_ransac", "ms_feature_mask",
     "ms_create", "ms_destroy", "ms_set_camera", "ms_set_gain", "ms_build_maps", "ms_build_masks", "ms_set_mask",
-    "ms_init_blender", "ms_set_mesh", "ms_set_meshes", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_view_geom",
+    "ms_init_blender", "ms_set_mesh", "ms_set_meshes", "ms_set_mesh_maps", "ms_stitch", "ms_get_result_mask", "ms_get_band_cells", "ms_get_view_geom",
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
@@ -704,6 +704,12 @@ class Compositor:
         m = Image()
         _chk(load().ms_get_result_mask(self._ctx, C.byref(m)))
         return tensor_of(m)
+
+    def band_cells(self, level):
+        """(owned, exclusive, general) 64 x 16 cells of a band: see ms_get_band_cells."""
+        a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+        _chk(load().ms_get_band_cells(self._ctx, level, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def _tables(self, frames, out8u, out16s):
         n_frames = len(frames)
