@@ -165,6 +165,16 @@ __device__ __forceinline__ int rne_shift(int s, int k)
 
 // row * pitch for index arithmetic, both below 2^24: the full-rate 24-bit multiplier (v_mul_u32_u24 / v_mad_u32_u24) instead of the quarter-rate
 // v_mul_lo_u32 / v_mad_u64_u32 the compiler emits for int * int and (size_t) * int
+// per-half logical shift right of two packed 16-bit values (v_pk_lshrrev_b16): no bits move from the high half into the low one, so no mask afterwards
+typedef unsigned short ms_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_lshr16(unsigned x, unsigned n)
+{
+    ms_u16x2 v;
+    __builtin_memcpy(&v, &x, 4);
+    v >>= (unsigned short)n;
+    __builtin_memcpy(&x, &v, 4);
+    return x;
+}
 __device__ __forceinline__ unsigned mul24(int a, int b) { return __umul24((unsigned)a, (unsigned)b); }
 
 // acc + 6 x with two full-rate v_lshl_add_u32 (x + 2x, then acc + 2 (3x)) instead of the quarter-rate v_mul_lo_u32 the compiler picks for

@@ -583,8 +583,8 @@ __device__ __forceinline__ void up_2x8(const int16_t *__restrict__ cs, int cpitc
 // and plain 32-bit adds/shifts never carry from one half into the other.  Results are identical to up_2x8.
 __device__ __forceinline__ unsigned rne6_pk(unsigned s)
 {
-    const unsigned t = (s >> 6) & 0x00010001u;
-    return ((s + t + 0x001f001fu) >> 6) & 0x03ff03ffu;
+    const unsigned t = pk_lshr16(s, 6) & 0x00010001u;
+    return pk_lshr16(s + t + 0x001f001fu, 6);          // (the halves stay below 2^16: the 32-bit add carries nothing across)
 }
 // pixel order of the four output registers of a row: (0,2) (1,3) (4,6) (5,7)  [low half, high half]
 __device__ __forceinline__ void up_rows_load(const int16_t *__restrict__ cs, int cpitch, int ch, int i, int j0, uint4 raw[3])
@@ -815,9 +815,9 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                 for (int q = 0; q < 4; ++q) {
                     // Laplacian L = g - up in [-255,255], formed as 256 + L per half (no borrow between the halves);
                     // |L*w| <= 255: neither saturate_cast of the reference chain (sub_mat.cu:59-65, multiband_blend.cu:46-49) can trigger
+                    if (pure) { accp[c][r][q] = sub_pk_u16(g[r][q], up[r][q]); continue; }             // weight exactly 1: (short)(L * 1.f) == L (one packed subtract)
+                    if (excl) { accp[c][r][q] |= sub_pk_u16(g[r][q], up[r][q]) & mq[r][q]; continue; }  // ... or exactly 0, per pixel; one view per pixel
                     const unsigned d = (g[r][q] | 0x01000100u) - up[r][q];
-                    if (pure) { accp[c][r][q] = sub_pk_u16(d, 0x01000100u); continue; }             // weight exactly 1: (short)(L * 1.f) == L
-                    if (excl) { accp[c][r][q] |= sub_pk_u16(d, 0x01000100u) & mq[r][q]; continue; }  // ... or exactly 0, per pixel; one view per pixel
                     const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
                     const int t0 = (int)((float)((int)(d & 0xffffu) - 256) * w[r][k0]);
                     const int t1 = (int)((float)((int)(d >> 16) - 256) * w[r][k1]);

@@ -818,8 +818,8 @@ __device__ __forceinline__ Down7 down_row(const Row11u8 &o, int t, int w)
 }
 __device__ __forceinline__ unsigned rne8_pk(unsigned s)
 {
-    const unsigned t = (s >> 8) & 0x00010001u;
-    return ((s + t + 0x007f007fu) >> 8) & 0x00ff00ffu;
+    const unsigned t = pk_lshr16(s, 8) & 0x00010001u;
+    return pk_lshr16(s + t + 0x007f007fu, 8);          // (sums <= 65280 + 128: the halves stay below 2^16)
 }
 // horizontal pass on a vertical sum; returns the four outputs as bytes of one dword (each is <= 255)
 __device__ __forceinline__ unsigned down_hpass(const Down7 &v)
