@@ -40,7 +40,7 @@ def main(tag):
     clk = 2.33e9
     rows = []
     for k, v in traffic["kernels"].items():
-        if k in ("k_warp", "k_blend_l0", "k_down_l0", "k_remap_gain") or v["launches"] < 20 or "calib" in k or not k.startswith(("k_warp_t", "k_blend", "k_down", "k_stage1", "k_remap", "k_single")):      # (aliases, calibration-time kernels)
+        if k in ("k_warp", "k_blend_l0", "k_down_l0", "k_remap_gain") or v["launches"] < 20 or "calib" in k or not k.startswith(("k_warp_t", "k_blend", "k_down", "k_stage1", "k_remap", "k_single", "k_resize_linear3")):      # (aliases, calibration-time kernels)
             continue
         c = next((d for n, d in ctr.items() if short(n) == k), {})
         waves = c.get("SQ_WAVES", 0)
@@ -50,13 +50,15 @@ def main(tag):
         occ = c.get("SQ_WAVE_CYCLES", 0) * 4 / (c.get("_us", us) * 1e-6 * clk) / 1024 if c.get("SQ_WAVE_CYCLES") else None
         rows.append((us * v["launches"], k, v["launches"], us, v["hbm_bytes_per_launch"], waves, valu / waves if waves else None, busy, occ))
     rows.sort(reverse=True)
+    # launches per ms_stitch call: 1 for the per-frame kernels of the compositor; the per-frame resize of the shipped configuration needs ceil(views x F / 64) launches per call
+    calls = max([r[2] for r in rows if r[1].startswith(("k_warp_t", "k_stage1_t"))] or [1])
     lines = ["# Per-kernel report (%s): %s, %d frames per launch, one context / one stream" % (tag, traffic.get("config", "cfg2"), F), "",
              "Sources: `%s_kernel_trace.txt`/`%s_traffic.json` (rocprofv3 kernel trace; FETCH_SIZE x2.0 + WRITE_SIZE x1.0, calibrated on a 1 GiB copy),"
              " `%s_counters.txt` (SQ counters), `%s_bench.json` (bench.py line).  VALU busy = VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.33 GHz)." % (tag, tag, tag, tag), "",
              "| kernel | mean launch µs | µs / frame | HBM MB / launch | HBM TB/s | waves | VALU / wave | VALU busy | waves / SIMD |", "|---|---|---|---|---|---|---|---|---|"]
     for _, k, n, us, hb, waves, vpw, busy, occ in rows:
         lines.append("| `%s` | %.1f | %.2f | %.0f | %.2f | %s | %s | %s | %s |" % (
-            k, us, us / F, hb / 1e6, hb / (us * 1e-6) / 1e12, "%d" % waves if waves else "-", "%.0f" % vpw if vpw else "-",
+            k + (" (x %d per call)" % round(n / calls) if n > 1.5 * calls and k.startswith("k_resize") else ""), us, us * max(1, round(n / calls)) / F if k.startswith("k_resize") else us / F, hb / 1e6, hb / (us * 1e-6) / 1e12, "%d" % waves if waves else "-", "%.0f" % vpw if vpw else "-",
             "%.2f" % busy if busy is not None else "-", "%.1f" % occ if occ is not None else "-"))
     r = bench["roofline"]
     lines += ["", "bench.py: **%.0f frames/s** (%s); dominant kernel `%s`: %.0f MB of PMC-measured HBM traffic / %.1f µs = %.0f GB/s = **%.3f of 8 TB/s** (physical; %s); "

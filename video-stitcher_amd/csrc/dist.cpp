@@ -149,18 +149,22 @@ struct ms_dist {
 namespace ms {
 namespace {
 
-int copy_in(void *dst_host, const void *src, size_t n, int mem)      // user buffer -> mailbox slot
+// Device buffers move on the operation's OWN stream and the host waits for that stream: the data is then ordered with what the caller enqueues next on it
+// (a plain hipMemcpy runs on the NULL stream, which a non-blocking stream does not wait for) and the mailbox slot is free / filled when the call returns.
+int copy_in(void *dst_host, const void *src, size_t n, int mem, hipStream_t st)      // user buffer -> mailbox slot
 {
     if (n == 0) return MS_OK;
-    if (mem == MS_DIST_MEM_HOST) memcpy(dst_host, src, n);
-    else MS_HIP(hipMemcpy(dst_host, src, n, hipMemcpyDeviceToHost));
+    if (mem == MS_DIST_MEM_HOST) { memcpy(dst_host, src, n); return MS_OK; }
+    MS_HIP(hipMemcpyAsync(dst_host, src, n, hipMemcpyDeviceToHost, st));
+    MS_HIP(hipStreamSynchronize(st));
     return MS_OK;
 }
-int copy_out(void *dst, const void *src_host, size_t n, int mem)     // mailbox slot -> user buffer
+int copy_out(void *dst, const void *src_host, size_t n, int mem, hipStream_t st)     // mailbox slot -> user buffer
 {
     if (n == 0) return MS_OK;
-    if (mem == MS_DIST_MEM_HOST) memcpy(dst, src_host, n);
-    else MS_HIP(hipMemcpy(dst, src_host, n, hipMemcpyHostToDevice));
+    if (mem == MS_DIST_MEM_HOST) { memcpy(dst, src_host, n); return MS_OK; }
+    MS_HIP(hipMemcpyAsync(dst, src_host, n, hipMemcpyHostToDevice, st));
+    MS_HIP(hipStreamSynchronize(st));
     return MS_OK;
 }
 
@@ -174,7 +178,7 @@ int host_step(ms_dist *d, Op &op, bool *moved)
     if (op.send) {
         if (h != t) return MS_OK;                                   // the slot still holds a piece the peer has not taken
         const size_t n = std::min(CHUNK, op.bytes - op.done);
-        if (int e = copy_in(c->data, op.buf + op.done, n, op.mem)) return e;
+        if (int e = copy_in(c->data, op.buf + op.done, n, op.mem, op.st)) return e;
         c->len = n;
         c->head.store(h + 1, std::memory_order_release);
         op.done += n;
@@ -182,7 +186,7 @@ int host_step(ms_dist *d, Op &op, bool *moved)
         if (h == t) return MS_OK;                                   // nothing there yet
         const size_t n = (size_t)c->len;
         if (n > op.bytes - op.done) return fail(MS_ERR_COMM, "ms_dist: rank %d receives %zu bytes from rank %d but %zu were posted (mismatched send / recv sizes)", d->rank, n, op.peer, op.bytes - op.done);
-        if (int e = copy_out(op.buf + op.done, c->data, n, op.mem)) return e;
+        if (int e = copy_out(op.buf + op.done, c->data, n, op.mem, op.st)) return e;
         c->tail.store(t + 1, std::memory_order_release);
         op.done += n;
     }
@@ -449,7 +453,11 @@ int ms_dist_group_end(ms_dist *d)
         for (size_t j = 0; j < ops.size(); ++j)
             if (!ops[j].send && ops[j].peer == d->rank && !ops[j].finished && ops[j].bytes == ops[i].bytes) {
                 if (ops[i].mem == MS_DIST_MEM_HOST && ops[j].mem == MS_DIST_MEM_HOST) memcpy(ops[j].buf, ops[i].buf, ops[i].bytes);
-                else MS_HIP(hipMemcpy(ops[j].buf, ops[i].buf, ops[i].bytes, hipMemcpyDefault));
+                else {      // behind what produced the source, on the receive's stream, complete on return (as the mailbox path)
+                    if (ops[i].mem == MS_DIST_MEM_DEVICE && ops[i].st != ops[j].st) MS_HIP(hipStreamSynchronize(ops[i].st));
+                    MS_HIP(hipMemcpyAsync(ops[j].buf, ops[i].buf, ops[i].bytes, hipMemcpyDefault, ops[j].st));
+                    MS_HIP(hipStreamSynchronize(ops[j].st));
+                }
                 ops[i].finished = ops[j].finished = true;
                 break;
             }
