@@ -540,13 +540,28 @@ def main():
     D, dist_info = None, None
     if world > 1:
         import msdist
-        try:
-            box = [msdist.unique_id(world, msdist.HOST if share else msdist.RCCL) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            D = msdist.Dist(rank, world, box[0], device=local_rank)
-            dist_info = D.info()
-        except Exception as e:      # the bench line must survive a transport that does not come up: fall back to torch.distributed.gather, and SAY so
-            D, dist_info = None, {"transport": "torch.distributed (ms_dist did not come up: %s)" % str(e)[:160]}
+        # The bring-up is decided by ALL ranks together: rank 0's id (or its failure) is broadcast, and after the collective creation the ranks agree (MIN over a flag)
+        # on whether every one of them has a communicator -- a rank that fell back alone would wait for ever in the first gather.
+        why = None
+        box = [None]
+        if rank == 0:
+            try:
+                box = [msdist.unique_id(world, msdist.HOST if share else msdist.RCCL)]
+            except Exception as e:
+                why = str(e)[:160]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is not None:
+            try:
+                D = msdist.Dist(rank, world, box[0], device=local_rank)
+                dist_info = D.info()
+            except Exception as e:
+                D, why = None, str(e)[:160]
+        flag = torch.tensor([1 if D is not None else 0], dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:      # the bench line must survive a transport that does not come up: fall back to torch.distributed.gather, and SAY so
+            if D is not None:
+                D.close()
+            D, dist_info = None, {"transport": "torch.distributed (ms_dist did not come up on every rank: %s)" % (why or "another rank failed")}
 
     shipped = args.config == "shipped"
     cpw = args.config in ("cfg3", "shipped")

@@ -132,3 +132,34 @@ def test_device_buffers_through_the_binding(ms, cuda):
     [t.start() for t in ts]; [t.join(timeout=180) for t in ts]
     assert not errs, errs
     assert res == {0: (41, 41, 8), 1: (40, 40, None)}
+
+
+def test_rccl_communicator_beside_torchs_nccl_process_group(cuda):
+    """bench.py --gpus N keeps torch.distributed (backend "nccl" = RCCL) for the barrier / max-over-ranks of the bench contract and moves the slabs through ms_dist's own
+    RCCL communicator: both live in one process.  One rank is all a one-GPU box offers -- the two communicators are created, used and destroyed side by side in a
+    child process (torch's process group cannot be re-created inside pytest's)."""
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.path.join(%r, "video-stitcher_amd"))
+import torch.distributed as dist
+import msdist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+t = torch.ones(8, device="cuda"); dist.all_reduce(t); dist.barrier()
+box = [msdist.unique_id(1, msdist.RCCL)]
+dist.broadcast_object_list(box, src=0)
+d = msdist.Dist(0, 1, box[0], device=0)
+info = d.info()
+a = torch.arange(1 << 18, dtype=torch.int32, device="cuda"); b = torch.zeros_like(a)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    d.group_begin(); d.send(a, 0); d.recv(b, 0); d.group_end()
+side.synchronize()
+dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
+assert torch.equal(a, b) and float(t[0]) == 1.0 and info["transport"] == "rccl" and info["comm_nranks"] == 1
+d.close(); dist.destroy_process_group()
+print("OK", info["rccl_version"])
+''' % ROOT
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, timeout=300)
+    assert out.returncode == 0 and b"OK" in out.stdout, (out.stdout.decode()[-500:], out.stderr.decode()[-1500:])

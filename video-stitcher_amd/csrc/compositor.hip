@@ -716,7 +716,13 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
     // owner of this wave's cell: the one view with non-zero weights there, all exactly 1 -- then (short)(L * 1.f) = L and the weight sum
     // is exactly 1.00001f; 255 = general case.  Wave-uniform by construction (one byte per 64 x 16 cell).
     int owner = 255;
-    if (MODE == 0 && P.pure[l]) owner = __builtin_amdgcn_readfirstlane((int)P.pure[l][(size_t)(y0 >> 4) * P.ppitch[l] + (x0 >> 6)]);
+    if (MODE == 0 && P.pure[l]) {
+        // the cell index is made of scalars only (tile record, blockIdx.y): the byte comes through the scalar cache as part of its aligned dword (build_plan aligns every
+        // band's map to 4 bytes) instead of a per-lane load + readfirstlane -- one vector-memory round trip less before the wave knows which path it takes
+        const unsigned ci = (unsigned)(T.y0 >> 4) * (unsigned)P.ppitch[l] + (unsigned)((T.x0 >> 6) + (int)blockIdx.y);
+        const unsigned word = reinterpret_cast<const unsigned *>(P.pure[l])[ci >> 2];
+        owner = (int)((word >> (8u * (ci & 3u))) & 0xffu);
+    }
     // 254 (level 0): a seam runs through the cell, but every pixel has exactly one contributing view with weight exactly 1 (binary masks): the owner
     // arithmetic per pixel -- the Laplacian of each view ANDed with its mask bytes, no float multiply, no division (k_owner_map)
     if (!L0 && owner == 254) owner = 255;                 // (never written for l > 0)
@@ -1936,7 +1942,7 @@ static int build_plan(ms_ctx *c)
         const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
         c->pure_off[l] = c->pure_total + 1;          // (+1: 0 means "no map")
         c->pano.ppitch[l] = pw_;
-        c->pure_total += (size_t)pw_ * ph_;
+        c->pure_total += ((size_t)pw_ * ph_ + 3) & ~(size_t)3;        // (k_blend8 reads a cell's byte as part of its aligned dword)
     }
     if (c->pure_total) {
         if (int e = c->pure_maps.alloc(c->pure_total)) return e;
