@@ -699,7 +699,7 @@ __device__ __forceinline__ bool up_2x8_pkb(const uint4 raw[3], int cw, int j0, u
     return true;
 }
 
-template <bool L0, int MODE>
+template <bool L0, int MODE, int CLS = 0>      // CLS 1: only the integer cells (owned + exclusive) of the band, 2: only the general ones, 0: all
 __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__restrict__ tiles, const ViewDesc *__restrict__ views, PanoDesc P, int l,
                                                 const uint8_t *__restrict__ g0, long long g0_stride,
                                                 const uint8_t *__restrict__ gl, long long gl_stride,
@@ -726,7 +726,8 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
     // 254 (level 0): a seam runs through the cell, but every pixel has exactly one contributing view with weight exactly 1 (binary masks): the owner
     // arithmetic per pixel -- the Laplacian of each view ANDed with its mask bytes, no float multiply, no division (k_owner_map)
     if (!L0 && owner == 254) owner = 255;                 // (never written for l > 0)
-    const bool excl = L0 && owner == 254, pure = owner < 254, integer_cell = owner != 255;
+    const bool excl = L0 && owner == 254, pure = owner < 254, integer_cell = CLS == 1 || (CLS != 2 && owner != 255);
+    if ((CLS == 1 && owner == 255) || (CLS == 2 && owner != 255)) return;
     // The accumulators are the reference's int16 `dst += (short)(v * w)` themselves: two pixels per register, added with the packed 16-bit
     // add (wraps per half exactly like `short +=`).  Pixel order of the four registers of a row: (0,2) (1,3) (4,6) (5,7), the order
     // the packed pyrUp produces.  Half as many accumulator registers = more waves in flight (the kernel waits on memory, not on VALU).
@@ -764,18 +765,19 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
             const uint8_t *mp = views[v].wm0 + (mul24(ly, views[v].wm0_pitch) + (unsigned)lx);
             const uint2 ma = *reinterpret_cast<const uint2 *>(mp), mb = *reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch);
             if ((ma.x | ma.y | mb.x | mb.y) == 0u) continue;          // all 16 weights zero: (short)(L * 0) == 0
-            if (excl) {                                               // mask bytes are 0 / 255 here
+            if (excl || CLS == 1) {                                   // mask bytes are 0 / 255 here
                 mq[0][0] = __builtin_amdgcn_perm(0u, ma.x, 0x02020000u); mq[0][1] = __builtin_amdgcn_perm(0u, ma.x, 0x03030101u);
                 mq[0][2] = __builtin_amdgcn_perm(0u, ma.y, 0x02020000u); mq[0][3] = __builtin_amdgcn_perm(0u, ma.y, 0x03030101u);
                 mq[1][0] = __builtin_amdgcn_perm(0u, mb.x, 0x02020000u); mq[1][1] = __builtin_amdgcn_perm(0u, mb.x, 0x03030101u);
                 mq[1][2] = __builtin_amdgcn_perm(0u, mb.y, 0x02020000u); mq[1][3] = __builtin_amdgcn_perm(0u, mb.y, 0x03030101u);
-            }
-            int m0[8], m1[8];
-            unpack8(ma, m0); unpack8(mb, m1);
+            } else {
+                int m0[8], m1[8];
+                unpack8(ma, m0); unpack8(mb, m1);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                w[0][k] = __builtin_fmaf(P.alpha, (float)m0[k], 0.f);
-                w[1][k] = __builtin_fmaf(P.alpha, (float)m1[k], 0.f);
+                for (int k = 0; k < 8; ++k) {
+                    w[0][k] = __builtin_fmaf(P.alpha, (float)m0[k], 0.f);
+                    w[1][k] = __builtin_fmaf(P.alpha, (float)m1[k], 0.f);
+                }
             }
         } else {
             const float *wp = L.wgt + (mul24(ly, L.wpitch) + (unsigned)lx);
@@ -822,7 +824,7 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                     // Laplacian L = g - up in [-255,255], formed as 256 + L per half (no borrow between the halves);
                     // |L*w| <= 255: neither saturate_cast of the reference chain (sub_mat.cu:59-65, multiband_blend.cu:46-49) can trigger
                     if (pure) { accp[c][r][q] = sub_pk_u16(g[r][q], up[r][q]); continue; }             // weight exactly 1: (short)(L * 1.f) == L (one packed subtract)
-                    if (excl) { accp[c][r][q] |= sub_pk_u16(g[r][q], up[r][q]) & mq[r][q]; continue; }  // ... or exactly 0, per pixel; one view per pixel
+                    if (excl || CLS == 1) { accp[c][r][q] |= sub_pk_u16(g[r][q], up[r][q]) & mq[r][q]; continue; }  // ... or exactly 0, per pixel; one view per pixel
                     const unsigned d = (g[r][q] | 0x01000100u) - up[r][q];
                     const int k0 = (q >> 1) * 4 + (q & 1), k1 = k0 + 2;
                     const int t0 = (int)((float)((int)(d & 0xffffu) - 256) * w[r][k0]);
@@ -847,7 +849,7 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
         return;
     }
     float den[2][8];
-    if (owner == 255) {
+    if (!integer_cell) {
         const float *dp = P.den[l] + (mul24(y0, P.dpitch[l]) + (unsigned)x0);
         const float4 da = *reinterpret_cast<const float4 *>(dp), db = *reinterpret_cast<const float4 *>(dp + 4);
         const float4 dc = *reinterpret_cast<const float4 *>(dp + P.dpitch[l]), dd = *reinterpret_cast<const float4 *>(dp + P.dpitch[l] + 4);
@@ -1570,6 +1572,8 @@ struct ms_ctx {
     bool tab_wait = false;
     DevBuf mask_tmp, wm_scratch;       // re-warped mask / float weight map of the largest view
     size_t w_total = 0, wm0_total = 0, den_total = 0, pure_total = 0, pure_off[MAX_LEVELS] = {};
+    bool l0_integer_only = false;      // level 0 has an owner map without a single general cell (binary, exclusive seam masks): k_blend8's integer-only build (88 VGPRs) runs it;
+                                       // counted when build_plan makes the map, dropped by the first enqueue-only mask update (whose maps the host never sees)
     bool use_eff[MAX_VIEWS] = {};
     DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
     DevBuf disp_dev;                   // [view][mesh buffer]: max |mesh map - identity| as float bits, written by ms_set_mesh
@@ -1949,6 +1953,12 @@ static int build_plan(ms_ctx *c)
         for (int l = 0; l < nb; ++l) if (c->pure_off[l]) c->pano.pure[l] = (const uint8_t *)c->pure_maps.p + (c->pure_off[l] - 1);
         if (int e = launch_owner_maps(c, (const ViewDesc *)c->view_tab.p, (uint8_t *)c->pure_maps.p, nullptr)) return e;
         MS_HIP(hipStreamSynchronize(nullptr));
+    }
+    c->l0_integer_only = false;
+    if (c->pure_off[0]) {
+        std::vector<uint8_t> h((size_t)div_up(c->pano.qw[0], 64) * div_up(c->pano.qh[0], 16));
+        MS_HIP(hipMemcpy(h.data(), (const uint8_t *)c->pure_maps.p + (c->pure_off[0] - 1), h.size(), hipMemcpyDeviceToHost));
+        c->l0_integer_only = std::find(h.begin(), h.end(), (uint8_t)255) == h.end();
     }
     return MS_OK;
 }
@@ -2848,6 +2858,7 @@ static int update_mask_async(ms_ctx *c, int view, hipStream_t st)
         std::lock_guard<std::mutex> mk(c->mesh_mu);
         MS_HIP(hipEventRecord(c->tab_ready, st));
         c->tab_active = from ^ 1; c->tab_wait = true;
+        c->l0_integer_only = false;
         // the re-warp above READS this view's mesh slot and displacement entry: later mesh updates (any stream) are ordered behind it through the
         // chain event they all wait for, so the second ms_set_mesh from now cannot overwrite the slot under the re-warp
         if (c->mesh_chain) { MS_HIP(hipEventRecord(c->mesh_chain, st)); c->mesh_chain_set = true; }
@@ -3000,6 +3011,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         }
     }
 
+    const bool int_only = c->l0_integer_only && P.pure[0] != nullptr;      // (read under mesh_mu, like the table pointers: an enqueue-only mask update clears it)
+
     // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
     // (the reference makes a fresh cuda::Stream per stitch_online call, timed.cpp:64, and relies on the NULL stream for ordering)
     if (c->last_stream_set && c->last_stream != st && c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
@@ -3139,7 +3152,10 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     for (int l = l_first; l >= 0; --l) {
         if (c->blend_vec[l] && c->cfg.debug_simple_kernels == 0) {
             const dim3 g(c->n_blend_tiles[l], 4, F), b(32, 2);
-            if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            static const bool no_cls = [] { const char *e = getenv("MS_BLEND_CLS"); return e && atoi(e) == 0; }();      // MS_BLEND_CLS=0: always the all-classes build (A/B)
+            // level 0 without general cells (the usual case: binary Voronoi seam masks): the build that has no general path -- 88 instead of 120 VGPRs, 5 waves per SIMD
+            if (l == 0 && S.mode == 0 && int_only && !no_cls) k_blend8<true, 0, 1><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            else if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else        MS_MODE_LAUNCH2(k_blend8, false, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         } else {
             const dim3 g(div_up(P.qw[l] / 2, 64), div_up(P.qh[l] / 2, 4), F);
