@@ -544,25 +544,18 @@ __device__ __forceinline__ uint2 load8_a1(const void *p)
     __builtin_memcpy(&r, p, 8);
     return r;
 }
-// pyrUp of the 2x8 fine block whose top-left is (2i, 2*j0) (j0 % 4 == 0, cw % 4 == 0) from one coarse plane.
-// One 16-byte load per coarse row: columns j0-2 .. j0+5 cover the 6 taps j0-1 .. j0+4 (at j0 == 0 the window
-// starts at 0 and column -1 mirrors to 1; past the right edge column cw clamps to cw-1).  The load may run two
-// int16 past the end of a row: rows are contiguous inside buffers that carry 64 bytes of slack.
-__device__ __forceinline__ void up_2x8(const int16_t *__restrict__ cs, int cpitch, int ch, int cw, int i, int j0,
-                                       int ue[8], int uo[8])
+// pyrUp of the 2x8 fine block whose top-left is (2i, 2*j0) (j0 % 4 == 0, cw % 4 == 0) in plain 32-bit arithmetic, from the three coarse rows ALREADY in registers
+// (up_rows_load: columns j0-2 .. j0+5 cover the 6 taps j0-1 .. j0+4; at j0 == 0 column -1 mirrors to 1, past the right edge column cw clamps to cw-1).
+// The fallback of up_2x8_pkb for collapsed values outside the packed range.  It deliberately issues no load of its own: a load inside this rarely taken branch
+// makes the wait-count pass assume the worst at the join, and the planes' software pipeline (next plane's rows in flight) degrades to "wait for everything".
+__device__ __forceinline__ void up_2x8_raw(const uint4 raw[3], int cw, int j0, int ue[8], int uo[8])
 {
-    const int rr[3] = {pu_idx(i - 1, ch), pu_idx(i, ch), pu_idx(i + 1, ch)};
-    const int jb = max(j0 - 2, 0);
-    uint4 raw[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) raw[r] = load16_a4(cs + (size_t)rr[r] * cpitch + jb);
     int he[3][4], ho[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         int v[8], a[6];
         unpack8(raw[r], v);
-        if (j0 == 0) { a[0] = v[1]; a[1] = v[0]; a[2] = v[1]; a[3] = v[2]; a[4] = v[3]; a[5] = v[4]; }
-        else { a[0] = v[1]; a[1] = v[2]; a[2] = v[3]; a[3] = v[4]; a[4] = v[5]; a[5] = v[6]; }
+        a[0] = j0 == 0 ? v[3] : v[1]; a[1] = v[2]; a[2] = v[3]; a[3] = v[4]; a[4] = v[5]; a[5] = v[6];
         if (j0 + 4 >= cw) a[5] = a[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { he[r][q] = a[q] + 6 * a[q + 1] + a[q + 2]; ho[r][q] = 4 * (a[q + 1] + a[q + 2]); }
@@ -763,7 +756,9 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
             for (int k = 0; k < 8; ++k) w[0][k] = w[1][k] = 1.f;       // (unused: the owner path adds L itself)
         } else if (L0) {   // level-0 weights are mask * (1/255) (blenders.cpp:412): rebuilt from the padded 8-bit mask, 1 byte/px
             const uint8_t *mp = views[v].wm0 + (mul24(ly, views[v].wm0_pitch) + (unsigned)lx);
-            const uint2 ma = *reinterpret_cast<const uint2 *>(mp), mb = *reinterpret_cast<const uint2 *>(mp + views[v].wm0_pitch);
+            typedef unsigned u32x2_g __attribute__((ext_vector_type(2)));      // (global address space named: the pointer comes out of the view descriptor -- see load_px2)
+            const u32x2_g ga = *(const MS_GLOBAL_AS u32x2_g *)(uintptr_t)mp, gb = *(const MS_GLOBAL_AS u32x2_g *)(uintptr_t)(mp + views[v].wm0_pitch);
+            const uint2 ma = make_uint2(ga.x, ga.y), mb = make_uint2(gb.x, gb.y);
             if ((ma.x | ma.y | mb.x | mb.y) == 0u) continue;          // all 16 weights zero: (short)(L * 0) == 0
             if (excl || CLS == 1) {                                   // mask bytes are 0 / 255 here
                 mq[0][0] = __builtin_amdgcn_perm(0u, ma.x, 0x02020000u); mq[0][1] = __builtin_amdgcn_perm(0u, ma.x, 0x03030101u);
@@ -781,8 +776,9 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
             }
         } else {
             const float *wp = L.wgt + (mul24(ly, L.wpitch) + (unsigned)lx);
-            const float4 wa = *reinterpret_cast<const float4 *>(wp), wb = *reinterpret_cast<const float4 *>(wp + 4);
-            const float4 wc = *reinterpret_cast<const float4 *>(wp + L.wpitch), wd = *reinterpret_cast<const float4 *>(wp + L.wpitch + 4);
+            typedef float f32x4_g __attribute__((ext_vector_type(4)));
+            const f32x4_g wa = *(const MS_GLOBAL_AS f32x4_g *)(uintptr_t)wp, wb = *(const MS_GLOBAL_AS f32x4_g *)(uintptr_t)(wp + 4);
+            const f32x4_g wc = *(const MS_GLOBAL_AS f32x4_g *)(uintptr_t)(wp + L.wpitch), wd = *(const MS_GLOBAL_AS f32x4_g *)(uintptr_t)(wp + L.wpitch + 4);
             w[0][0] = wa.x; w[0][1] = wa.y; w[0][2] = wa.z; w[0][3] = wa.w; w[0][4] = wb.x; w[0][5] = wb.y; w[0][6] = wb.z; w[0][7] = wb.w;
             w[1][0] = wc.x; w[1][1] = wc.y; w[1][2] = wc.z; w[1][3] = wc.w; w[1][4] = wd.x; w[1][5] = wd.y; w[1][6] = wd.z; w[1][7] = wd.w;
             float wsum = 0.f;
@@ -882,7 +878,7 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                 for (int q = 0; q < 4; ++q) upq[r][q] = sub_pk_u16(upq[r][q], (unsigned)UP_BIAS * 0x00010001u);
         } else {
             int up[2][8];
-            up_2x8(cc + c * cplane, P.qpitch[l + 1], P.qh[l + 1], P.qw[l + 1], y0 >> 1, x0 >> 1, up[0], up[1]);
+            up_2x8_raw(ccraw[c & 1], P.qw[l + 1], x0 >> 1, up[0], up[1]);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll

@@ -40,11 +40,31 @@ __device__ __forceinline__ Taps make_taps(float xc, float yc, int srows, int sco
 // gather is per instruction, not per byte.  The 2 extra bytes stay inside the image row because the caller only
 // uses this for taps with x1 <= cols-3 (the last column pair goes through the bounds-checked path).
 struct Px2 { unsigned lo; unsigned hi; };
+// (Both tap reads name the GLOBAL address space: the source pointers come out of a by-value table, or through an integer mask, so the compiler cannot tell -- and
+// FLAT loads cost full 64-bit VGPR addresses, count on lgkmcnt too, and can only be waited for all together: see assume_global in common.hpp.)
+typedef unsigned ms_u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef unsigned ms_u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+#define MS_GLOBAL_AS __attribute__((address_space(1)))
+typedef float ms_f32x2_g __attribute__((ext_vector_type(2)));
+typedef float ms_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ float2 gload_f2(const float2 *p) { const ms_f32x2_g v = *(const MS_GLOBAL_AS ms_f32x2_g *)(uintptr_t)p; return make_float2(v.x, v.y); }
+__device__ __forceinline__ float4 gload_f4(const float2 *p) { const ms_f32x4_a8 v = *(const MS_GLOBAL_AS ms_f32x4_a8 *)(uintptr_t)p; return make_float4(v.x, v.y, v.z, v.w); }   // two table entries, 8-byte aligned
+// The UNALIGNED 8-byte form stays a flat load: measured, config 5 (every tile takes this form): global_load_dwordx2 433-437 us per 8 frames, flat_load_dwordx2 392-395
+// (the commit before, whose scheduler order made unit 0 wait for all 16 reads: 402-408).  The aligned 12-byte form below gains from being global: config 2 218.9 -> 211.7 us per
+// 16 frames, the shipped configuration's stage 1 351 -> 324 (counted waits: unit 0 is blended while unit 1's reads are still in flight).
+#ifndef MS_PX2_FLAT
+#define MS_PX2_FLAT 1
+#endif
 __device__ __forceinline__ Px2 load_px2(const uint8_t *p)
 {
+#if MS_PX2_FLAT
     uint2 v;
     __builtin_memcpy(&v, p, 8);
     return Px2{v.x, v.y};
+#else
+    const ms_u32x2_a1 v = *(const MS_GLOBAL_AS ms_u32x2_a1 *)(uintptr_t)p;
+    return Px2{v.x, v.y};
+#endif
 }
 // The same 8 bytes out of ONE dword-aligned 12-byte read (global_load_dwordx3) and two v_alignbyte_b32 by the address's low two bits: an unaligned
 // 8-byte gather costs the texture-address path 13 % more than an aligned one (profiles/r02_warp_probes.txt: 242 vs 210 us), the aligned 12-byte form
@@ -53,9 +73,8 @@ __device__ __forceinline__ Px2 load_px2(const uint8_t *p)
 struct Px3 { unsigned d0, d1, d2; };
 __device__ __forceinline__ Px3 load_px3(const uint8_t *p)
 {
-    Px3 v;
-    __builtin_memcpy(&v, __builtin_assume_aligned((const uint8_t *)((uintptr_t)p & ~(uintptr_t)3), 4), 12);
-    return v;
+    const ms_u32x3_a4 v = *(const MS_GLOBAL_AS ms_u32x3_a4 *)((uintptr_t)p & ~(uintptr_t)3);
+    return Px3{v.x, v.y, v.z};
 }
 __device__ __forceinline__ Px2 px3_to_px2(const Px3 &q, unsigned addr_lo)      // v_alignbyte_b32 uses the low two bits of its shift operand
 {
@@ -178,16 +197,16 @@ __device__ __forceinline__ void warp_coords4(const ViewDesc &V, const MeshTable 
     const int i0 = x - V.left;
     const bool interior = i0 >= 0 && i0 + 3 < V.aw;
     if (!CPW) {
-        const float2 rt = V.rowtab[ay];
+        const float2 rt = gload_f2(V.rowtab + ay);
         float2 ct[4];
         if (interior) {
             float4 a, b;
-            __builtin_memcpy(&a, __builtin_assume_aligned(V.coltab + i0, 8), 16);
-            __builtin_memcpy(&b, __builtin_assume_aligned(V.coltab + i0 + 2, 8), 16);
+            a = gload_f4(V.coltab + i0);
+            b = gload_f4(V.coltab + i0 + 2);
             ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ct[k] = V.coltab[reflect_fast(i0 + k, V.aw)];
+            for (int k = 0; k < 4; ++k) ct[k] = gload_f2(V.coltab + reflect_fast(i0 + k, V.aw));
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) warp_combine(PROJ < 0 ? V.proj : PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
@@ -217,12 +236,12 @@ __device__ __forceinline__ void warp_coltab4(const ViewDesc &V, int x, float2 ct
     const int i0 = x - V.left;
     if (i0 >= 0 && i0 + 3 < V.aw) {
         float4 a, b;
-        __builtin_memcpy(&a, __builtin_assume_aligned(V.coltab + i0, 8), 16);
-        __builtin_memcpy(&b, __builtin_assume_aligned(V.coltab + i0 + 2, 8), 16);
+        a = gload_f4(V.coltab + i0);
+        b = gload_f4(V.coltab + i0 + 2);
         ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ct[k] = V.coltab[reflect_fast(i0 + k, V.aw)];
+        for (int k = 0; k < 4; ++k) ct[k] = gload_f2(V.coltab + reflect_fast(i0 + k, V.aw));
     }
 }
 
@@ -342,7 +361,7 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
         } else {
             warp_coltab4(V, min(x, V.pw - 4), ct);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) rt[g] = V.rowtab[reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah)];
+            for (int g = 0; g < NG; ++g) rt[g] = gload_f2(V.rowtab + reflect_fast(min(ys[g], V.ph - 1) - V.top, V.ah));
         }
     }
     if (CPW && NG <= 2) {        // the dense mesh maps of both row groups are read up front too (one round trip, not one per group)
@@ -374,7 +393,8 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
                 for (int k = 0; k < 4; ++k) xc[cb][k] = yc[cb][k] = -1.f;
             }
         }
-        if (NF > 1 && fi >= nf) return;       // (wave-uniform)
+        // (no early exit for the missing second frame of an odd batch: its reads go to frame f0 again and are dropped.  A branch around them would make the
+        //  wait-count pass assume either path at the join -- vmcnt(7) instead of vmcnt(15) before unit 0's first use, i.e. a wait for ALL of unit 1's reads)
         const uint8_t *spf = sp[fi];
         const unsigned stf = sstep[fi];
         const unsigned sp_lo = (unsigned)(uintptr_t)spf;
@@ -405,6 +425,9 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
         }
     };
     issue(0);
+#ifndef MS_NO_ORDER_BARRIER
+    __builtin_amdgcn_sched_barrier(0);      // unit 0's reads go out FIRST: without this the scheduler hoists unit 1's above them, and unit 0's blend then waits for all 16
+#endif
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int fi = u / NG, g = u % NG, cb = g & 1, lb = u & 1;
@@ -549,7 +572,7 @@ __device__ __forceinline__ void wa_tables(const WarpTile &T, const ViewDesc *__r
         const ViewDesc &V = views[T.view];
         warp_coltab4(V, min(T.x0 + 4 * tx, V.pw - 4), ct);
 #pragma unroll
-        for (int g = 0; g < WA_NG; ++g) rt[g] = V.rowtab[reflect_fast(min(T.y0 + ty + g * WA_BY, V.ph - 1) - V.top, V.ah)];
+        for (int g = 0; g < WA_NG; ++g) rt[g] = gload_f2(V.rowtab + reflect_fast(min(T.y0 + ty + g * WA_BY, V.ph - 1) - V.top, V.ah));
     }
 }
 
@@ -709,22 +732,21 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, c
     float2 ct[4];
     if (x + 3 < V.aw) {
         float4 a, b;
-        __builtin_memcpy(&a, __builtin_assume_aligned(V.coltab + x, 8), 16);
-        __builtin_memcpy(&b, __builtin_assume_aligned(V.coltab + x + 2, 8), 16);
+        a = gload_f4(V.coltab + x);
+        b = gload_f4(V.coltab + x + 2);
         ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ct[k] = V.coltab[min(x + k, V.aw - 1)];
+        for (int k = 0; k < 4; ++k) ct[k] = gload_f2(V.coltab + min(x + k, V.aw - 1));
     }
-    const float2 rt = V.rowtab[y];
+    const float2 rt = gload_f2(V.rowtab + y);
     float xc[4], yc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
     Px2 r1[2][4], r2[2][4];
     Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];      // AL: aligned 12-byte tap reads, as in warp_tile_direct
     unsigned sh1[2] = {0u, 0u}, sh2[2] = {0u, 0u};
-    auto issue = [&](int fi) {
-        if (fi >= nf) return;
+    auto issue = [&](int fi) {      // (unconditional, also for the missing second frame of an odd batch: see warp_tile_direct)
         const int b = fi & 1;
         const uint8_t *spf = sp[fi];
         const unsigned stf = sstep[fi], sp_lo = (unsigned)(uintptr_t)spf;
@@ -744,10 +766,12 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, c
         }
     };
     issue(0);
+    __builtin_amdgcn_sched_barrier(0);      // (frame 0's reads first: see warp_tile_direct)
 #pragma unroll
     for (int fi = 0; fi < S1_NF; ++fi) {
         const int b = fi & 1;
         if (fi + 1 < S1_NF) issue(fi + 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (fi >= nf) continue;
         unsigned w[3] = {0u, 0u, 0u};
 #pragma unroll
