@@ -3007,6 +3007,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         }
     }
 
+    // Occupancy of the warp kernels, set through dynamic LDS nobody touches (bytes per 128-lane workgroup; 160 KiB per CU).  The aligned-read projection warp needs 85 VGPRs
+    // (5 waves per SIMD) since its tap addresses became SGPR base + 32-bit offset, and runs 3.7 % FASTER at 4 waves (20 000 bytes -> 8 workgroups per CU): fewer waves
+    // thrash the vector cache less (same-box sweep, us per 16 frames: 5 waves 215, 4 waves 207, 3 waves 214; profiles/r03_resize_ab.txt).  The unaligned variant
+    // (config 5, 61 VGPRs) and the mesh remap (98 VGPRs = 4 waves anyway) are best left alone.  MS_WARP_LDS=<bytes> overrides all three (A/B).
+    static const int warp_lds_env = [] { const char *e = getenv("MS_WARP_LDS"); return e ? atoi(e) : -1; }();
+    const size_t warp_lds = warp_lds_env >= 0 ? (size_t)warp_lds_env : 0, warp_lds_al = warp_lds_env >= 0 ? (size_t)warp_lds_env : 20000;
     const bool int_only = c->l0_integer_only && P.pure[0] != nullptr;      // (read under mesh_mu, like the table pointers: an enqueue-only mask update clears it)
 
     // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
@@ -3051,7 +3057,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
-            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
@@ -3069,9 +3075,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         } else
         {
             if (c->warp_aligned)
-                MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else
-                MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), 0, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         }
     } else if (c->cfg.cpu_flavour_remap != 0) {
         k_warp<false, true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
@@ -3094,7 +3100,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
         if (c->down_vec[l] && c->cfg.debug_simple_kernels == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
-            if (l == 0) k_down_t<true><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
+            static const int down_lds = [] { const char *e = getenv("MS_DOWN_LDS"); return e ? atoi(e) : 0; }();      // occupancy A/B knob (dynamic LDS nobody touches)
+            if (l == 0) k_down_t<true><<<g, b, down_lds, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
             else        k_down_t<false><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
         } else {
             const dim3 g(div_up(ow, 64), div_up(oh, 4), F * N * 3);
@@ -3150,7 +3157,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             const dim3 g(c->n_blend_tiles[l], 4, F), b(32, 2);
             static const bool no_cls = [] { const char *e = getenv("MS_BLEND_CLS"); return e && atoi(e) == 0; }();      // MS_BLEND_CLS=0: always the all-classes build (A/B)
             // level 0 without general cells (the usual case: binary Voronoi seam masks): the build that has no general path -- 88 instead of 120 VGPRs, 5 waves per SIMD
-            if (l == 0 && S.mode == 0 && int_only && !no_cls) k_blend8<true, 0, 1><<<g, b, 0, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
+            static const int blend_lds = [] { const char *e = getenv("MS_BLEND_LDS"); return e ? atoi(e) : 0; }();      // occupancy A/B knob
+            if (l == 0 && S.mode == 0 && int_only && !no_cls) k_blend8<true, 0, 1><<<g, b, blend_lds, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else        MS_MODE_LAUNCH2(k_blend8, false, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
         } else {

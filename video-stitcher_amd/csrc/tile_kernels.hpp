@@ -76,6 +76,14 @@ __device__ __forceinline__ Px3 load_px3(const uint8_t *p)
     const ms_u32x3_a4 v = *(const MS_GLOBAL_AS ms_u32x3_a4 *)((uintptr_t)p & ~(uintptr_t)3);
     return Px3{v.x, v.y, v.z};
 }
+// the same read as "4-aligned uniform base + 32-bit lane offset": the address stays one VGPR (global_load_dwordx3 v, v_off, s[base:base+1]) instead of a 64-bit
+// add and mask per read.  base_al = the image pointer rounded down to 4 bytes, a = (pointer & 3) + byte offset of the tap; a & 3 is the byte shift for px3_to_px2.
+typedef const MS_GLOBAL_AS uint8_t *ms_gptr_u8;
+__device__ __forceinline__ Px3 load_px3_at(ms_gptr_u8 base_al, unsigned a)
+{
+    const ms_u32x3_a4 v = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base_al + (a & ~3u));
+    return Px3{v.x, v.y, v.z};
+}
 __device__ __forceinline__ Px2 px3_to_px2(const Px3 &q, unsigned addr_lo)      // v_alignbyte_b32 uses the low two bits of its shift operand
 {
     return Px2{__builtin_amdgcn_alignbyte(q.d1, q.d0, addr_lo), __builtin_amdgcn_alignbyte(q.d2, q.d1, addr_lo)};
@@ -398,6 +406,7 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
         const uint8_t *spf = sp[fi];
         const unsigned stf = sstep[fi];
         const unsigned sp_lo = (unsigned)(uintptr_t)spf;
+        const ms_gptr_u8 sp_al = (ms_gptr_u8)((uintptr_t)spf & ~(uintptr_t)3);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float xq = xc[cb][k], yq = yc[cb][k];
@@ -412,9 +421,9 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
             r1[lb][k] = Px2{off, off * 3u}; r2[lb][k] = Px2{off ^ 0x55u, off + 7u};
 #else
             if (AL) {
-                q1[AL ? lb : 0][AL ? k : 0] = load_px3(spf + off);
-                q2[AL ? lb : 0][AL ? k : 0] = load_px3(spf + stf + off);
-                const unsigned a = sp_lo + off;
+                const unsigned a = (sp_lo & 3u) + off;
+                q1[AL ? lb : 0][AL ? k : 0] = load_px3_at(sp_al, a);
+                q2[AL ? lb : 0][AL ? k : 0] = load_px3_at(sp_al, a + stf);
                 if (k == 0) { sh1[lb] = a & 3u; sh2[lb] = (a + stf) & 3u; }
                 else { sh1[lb] |= (a & 3u) << (2 * k); sh2[lb] |= ((a + stf) & 3u) << (2 * k); }
             } else {
@@ -750,13 +759,14 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, c
         const int b = fi & 1;
         const uint8_t *spf = sp[fi];
         const unsigned stf = sstep[fi], sp_lo = (unsigned)(uintptr_t)spf;
+        const ms_gptr_u8 sp_al = (ms_gptr_u8)((uintptr_t)spf & ~(uintptr_t)3);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned off = tap_offset(f2i_rd(xc[k]), f2i_rd(yc[k]), srows, scols, stf);
             if (AL) {
-                q1[AL ? b : 0][AL ? k : 0] = load_px3(spf + off);
-                q2[AL ? b : 0][AL ? k : 0] = load_px3(spf + stf + off);
-                const unsigned a = sp_lo + off;
+                const unsigned a = (sp_lo & 3u) + off;
+                q1[AL ? b : 0][AL ? k : 0] = load_px3_at(sp_al, a);
+                q2[AL ? b : 0][AL ? k : 0] = load_px3_at(sp_al, a + stf);
                 if (k == 0) { sh1[b] = a & 3u; sh2[b] = (a + stf) & 3u; }
                 else { sh1[b] |= (a & 3u) << (2 * k); sh2[b] |= ((a + stf) & 3u) << (2 * k); }
             } else {
