@@ -2919,11 +2919,11 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
     } while (0)
 
 // k_stage1_t<PROJ, AL>: the projection comes first there
-#define MS_PROJ_AL_LAUNCH(K, AL, CFG, ...)                                                                                  \
+#define MS_PROJ_AL_LAUNCH(K, AL, NF, CFG, ...)                                                                              \
     do {                                                                                                                    \
-        if (c->cfg.projection == MS_PROJ_SPHERICAL) K<MS_PROJ_SPHERICAL, AL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);               \
-        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) K<MS_PROJ_CYLINDRICAL, AL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);      \
-        else K<MS_PROJ_PLANE, AL><<<MS_UNPAREN CFG>>>(__VA_ARGS__);                                                          \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) K<MS_PROJ_SPHERICAL, AL, NF><<<MS_UNPAREN CFG>>>(__VA_ARGS__);           \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) K<MS_PROJ_CYLINDRICAL, AL, NF><<<MS_UNPAREN CFG>>>(__VA_ARGS__);  \
+        else K<MS_PROJ_PLANE, AL, NF><<<MS_UNPAREN CFG>>>(__VA_ARGS__);                                                      \
     } while (0)
 
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
@@ -3044,12 +3044,14 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     if (cpw) {
         if (c->cfg.debug_simple_kernels == 0)
         {
-            if (c->warp_aligned)
-                MS_PROJ_AL_LAUNCH(k_stage1_t, true, (dim3(c->n_stage1_tiles, 1, div_up(F, S1_NF)), dim3(WARP_BX, S1_BY), 0, st),
-                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F);
-            else
-                MS_PROJ_AL_LAUNCH(k_stage1_t, false, (dim3(c->n_stage1_tiles, 1, div_up(F, S1_NF)), dim3(WARP_BX, S1_BY), 0, st),
-                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F);
+            // frames per lane of the first CPW remap: three where the source is sampled about 1 : 1 (VALU-bound), two otherwise (see k_stage1_t)
+            static const int s1_env = [] { const char *e = getenv("MS_S1_NF"); return e ? atoi(e) : 0; }();
+            const int s1_nf = s1_env == 2 || s1_env == 3 ? s1_env : ((c->warp_minification > 0 && c->warp_minification < 1.5) ? 3 : 2);
+#define MS_S1_LAUNCH(AL, NF) MS_PROJ_AL_LAUNCH(k_stage1_t, AL, NF, (dim3(c->n_stage1_tiles, 1, div_up(F, NF)), dim3(WARP_BX, S1_BY), 0, st), \
+                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F)
+            if (c->warp_aligned) { if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
+            else { if (s1_nf == 3) MS_S1_LAUNCH(false, 3); else MS_S1_LAUNCH(false, 2); }
+#undef MS_S1_LAUNCH
         }
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
@@ -3057,7 +3059,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
         if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
-            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, warp_nf(true))), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);

@@ -500,6 +500,12 @@ __device__ __forceinline__ void warp_tile_direct(const WarpTile &T, int f0, int 
 #define MS_WARP_NF 2
 #endif
 constexpr int WARP_NF = MS_WARP_NF;
+// the mesh remap (CPW) also reads its two dense coordinate maps once per lane and frame GROUP: three frames per lane there (same box, 24 frames per launch:
+// 214.9 us with two, 204.8 with three, 205.6 with four); the projection warp is best at two (307 / 332 / 345 us for two / three / four)
+#ifndef MS_WARP_NF_CPW
+#define MS_WARP_NF_CPW 3
+#endif
+constexpr int warp_nf(bool cpw) { return cpw ? MS_WARP_NF_CPW : WARP_NF; }
 // lane rows per WORKGROUP: a tile's WARP_BY lane rows are split over WARP_BY / WARP_WY workgroups (blockIdx.y).  MS_WARP_ONE_WAVE: 64-lane workgroups
 // (the waves of a tile share nothing but the tile record), as k_blend8 got in round 2.
 #ifndef MS_WARP_ONE_WAVE
@@ -513,13 +519,14 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_t(const WarpTile *__
                                                          uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs, int n_frames)
 {
     const WarpTile T = tiles[blockIdx.x];
-    const int f0 = (int)blockIdx.z * WARP_NF, nf = min(WARP_NF, n_frames - f0);
+    constexpr int NF = warp_nf(CPW);
+    const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
     // aligned tap reads unless a sample of the tile reads the last row of a caller's image (flags bit 3, k_tile_bbox); the CPW stage buffer is ours and padded
     if (AL && (CPW || (T.flags & 8)))
-        warp_tile_direct<CPW, PROJ, true, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+        warp_tile_direct<CPW, PROJ, true, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
                                                    g0, g0_stride, tabs);
     else
-        warp_tile_direct<CPW, PROJ, false, WARP_NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+        warp_tile_direct<CPW, PROJ, false, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
                                                     g0, g0_stride, tabs);
 }
 
@@ -718,12 +725,8 @@ __global__ void __launch_bounds__(64) k_warp_a(const WarpTile *__restrict__ tile
 // Same sampling code as k_warp_t without the reflect pad; interleaved 8UC3 output (the stage-2 remap samples it).  One row of 4 pixels per lane,
 // S1_NF frames per lane: the projection coordinates and bilinear weights are built once and used for both frames (as in warp_tile_direct), the tap
 // reads of frame fi + 1 are in flight while frame fi is blended.
-#ifndef MS_S1_NF
-#define MS_S1_NF 2
-#endif
-constexpr int S1_NF = MS_S1_NF;
 constexpr int S1_BY = WARP_TH;          // lane rows of the block (the launch uses the same): one tile row per lane
-template <int PROJ, bool AL>
+template <int PROJ, bool AL, int S1_NF>
 __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, const ViewDesc *__restrict__ views, int n_views,
                                             const SrcTable &src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
 {
@@ -818,7 +821,9 @@ __device__ __forceinline__ void stage1_tile(const WarpTile &T, int f0, int nf, c
     }
 }
 
-template <int PROJ, bool AL>
+// S1_NF frames per lane (coordinates, offsets and weights built once per lane): 2 where the remap is gather-bound (config 3: 338 / 344 / 358 us per 24 frames with 2 / 3 / 4),
+// 3 where the source is sampled about 1 : 1 and the kernel is VALU-bound (the shipped cylindrical rig: 494 / 438 / 430): ms_ctx::stage1_nf picks by the tiles' minification
+template <int PROJ, bool AL, int S1_NF>
 __global__ void __launch_bounds__(WARP_BX * S1_BY) k_stage1_t(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                              SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp, int n_frames)
 {
@@ -826,8 +831,8 @@ __global__ void __launch_bounds__(WARP_BX * S1_BY) k_stage1_t(const WarpTile *__
     // the mesh of this view moves no sample further than the bound the plan assumed: stage 2 never reads this tile
     if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;
     const int f0 = (int)blockIdx.z * S1_NF, nf = min(S1_NF, n_frames - f0);
-    if (AL && (T.flags & 8)) stage1_tile<PROJ, true>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
-    else stage1_tile<PROJ, false>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+    if (AL && (T.flags & 8)) stage1_tile<PROJ, true, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+    else stage1_tile<PROJ, false, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
 }
 
 // ---- pyrDown, tile list, DOWN_ROWS (4) rows x 4 cols per lane (block 32 x 8): 11 input rows for 4 output rows (2 rows per lane: 7 for 2, 16 % slower) ----
