@@ -3047,7 +3047,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             // frames per lane of the first CPW remap: three where the source is sampled about 1 : 1 (VALU-bound), two otherwise (see k_stage1_t)
             static const int s1_env = [] { const char *e = getenv("MS_S1_NF"); return e ? atoi(e) : 0; }();
             const int s1_nf = s1_env == 2 || s1_env == 3 ? s1_env : ((c->warp_minification > 0 && c->warp_minification < 1.5) ? 3 : 2);
-#define MS_S1_LAUNCH(AL, NF) MS_PROJ_AL_LAUNCH(k_stage1_t, AL, NF, (dim3(c->n_stage1_tiles, 1, div_up(F, NF)), dim3(WARP_BX, S1_BY), 0, st), \
+            static const int s1_lds = [] { const char *e = getenv("MS_S1_LDS"); return e ? atoi(e) : 0; }();      // occupancy A/B knob (dynamic LDS nobody touches)
+#define MS_S1_LAUNCH(AL, NF) MS_PROJ_AL_LAUNCH(k_stage1_t, AL, NF, (dim3(c->n_stage1_tiles, 1, div_up(F, NF)), dim3(WARP_BX, S1_BY), s1_lds, st), \
                     (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F)
             if (c->warp_aligned) { if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
             else { if (s1_nf == 3) MS_S1_LAUNCH(false, 3); else MS_S1_LAUNCH(false, 2); }
