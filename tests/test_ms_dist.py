@@ -40,6 +40,27 @@ def _exchange(rank, world, idb, results):
         d.group_end()
         for r in range(world):
             assert ins[r][0] == 10 * r + rank and ins[r][-1] == 10 * r + rank, (rank, r)
+        # 2b. TWO sends and TWO receives per peer in one group, 2.5 MiB each (three mailbox pieces): the operations that share a channel run in posting order --
+        #     the second receive must not take the first message's pieces, two multi-piece sends must not interleave
+        n2 = 5 * (1 << 19)
+        a_out = [np.full(n2, (3 + 2 * rank + 7 * r) % 251, np.uint8) for r in range(world)]
+        b_out = [np.full(n2 + 1, (4 + 2 * rank + 7 * r) % 251, np.uint8) for r in range(world)]
+        a_in = [np.zeros(n2, np.uint8) for _ in range(world)]
+        b_in = [np.zeros(n2 + 1, np.uint8) for _ in range(world)]
+        d.group_begin()
+        for r in range(world):
+            if r == rank:
+                continue
+            d.recv(a_in[r], r)
+            d.send(a_out[r], r)
+            d.send(b_out[r], r)
+            d.recv(b_in[r], r)
+        d.group_end()
+        for r in range(world):
+            if r == rank:
+                continue
+            assert np.all(a_in[r] == (3 + 2 * r + 7 * rank) % 251), (rank, r, "first message")
+            assert np.all(b_in[r] == (4 + 2 * r + 7 * rank) % 251), (rank, r, "second message")
         # 3. broadcast from the last rank
         b = np.arange(100000, dtype=np.float32) * (1.0 if rank == world - 1 else 0.0)
         d.broadcast(b, world - 1)
@@ -52,6 +73,12 @@ def _exchange(rank, world, idb, results):
         mx, my = rng.random((n_views, rows, cols), dtype=np.float32), rng.random((n_views, rows, cols), dtype=np.float32)
         got = d.mesh_exchange(0, (4800, 2, mx, my) if rank == 0 else None, n_views, rows, cols)
         assert got is not None and got[0] == 4800 and got[1] == 2 and np.array_equal(got[2], mx) and np.array_equal(got[3], my)
+        assert d.mesh_exchange(0, None, n_views, rows, cols) is None
+        # 5. an invalid update on the root is an error on EVERY rank (it travels in the header), and the communicator stays in step
+        import msstitch as ms
+        bad = (1, 3, np.zeros((n_views, 1, cols), np.float32), np.zeros((n_views, 1, cols), np.float32))      # one mesh row: invalid
+        with pytest.raises(ms.MsError):
+            d.mesh_exchange(0, bad if rank == 0 else None, n_views, 1, cols)
         assert d.mesh_exchange(0, None, n_views, rows, cols) is None
         d.barrier()
         results[rank] = "ok"

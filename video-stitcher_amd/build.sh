@@ -13,6 +13,10 @@ for f in prims.hip compositor.hip mesh_solver.hip matcher.hip features.hip calib
     $HIPCC $FLAGS -x hip -c "$f" -o "$o" & pids+=($!)
   fi
 done
+# the hand-declared RCCL prototypes of dist.cpp against the installed header (syntax only; skipped where the header is absent)
+if [ -f /opt/rocm/include/rccl/rccl.h ] && { [ ! -f ../build/rccl_abi.ok ] || [ rccl_abi_check.cpp -nt ../build/rccl_abi.ok ] || [ dist.cpp -nt ../build/rccl_abi.ok ]; }; then
+  $HIPCC -std=c++17 -fsyntax-only -x hip --offload-host-only rccl_abi_check.cpp && touch ../build/rccl_abi.ok
+fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || { echo "compile failed" >&2; exit 1; }; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmsstitch.so ../build/prims.o ../build/compositor.o ../build/mesh_solver.o ../build/matcher.o ../build/features.o ../build/calib.o ../build/api.o ../build/geometry.o ../build/dist.o -ldl -lrt
 # C++ host pipeline over the C-ABI (thread / queue graph of the reference's timed.cpp); host code only, links the library above

@@ -140,6 +140,7 @@ struct ms_dist {
     // HOST
     ms::ShmHeader *shm = nullptr;
     size_t shm_len = 0;
+    char shm_name[48] = {0};          // rank 0, while the name still exists in /dev/shm (unlinked as soon as every rank has mapped it, or by ms_dist_destroy on a failed attach)
     ms::Channel *chan(int src, int dst) const { return reinterpret_cast<ms::Channel *>(reinterpret_cast<unsigned char *>(shm) + sizeof(ms::ShmHeader)) + ((size_t)src * nranks + dst); }
     // group state
     bool grouping = false;
@@ -202,8 +203,15 @@ int host_run(ms_dist *d, std::vector<Op> &ops)
     Backoff bo;
     for (;;) {
         bool all = true, any = false;
-        for (Op &op : ops) {
+        for (size_t i = 0; i < ops.size(); ++i) {
+            Op &op = ops[i];
             if (op.finished) continue;
+            // One untagged single-slot channel per ordered rank pair: the operations of a group that share a channel -- same peer, same direction -- run strictly in
+            // posting order, the next one only after the previous one's last piece (ncclGroup semantics for matching sends and receives posted in the same order on
+            // both sides).  Advancing them round-robin would let a second receive take the first message's pieces, or interleave the pieces of two sends.
+            bool blocked = false;
+            for (size_t j = 0; j < i && !blocked; ++j) blocked = !ops[j].finished && ops[j].peer == op.peer && ops[j].send == op.send;
+            if (blocked) { all = false; continue; }
             bool moved = false;
             if (int e = host_step(d, op, &moved)) return e;
             any |= moved;
@@ -246,6 +254,7 @@ int host_attach(ms_dist *d, const DistId &id)
     if (d->rank == 0) {
         shm_unlink(name);                                            // (a stale segment of a crashed run with the same id: impossible in practice, harmless)
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0) memcpy(d->shm_name, name, sizeof(name));        // from here on every failure path ends in ms_dist_destroy, which unlinks it
         if (fd < 0 || ftruncate(fd, (off_t)len) != 0) { if (fd >= 0) close(fd); return fail(MS_ERR_COMM, "ms_dist: cannot create the shared-memory mailbox %s (%zu bytes)", name, len); }
     } else {
         Backoff bo;
@@ -281,7 +290,7 @@ int host_attach(ms_dist *d, const DistId &id)
     while (H->attached.load(std::memory_order_acquire) < (unsigned)d->nranks)
         if (!bo.wait()) return fail(MS_ERR_COMM, "ms_dist: rank %d: only %u of %d ranks joined within %.0f s", d->rank, H->attached.load(), d->nranks, TIMEOUT_S);
     if (int e = host_barrier(d)) return e;                           // everybody has mapped the segment ...
-    if (d->rank == 0) shm_unlink(name);                              // ... so the name can go: nothing is left behind whatever happens later
+    if (d->rank == 0) { shm_unlink(name); d->shm_name[0] = 0; }      // ... so the name can go: nothing is left behind whatever happens later
     for (int r = 0; r < d->nranks; ++r) { d->info.device[r] = H->info[r].device; memcpy(d->info.pci_bus_id[r], H->info[r].pci, 16); }
     return MS_OK;
 }
@@ -306,6 +315,9 @@ int rccl_attach(ms_dist *d, const DistId &id)
     MS_HIP(hipSetDevice(d->device));
     MS_NCCL(R.CommInitRank(&d->comm, d->nranks, id.nccl, d->rank));
     MS_NCCL(R.GetVersion(&d->info.rccl_version));
+    // the prototypes above are hand-declared from rccl.h 2.27.7 (ROCm 7.2; csrc/rccl_abi_check.cpp holds them against the installed header at build time): NCCL keeps
+    // these entry points stable within a major version, so refuse anything else rather than call through a changed ABI
+    if (d->info.rccl_version / 10000 != 2) return fail(MS_ERR_COMM, "ms_dist: librccl reports version %d; the declarations in dist.cpp are for major version 2", d->info.rccl_version);
     MS_NCCL(R.CommCount(d->comm, &d->info.comm_nranks));
     // device ordinal + PCI bus id of every rank: one small all-gather (also the first real traffic on the communicator)
     RankInfo me{};
@@ -336,6 +348,7 @@ int p2p(ms_dist *d, bool send, void *buf, size_t bytes, int peer, int mem, hipSt
     MS_CHECK(buf || bytes == 0, "%s: null buffer", what);
     MS_CHECK(mem == MS_DIST_MEM_DEVICE || mem == MS_DIST_MEM_HOST, "%s: bad memory kind %d", what, mem);
     MS_CHECK(peer != d->rank || d->grouping, "%s: a transfer to oneself needs its counterpart in the same group", what);
+    if (mem == MS_DIST_MEM_DEVICE && d->device < 0) return fail(MS_ERR_NO_DEVICE, "%s: this communicator was created without a device: host-memory messages only", what);
     if (d->transport == MS_DIST_RCCL) {
         Rccl &R = rccl();
         if (mem == MS_DIST_MEM_HOST) return fail(MS_ERR_UNSUPPORTED, "%s: host memory goes through ms_dist_broadcast / ms_dist_mesh_exchange on the RCCL transport", what);
@@ -399,8 +412,8 @@ int ms_dist_create(ms_dist **out, int rank, int nranks, const void *id_bytes, in
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     if (device >= 0 && device < ndev) (void)hipSetDevice(device);
-    else if (id.transport == MS_DIST_RCCL) { delete d; return fail(MS_ERR_NO_DEVICE, "ms_dist_create: device %d not present (%d visible)", device, ndev); }
-    else d->device = ndev > 0 ? device : -1;                         // host transport without a GPU: host-memory messages only
+    else if (id.transport == MS_DIST_RCCL || (ndev > 0 && device >= 0)) { delete d; return fail(MS_ERR_NO_DEVICE, "ms_dist_create: device %d not present (%d visible)", device, ndev); }
+    else d->device = -1;                                             // host transport with no GPU (or device < 0): host-memory messages only, MS_DIST_MEM_DEVICE is refused
     const int e = id.transport == MS_DIST_RCCL ? rccl_attach(d, id) : host_attach(d, id);
     if (e) { ms_dist_destroy(d); return e; }
     *out = d;
@@ -413,6 +426,7 @@ void ms_dist_destroy(ms_dist *d)
     if (d->comm) (void)rccl().CommDestroy(d->comm);
     if (d->stage) (void)hipFree(d->stage);
     if (d->shm) munmap(d->shm, d->shm_len);
+    if (d->shm_name[0]) shm_unlink(d->shm_name);                     // rank 0 of an attach that failed (a peer never joined, a barrier timed out): nranks^2 MiB would stay in /dev/shm
     delete d;
 }
 
@@ -515,50 +529,65 @@ int ms_dist_gather_slabs(ms_dist *d, const void *slab, size_t bytes, void *const
     if (int e = check_peer(d, sink, "ms_dist_gather_slabs")) return e;
     MS_CHECK(bytes > 0 && !d->grouping, "ms_dist_gather_slabs: empty slab or inside a group");
     if (d->nranks == 1) return MS_OK;
+    // A rank that finds its own arguments wrong still takes part in the collective (into / out of scratch) and reports the error afterwards: leaving early would
+    // leave the peers blocked in their half of the transfer (120 s on the host transport, for ever on RCCL) and the communicator out of step.
+    int bad = MS_OK;
+    void *scratch = nullptr;
+    if (d->rank == sink) {
+        bool missing = !recv;
+        for (int r = 0; r < d->nranks && !missing; ++r) missing = r != sink && !recv[r];
+        if (missing) bad = fail(MS_ERR_INVALID, "ms_dist_gather_slabs: the sink needs one receive buffer per peer");
+    } else if (!slab) bad = fail(MS_ERR_INVALID, "ms_dist_gather_slabs: null slab");
+    if (bad) {
+        if (d->device < 0) return bad;                    // (no device at all: nothing can be posted; device slabs are refused on such a communicator anyway)
+        if (int e = stage_get(d, bytes, &scratch)) return e;
+    }
     if (int e = ms_dist_group_begin(d)) return e;
     int err = MS_OK;
     if (d->rank == sink) {
-        if (!recv) err = fail(MS_ERR_INVALID, "ms_dist_gather_slabs: the sink needs receive buffers");
         for (int r = 0; r < d->nranks && !err; ++r) {
             if (r == sink) continue;
-            if (!recv[r]) { err = fail(MS_ERR_INVALID, "ms_dist_gather_slabs: no receive buffer for rank %d", r); break; }
-            err = ms_dist_recv(d, recv[r], bytes, r, MS_DIST_MEM_DEVICE, stream);
+            err = ms_dist_recv(d, (recv && recv[r]) ? recv[r] : scratch, bytes, r, MS_DIST_MEM_DEVICE, stream);
         }
-    } else {
-        if (!slab) err = fail(MS_ERR_INVALID, "ms_dist_gather_slabs: null slab");
-        else err = ms_dist_send(d, slab, bytes, sink, MS_DIST_MEM_DEVICE, stream);
-    }
+    } else err = ms_dist_send(d, slab ? slab : scratch, bytes, sink, MS_DIST_MEM_DEVICE, stream);
     if (err) {                  // close the group without running it (RCCL: end the group so the communicator stays usable), report the first error
         d->grouping = false;
         d->ops.clear();
         if (d->transport == MS_DIST_RCCL) (void)rccl().GroupEnd();
         return err;
     }
-    return ms_dist_group_end(d);
+    if (int e = ms_dist_group_end(d)) return e;
+    if (bad) { if (d->device >= 0) (void)hipStreamSynchronize(as_stream(stream)); return fail(MS_ERR_INVALID, "ms_dist_gather_slabs: rank %d had a null buffer (the transfer ran into scratch memory so that the peers return)", d->rank); }
+    return MS_OK;
 }
 
 namespace {
-struct MeshHeader { unsigned magic; int have, version, n_views, rows, cols; long long swap_frame; };
+struct MeshHeader { unsigned magic; int have, version, n_views, rows, cols; long long swap_frame; };      // have: 0 no update, 1 update follows, -1 the root's update was invalid
 }
 
 int ms_dist_mesh_exchange(ms_dist *d, int root, const ms_dist_mesh_update *upd, ms_dist_mesh_update *out, size_t cap_floats, int *have, ms_stream stream)
 {
     if (int e = check_peer(d, root, "ms_dist_mesh_exchange")) return e;
-    MS_CHECK(out && have && out->mesh_x && out->mesh_y, "ms_dist_mesh_exchange: null output");
-    *have = 0;
+    if (have) *have = 0;
+    // Every rank takes part in the header broadcast whatever it thinks of its own arguments, and in the payload broadcast whenever the header announces one: the
+    // status travels in the header (root's update invalid) or is decided from it identically everywhere, so no rank leaves the collective half way.
+    const bool out_ok = out && have && out->mesh_x && out->mesh_y;
     MeshHeader h{ID_MAGIC, 0, 0, 0, 0, 0, 0};
     if (d->rank == root && upd) {
-        MS_CHECK(upd->mesh_x && upd->mesh_y && upd->n_views >= 1 && upd->n_views <= 16 && upd->rows >= 2 && upd->cols >= 2, "ms_dist_mesh_exchange: bad update");
-        h.have = 1; h.version = upd->version; h.n_views = upd->n_views; h.rows = upd->rows; h.cols = upd->cols; h.swap_frame = upd->swap_frame;
+        const bool ok = upd->mesh_x && upd->mesh_y && upd->n_views >= 1 && upd->n_views <= 16 && upd->rows >= 2 && upd->cols >= 2;
+        h.have = ok ? 1 : -1;
+        if (ok) { h.version = upd->version; h.n_views = upd->n_views; h.rows = upd->rows; h.cols = upd->cols; h.swap_frame = upd->swap_frame; }
     }
     if (d->nranks > 1) if (int e = ms_dist_broadcast(d, &h, sizeof(h), root, MS_DIST_MEM_HOST, stream)) return e;
     if (h.magic != ID_MAGIC) return fail(MS_ERR_COMM, "ms_dist_mesh_exchange: rank %d received a corrupt header (ranks out of step?)", d->rank);
-    if (!h.have) return MS_OK;
+    if (h.have < 0) return fail(MS_ERR_INVALID, "ms_dist_mesh_exchange: bad update on rank %d (every rank returns this)", root);
+    if (!h.have) { MS_CHECK(out_ok, "ms_dist_mesh_exchange: null output"); return MS_OK; }
     const size_t n = (size_t)h.n_views * h.rows * h.cols;
-    MS_CHECK(n <= cap_floats, "ms_dist_mesh_exchange: update of %zu floats per map exceeds the caller's capacity %zu", n, cap_floats);
     std::vector<float> pack(2 * n);
     if (d->rank == root) { memcpy(pack.data(), upd->mesh_x, n * sizeof(float)); memcpy(pack.data() + n, upd->mesh_y, n * sizeof(float)); }
     if (d->nranks > 1) if (int e = ms_dist_broadcast(d, pack.data(), 2 * n * sizeof(float), root, MS_DIST_MEM_HOST, stream)) return e;
+    MS_CHECK(out_ok, "ms_dist_mesh_exchange: null output");
+    MS_CHECK(n <= cap_floats, "ms_dist_mesh_exchange: update of %zu floats per map exceeds the caller's capacity %zu", n, cap_floats);
     memcpy(out->mesh_x, pack.data(), n * sizeof(float));
     memcpy(out->mesh_y, pack.data() + n, n * sizeof(float));
     out->swap_frame = h.swap_frame; out->version = h.version; out->n_views = h.n_views; out->rows = h.rows; out->cols = h.cols;
