@@ -69,6 +69,17 @@ def kernel_bytes(comp, cfg, n_frames, cpw):
     return {k: v * n_frames for k, v in kb.items()}, sumP, Q, A
 
 
+def csrc_sha16():
+    """hash of the product's kernel sources: a PMC traffic summary collected on another state of csrc/ is flagged stale in the bench line"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "video-stitcher_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp", ".inc")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def oracle_check(cfg, gains, comp, frame_dev, cpw):
     """`verified` only says the batched path equals the one-frame path of the SAME library.  This compares one full-size frame of this run's workload with
     the CPU oracle (the restatement of the reference's CUDA arithmetic, oracle/ms_oracle_*.c) fed the context's maps, masks [and meshes]: the 16SC3
@@ -474,6 +485,8 @@ def main():
                          "calibration.cpp:100,147-194): cylindrical warper, COMPOSE_MEGAPIX 1.4 (every frame through cuda::resize INSIDE the timed region), "
                          "num_bands by the app's rule, seam-scale gains + Voronoi masks, CPW on with 10x10 meshes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frame sets cycled through the batch (SURVEY 8(d): 8 = 298 MB of source; 96 = every frame of the "
+                                                             "default pass distinct, 3.6 GB: nothing of the source survives in the 256 MiB Infinity Cache between passes; 1 = cache-resident A/B)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--egress-convert", action="store_true", help="N>1 egress as 8UC3 canvas + ms_bgr_to_i420_batch instead of ms_stitch_i420 (A/B)")
     ap.add_argument("--emulate-gather", action="store_true", help="single GPU: run the per-frame egress conversion of the N>1 path without the collective (host/GPU cost of that leg)")
@@ -620,7 +633,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
 
     # synthetic input: 8 distinct frames per view, cycled; frame t of the global sequence -> rank t mod G
-    n_distinct = 8
+    n_distinct = max(1, args.distinct)
     pool = [[torch.from_numpy(synth.frame(full_w, full_h, i, t)).to(dev) for i in range(cfg["n"])] for t in range(n_distinct)]
     frames_full = [pool[(rank + j * world) % n_distinct] for j in range(F)]
     if resize_scale:      # timed.cpp:75-85: every frame of every view goes through cuda::resize(compose_scale) before the remap -- per pass, inside the timed region
@@ -931,7 +944,8 @@ def main():
 
     # PMC-measured HBM bytes (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/profile_traffic.sh on the same workload, calibrated on a 1 GiB
     # copy): read from the committed summary -- counters cannot be collected inside this run -- and labelled as such
-    traffic, traffic_call, traffic_src = None, None, None
+    traffic, traffic_call, traffic_src, traffic_stale = None, None, None, None
+    csrc_now = csrc_sha16()
     for tname in ("traffic_%s.json" % args.config, "traffic_latest.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tpath):
@@ -943,6 +957,8 @@ def main():
                 if dom == "k_resize_batch":      # the instrumented time covers every launch of the call's resize (64 images per launch); so must the bytes
                     traffic *= -(-(Fs * cfg["n"]) // 64)
             traffic_call = tj.get("hbm_bytes_per_call")
+            # the counters were collected on the kernels of ONE state of csrc/; the summary records a hash of those sources and the line says when they have moved on
+            traffic_stale = (tj.get("csrc_sha16") != csrc_now) if tj.get("csrc_sha16") else "unknown (summary predates the source hash)"
             traffic_src = "profiles/%s: rocprofv3 PMC passes (FETCH_SIZE x %.2f, WRITE_SIZE x %.2f, calibrated on the tuned copy in the same run) of this workload, " \
                           "collected %s at commit %s (tag %s); NOT measured in this run" % (tname, tj.get("calibration", {}).get("fetch_factor", 2.0), tj.get("calibration", {}).get("write_factor", 1.0),
                                                                                           tj.get("collected", "?"), tj.get("commit", "?"), tj.get("tag"))
@@ -950,6 +966,24 @@ def main():
 
     # ---- the measured ceiling: what a tuned streaming copy / read of 1 GiB reaches on THIS device in THIS run (csrc/compositor.hip k_calib_copy / k_calib_read)
     ceiling = None
+    rank_ceilings = None
+    if world > 1:      # every rank's own streaming-copy ceiling (boxes and GPUs differ by +-8 %): gathered so that the line explains an uneven scaling curve
+        try:
+            n_c = 1 << 28
+            ca = torch.empty(n_c, dtype=torch.uint8, device=dev).random_(0, 255); cb = torch.empty_like(ca)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e9
+            for it in range(5):
+                e0.record(); ms.calib_copy(ca, cb); e1.record(); e1.synchronize()
+                if it >= 1:
+                    best = min(best, e0.elapsed_time(e1))
+            mine = round(2.0 * n_c / (best * 1e-3) / 1e12, 3)
+            del ca, cb
+        except Exception:
+            mine = None
+        allc = [None] * world
+        dist.all_gather_object(allc, mine)
+        rank_ceilings = allc
     if rank == 0 and world == 1:
         try:
             n_c = 1 << 30
@@ -996,7 +1030,7 @@ def main():
                                       cfg["out_w"], cfg["out_h"], "cylindrical panorama (the reference's shipped calibration: seam-scale gains + masks)" if shipped else "equirect, spherical",
                                       pg.num_bands, ("on (%dx%d mesh)" % mesh_nm) if cpw else "off",
                                       (", meshes re-expanded every %d frames" % args.recalib_every) if mesh_pool else "", args.passes, F, frames_per_step, S),
-                       "frames_per_step": frames_per_step, "frames_per_pass": F, "passes_per_step": args.passes, "streams": S, "parallelism": par},
+                       "distinct_frame_sets": n_distinct, "frames_per_step": frames_per_step, "frames_per_pass": F, "passes_per_step": args.passes, "streams": S, "parallelism": par},
             "verified": verified, "verified_how": verify_note,
             # `frac` is the PHYSICAL fraction: HBM bytes of the dominant kernel's launch as the PMC counters saw them / its mean launch duration measured in
             # this run / 8 TB/s.  `frac_contract` prices the same launch at SURVEY 8(d)'s ALGORITHMIC bytes (the level-materialised model: it credits bytes
@@ -1005,15 +1039,17 @@ def main():
                          "achieved": round((traffic if traffic else kb.get(dom, 0.0)) / (kmean[dom] * 1e-3) / 1e9, 1),
                          "frac": round((traffic if traffic else kb.get(dom, 0.0)) / (kmean[dom] * 1e-3) / 8e12, 4),
                          "basis": "pmc-measured HBM bytes" if traffic else "algorithmic bytes (no PMC summary for this workload)",
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "achieved_contract": round(achieved, 1), "frac_contract": round(achieved / 8000.0, 4),
                          "alg_bytes_per_launch": int(kb.get(dom, 0)), "mean_launch_ms": round(kmean[dom], 5),
                          "frac_of_copy_ceiling": (round(traffic / (kmean[dom] * 1e-3) / 1e12 / ceiling["copy_TBps"], 4) if (traffic and ceiling and "copy_TBps" in ceiling) else None)},
             "ceiling": ceiling,
             "frame_roofline": {"alg_bytes_per_frame": int(b_alg_frame), "gpu_ms_per_frame": round(gpu_ms_step / Fs, 5),
                                "achieved_GBps": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 1e9, 1),
-                               "frac": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),
-                               "wall_frac": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4),
+                               # NOT roofline fractions: SURVEY 8(d)'s level-materialised byte MODEL priced at 8 TB/s over the measured time; > 1 because the design moves
+                               # fewer bytes than the model (u8 levels, no accumulator read-modify-write, skipped tiles).  The physical figures are the *_traffic ones.
+                               "vs_contract_model": round(b_alg_frame * Fs / (gpu_ms_step * 1e-3) / 8e12, 4),
+                               "wall_vs_contract_model": round(b_alg_frame * total_frames / world / elapsed / 8e12, 4),
                                # SURVEY 8(d) bounds: B_min = perfect fusion (inputs + weight pyramids + output), B_ref = the reference's own pass structure
                                "b_min_bytes_per_frame": int(b_min_frame), "b_ref_bytes_per_frame": int(b_ref_frame),
                                "hbm_bytes_per_frame": (int(traffic_call / Fs) if traffic_call else None),
@@ -1021,8 +1057,8 @@ def main():
                                "wall_frac_traffic": (round(traffic_call / Fs * total_frames / world / elapsed / 8e12, 4) if traffic_call else None),
                                "wall_frac_of_copy_ceiling": (round(traffic_call / Fs * total_frames / world / elapsed / 1e12 / ceiling["copy_TBps"], 4)
                                                              if (traffic_call and ceiling and "copy_TBps" in ceiling) else None),
-                               "note": "the *_traffic fractions use PMC-measured HBM bytes and are the physical ones; frac / wall_frac use the algorithmic-byte model "
-                                       "and exceed 1 where the design moves fewer bytes than the model (u8 levels, no accumulator read-modify-write, skipped tiles)"},
+                               "note": "the *_traffic fractions use PMC-measured HBM bytes and are the physical ones; *vs_contract_model price the algorithmic-byte model "
+                                       "of SURVEY 8(d) and exceed 1 where the design moves fewer bytes than the model"},
             "kernels_ms_per_call": {k: round(v, 5) for k, v in kmean.items()},
             "latency": lat,
         }
@@ -1034,6 +1070,13 @@ def main():
             res["gather"] = {"gathered_passes": n_gathered, "of_passes": args.steps * args.passes, "every": state["gather_every"],
                              "GBps_into_sink": round(n_gathered * F * (world - 1) * slabs[0][0].numel() / elapsed / 1e9, 2),
                              "live_rate_every": live_gather[1], "live_rate_gathered_passes": live_gather[2]}
+        if world > 1:      # what a reader of the first multi-GPU record needs, at the top level: compute-only and live-rate scaling beside `value`, what the communicator saw, every rank's copy ceiling
+            res["comm_nranks"] = (dist_info or {}).get("comm_nranks")
+            res["transport"] = (dist_info or {}).get("transport")
+            res["pci_bus_ids"] = (dist_info or {}).get("pci_bus_ids")
+            res["rank_copy_TBps"] = rank_ceilings
+            res["how_to_read"] = ("value = every frame of every rank gathered on rank 0 inside the timed region (one sink: bound by its inbound xGMI links, not by the compositor); "
+                                  "value_no_gather = compute-only scaling; value_live_rate_gather = the egress of a 30 fps stream per rank (BASELINE configs[3])")
         if dist_info is not None:
             res["dist"] = dist_info      # what the communicator itself saw: transport, nranks (RCCL's own count), device ordinals and PCI bus ids of every rank
         if live is not None:

@@ -264,7 +264,8 @@ typedef struct ms_config {
      * whose edges move by up to this many pixels, so a re-warped mask needs no new plan.  An update whose mesh displaces further than the margin
      * (ms_get_mesh_displacement) leaves the tables as they are.  0: ms_update_mask rebuilds tables and work lists synchronously (calibration-time call). */
     int update_mask_margin;
-    int reserved[1];             /* must be 0 */
+    int self_check;              /* 1: ms_init_blender verifies the shared-reciprocal division of the band kernels against IEEE division over every
+                                  * denominator of this context's tables (a few ms; the test suite sets it); 0: no check (was reserved[0], must be 0 or 1) */
 } ms_config;
 
 MS_API int ms_create(const ms_config *cfg, ms_ctx **out);
@@ -370,6 +371,12 @@ MS_API int ms_get_result_mask(ms_ctx *ctx, ms_image *mask);
  * of band `level` by class -- owned: one view with weight exactly 1 everywhere (no multiply, no division); exclusive (level 0 only): several views meet but every
  * pixel has one contributing view with weight exactly 1 (binary seam masks) -- the same integer arithmetic, selected by the mask bytes; general: the reference's
  * float multiply + divide.  Results are identical in every class (tests/test_compositor_gpu.py); bands without a map report every cell as general. */
+/* Calibration tables as a blob (the reference re-runs stitch_calib at every start, APP/timed.cpp:553).  ms_save_tables writes what the static
+ * tables of a ready context derive from -- configuration, per view K, R, gain and blend mask, blender kind -- into `buf` (buf == NULL: only *bytes_out, the size
+ * needed).  ms_load_tables creates a context from such a blob and rebuilds every table (same library build => bit-identical tables, e.g. on every rank of a
+ * multi-GPU run); CPW meshes are run-time state and are set afterwards (ms_set_meshes).  Corrupt / foreign blobs are MS_ERR_INVALID before the device is touched. */
+MS_API int ms_save_tables(ms_ctx *ctx, void *buf, size_t cap, size_t *bytes_out);
+MS_API int ms_load_tables(const void *buf, size_t bytes, ms_ctx **out, ms_stream stream);
 MS_API int ms_get_band_cells(ms_ctx *ctx, int level, unsigned *owned, unsigned *exclusive, unsigned *general);
 
 /* geometry read-back (top_/left_/bottom_/right_, x_tl_.., dst_roi_: blenders.hpp:143-175) */

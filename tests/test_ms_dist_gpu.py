@@ -95,6 +95,29 @@ def test_full_size_two_ranks(cuda):
     assert run(*multi(2), "--col-shards", 2, "--frames", 8, "--batch", 2, rig="cfg2")["checksum_all"] == one["checksum_all"]
 
 
+def test_full_size_config5_two_shards_times_two_groups(cuda):
+    """BASELINE configs[4] at FULL size (12 x 4K -> 7680 x 3840, 5 bands) in its own shape: 2 column shards per frame x 2 frame-parallel groups = 4 ranks
+    (sharing the GPU over the host transport on a one-GPU box), against the single-rank run; plus the per-rank time breakdown the line carries."""
+    one = run("--gpus", 1, "--frames", 4, "--batch", 1, rig="cfg5", timeout=1200)
+    many = run(*multi(4), "--col-shards", 2, "--frames", 4, "--batch", 1, rig="cfg5", timeout=1200)
+    assert many["groups"] == 2 and many["col_shards"] == 2 and many["frames"] == 4
+    assert many["checksum_all"] == one["checksum_all"]
+    assert max(many["views_read_per_rank"]) < one["views"]                 # a shard uploads only the views that reach its window (7 and 8 of 12)
+    assert len(many["per_rank"]) == 4 and all(t["stitch_gpu_ms"] > 0 and t["wall_ms"] > 0 for t in many["per_rank"])
+    assert many["per_rank"][2]["gather_stream_ms"] > 0                      # the second group's leader sent its slabs to the sink
+
+
+def test_full_size_config3_recalibration_every_60_frames(cuda):
+    """BASELINE configs[2] at full size through the multi-rank pipeline: CPW with 40 x 40 meshes, new meshes every 60 frames from rank 0's recalibration
+    thread, broadcast one batch ahead -- 2 ranks x batches of 6 frames (swap at frame 60 = a batch boundary of both the 1- and the 2-rank run)."""
+    args = ("--frames", 72, "--batch", 6, "--recalib-every", 60, "--mesh", "40x40")
+    one = run("--gpus", 1, *args, rig="cfg2", timeout=1200)
+    assert one["recalibrations_applied"] == 1 and one["cpw"] is True
+    many = run(*multi(2), *args, rig="cfg2", timeout=1200)
+    assert many["recalibrations_applied"] == 1 and many["checksum_all"] == one["checksum_all"]
+    assert all(t["mesh_exchange_host_ms"] >= 0 for t in many["per_rank"]) and len(many["per_rank"]) == 2
+
+
 def test_device_buffers_through_the_binding(ms, cuda):
     """msdist.Dist with device tensors: a one-rank communicator on RCCL (self send / recv in a group, broadcast, barrier) and, from two threads
     sharing the GPU, the host transport moving device memory."""

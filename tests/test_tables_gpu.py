@@ -413,3 +413,41 @@ def test_mesh_to_map_adversarial_meshes(ms, cuda, oracle, kind):
         r2 = oracle.convert_mesh_to_map(sx, sy, r.width, r.height)
         assert np.array_equal(g2[0], r2[0], equal_nan=True) and np.array_equal(g2[1], r2[1], equal_nan=True)
     comp.close()
+
+
+def test_tables_blob_round_trip_rebuilds_identical_tables_and_frames(ms, cuda):
+    """ms_save_tables / ms_load_tables (the reference re-runs stitch_calib at every start, timed.cpp:553): a context rebuilt from the blob has the same masks,
+    weight pyramids, result mask and work lists (band cell classes), and stitches the same frame bit for bit; corrupt blobs are refused."""
+    cfg = synth.CONFIGS["mini6"]
+    comp = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), num_bands=cfg["num_bands"], out_size=(cfg["out_w"], cfg["out_h"]))
+    gains = synth.gains(cfg["n"])
+    for i in range(cfg["n"]):
+        comp.set_camera(i, *synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i))
+        comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    blob = comp.save_tables()
+    twin = ms.Compositor.from_tables(blob)
+    assert twin.n == cfg["n"]
+    for i in range(cfg["n"]):
+        assert torch.equal(comp.mask(i), twin.mask(i))
+        assert comp.view_geom(i).roi.tuple() == twin.view_geom(i).roi.tuple()
+        for l in range(cfg["num_bands"] + 1):
+            assert torch.equal(comp.weight_level(i, l), twin.weight_level(i, l))
+    assert torch.equal(comp.result_mask(), twin.result_mask())
+    for l in range(cfg["num_bands"]):
+        assert comp.band_cells(l) == twin.band_cells(l)
+    frames = [[torch.from_numpy(synth.frame(cfg["w"], cfg["h"], i, 3)).cuda() for i in range(cfg["n"])]]
+    pg = comp.pano_geom()
+    outs = []
+    for c in (comp, twin):
+        o16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device="cuda")
+        o8 = torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device="cuda")
+        c.stitch(frames, out8u=[o8], out16s=[o16])
+        torch.cuda.synchronize()
+        outs.append((o16, o8))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    bad = bytearray(blob); bad[len(bad) // 2] ^= 0x40
+    with pytest.raises(ms.MsError):
+        ms.Compositor.from_tables(bytes(bad))
+    with pytest.raises(ms.MsError):
+        ms.Compositor.from_tables(blob[:-5])

@@ -26,6 +26,16 @@ def short(n):
     return n.split("(")[0]
 
 
+def csrc_sha16(root):      # same hash as bench.py's: the line flags a summary whose kernels have changed since
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "video-stitcher_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp", ".inc")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main(out, tag, cfg, frames):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
@@ -40,7 +50,7 @@ def main(out, tag, cfg, frames):
     f_w = GiB / (cal_w[0][0] * 1024.0) if cal_w and cal_w[0][0] > 0 else 1.0
     import datetime
     res = {"tag": tag, "config": cfg, "frames_per_launch": int(frames), "unit": "bytes per launch",
-           "collected": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"), "commit": os.environ.get("MS_COMMIT", "?"),
+           "collected": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"), "commit": os.environ.get("MS_COMMIT", "?"), "csrc_sha16": csrc_sha16(root),
            "calibration": {"kernel": "k_calib_copy (1 GiB read + 1 GiB written, 16 B/lane, 4 non-temporal loads in flight: the tuned stream)",
                            "fetch_factor": f_r, "write_factor": f_w,
                            "FETCH_SIZE_KB_reported": cal_r[0][0] if cal_r else None, "WRITE_SIZE_KB_reported": cal_w[0][0] if cal_w else None,

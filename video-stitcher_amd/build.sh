@@ -5,6 +5,8 @@ cd "$(dirname "$0")/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function ${MS_EXTRA_FLAGS:-}"
 mkdir -p ../build
+# a change of flags (e.g. a -DMS_DEV_KNOBS developer build before, the production flags now) rebuilds every object
+if [ "$(cat ../build/flags.txt 2>/dev/null)" != "$FLAGS" ]; then rm -f ../build/*.o; echo "$FLAGS" > ../build/flags.txt; fi
 newest_hdr=$(ls -t *.hpp *.inc ../../include/ms_stitch.h ../../include/ms_dist.h | head -1)
 pids=()
 for f in prims.hip compositor.hip mesh_solver.hip matcher.hip features.hip calib.hip api.cpp geometry.cpp dist.cpp; do

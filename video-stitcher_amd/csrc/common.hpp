@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "../../include/ms_stitch.h"
 
@@ -76,6 +77,15 @@ struct DeviceScratch {
     }
 };
 DeviceScratch &device_scratch();
+
+// Developer A/B knobs (occupancy, kernel variants): read from the environment ONLY in a -DMS_DEV_KNOBS build (tools/build_ab.sh).  In the production
+// library they are their defaults at compile time: which kernels a deployed libmsstitch.so launches is a function of the context, never of the
+// caller's environment.  dflt is returned when the variable is unset.
+#ifdef MS_DEV_KNOBS
+static inline int dev_knob(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr int dev_knob(const char *, int dflt) { return dflt; }
+#endif
 
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 static inline hipStream_t as_stream(ms_stream s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1839,8 +1839,8 @@ static int build_plan(ms_ctx *c)
                 // registers (4 instead of 6 waves per SIMD) cost more than the alignment saves (measured: 1.9x -6 %, 2.7x +17 %)
                 c->warp_minification = sw_n ? sw_sum / sw_n / WARP_TW : 0.0;
                 c->warp_aligned = c->warp_minification > 0 && c->warp_minification < 2.3;
-                if (const char *e = getenv("MS_WARP_ALIGNED")) c->warp_aligned = atoi(e) != 0;
-                if (getenv("MS_DEBUG_PLAN")) {
+                { const int k = dev_knob("MS_WARP_ALIGNED", -1); if (k >= 0) c->warp_aligned = k != 0; }
+                if (dev_knob("MS_DEBUG_PLAN", 0)) {
                     int big = 0, last = 0, interior = 0; long long bytes = 0;
                     for (const WarpTile &t : tiles) {
                         if (t.flags & 1) bytes += 16ll * warp_lds_np(t.sw) * t.sh;
@@ -1882,7 +1882,7 @@ static int build_plan(ms_ctx *c)
                     tiles.push_back(t);
                 }
         }
-        if (getenv("MS_DEBUG_PLAN")) { int nf = 0; for (auto &t : tiles) nf += (t.flags & 2) != 0; fprintf(stderr, "[plan] stage-1 tiles %zu, reachable within %d px: %d\n", tiles.size(), CPW_DMAX, nf); }
+        if (dev_knob("MS_DEBUG_PLAN", 0)) { int nf = 0; for (auto &t : tiles) nf += (t.flags & 2) != 0; fprintf(stderr, "[plan] stage-1 tiles %zu, reachable within %d px: %d\n", tiles.size(), CPW_DMAX, nf); }
         {   // reachable tiles first, each part in XCD order on its own: when the others exit early every XCD still gets an equal share
             std::vector<WarpTile> a, b;
             for (const WarpTile &t : tiles) ((t.flags & 2) ? a : b).push_back(t);
@@ -1968,7 +1968,7 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     if (!cfg || !out) return fail(MS_ERR_INVALID, "ms_create: null argument");
     if (int e = require_device()) return e;
     MS_CHECK(cfg->struct_size == sizeof(ms_config), "ms_create: ms_config.struct_size is %u, this library expects %zu (header / library mismatch)", cfg->struct_size, sizeof(ms_config));
-    MS_CHECK(cfg->reserved[0] == 0, "ms_create: ms_config.reserved must be zero");
+    MS_CHECK(cfg->self_check == 0 || cfg->self_check == 1, "ms_create: ms_config.self_check must be 0 or 1");
     MS_CHECK(cfg->update_mask_margin >= 0 && cfg->update_mask_margin <= 64 && (cfg->update_mask_margin == 0 || (cfg->enable_cpw && cfg->num_bands >= 1 && cfg->view_shards <= 1)),
              "ms_create: update_mask_margin %d needs enable_cpw, num_bands >= 1, no view shards, and must be in [0, 64]", cfg->update_mask_margin);
     MS_CHECK(cfg->num_views >= 1 && cfg->num_views <= MAX_VIEWS, "ms_create: num_views %d not in [1,%d]", cfg->num_views, MAX_VIEWS);
@@ -2515,7 +2515,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             MS_HIP(hipMemsetAsync(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned), st));      // "unbounded" until measured
         }
     }
-    if (const char *chk = getenv("MS_CHECK_DIVIDE")) if (atoi(chk) != 0) {
+    if (c->cfg.self_check != 0) {
         // the band kernels' shared-reciprocal division against the compiler's IEEE a / d, over every distinct denominator these tables hold
         // and all int16 numerators (common.hpp, DivBy): the bit-exactness claim rests on this check, not on an argument about the sequence
         std::vector<float> hd(den_total);
@@ -2926,6 +2926,21 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
         else K<MS_PROJ_PLANE, AL, NF><<<MS_UNPAREN CFG>>>(__VA_ARGS__);                                                      \
     } while (0)
 
+// k_warp_s<CPW, PROJ, NF>: NF frames per lane, or 1 for a one-frame call
+#define MS_WARP_S_LAUNCH(CPW_, NF_, LDS_, ...)                                                                                                  \
+    do {                                                                                                                                        \
+        const dim3 b_(WARP_BX, WARP_WY);                                                                                                        \
+        if (F == 1) { const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, 1);                                                                     \
+            if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_s<CPW_, MS_PROJ_SPHERICAL, 1><<<g_, b_, LDS_, st>>>(__VA_ARGS__);                 \
+            else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_s<CPW_, MS_PROJ_CYLINDRICAL, 1><<<g_, b_, LDS_, st>>>(__VA_ARGS__);        \
+            else k_warp_s<CPW_, MS_PROJ_PLANE, 1><<<g_, b_, LDS_, st>>>(__VA_ARGS__);                                                            \
+        } else { const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, NF_));                                                             \
+            if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_s<CPW_, MS_PROJ_SPHERICAL, NF_><<<g_, b_, LDS_, st>>>(__VA_ARGS__);               \
+            else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_s<CPW_, MS_PROJ_CYLINDRICAL, NF_><<<g_, b_, LDS_, st>>>(__VA_ARGS__);      \
+            else k_warp_s<CPW_, MS_PROJ_PLANE, NF_><<<g_, b_, LDS_, st>>>(__VA_ARGS__);                                                          \
+        }                                                                                                                                       \
+    } while (0)
+
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
                        int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{}, ms_image *out_i420 = nullptr)
 {
@@ -3011,8 +3026,14 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     // (5 waves per SIMD) since its tap addresses became SGPR base + 32-bit offset, and runs 3.7 % FASTER at 4 waves (20 000 bytes -> 8 workgroups per CU): fewer waves
     // thrash the vector cache less (same-box sweep, us per 16 frames: 5 waves 215, 4 waves 207, 3 waves 214; profiles/r03_resize_ab.txt).  The unaligned variant
     // (config 5, 61 VGPRs) and the mesh remap (98 VGPRs = 4 waves anyway) are best left alone.  MS_WARP_LDS=<bytes> overrides all three (A/B).
-    static const int warp_lds_env = [] { const char *e = getenv("MS_WARP_LDS"); return e ? atoi(e) : -1; }();
+    static const int warp_lds_env = dev_knob("MS_WARP_LDS", -1);
     const size_t warp_lds = warp_lds_env >= 0 ? (size_t)warp_lds_env : 0, warp_lds_al = warp_lds_env >= 0 ? (size_t)warp_lds_env : 20000;
+    // k_warp_s / the shared form of k_stage1_t: every frame of a view with the same row step and the same address modulo 4 (then a pixel's aligned tap offset is one
+    // 32-bit value for all frames of a lane).  True for any sane caller (frames of one camera in buffers of one shape); checked, not assumed.
+    static const bool warp_shared_knob = dev_knob("MS_WARP_SHARED", 1) != 0;
+    bool src_shared = warp_shared_knob && S.mode != 2;
+    for (int i = N; i < F * N && src_shared; ++i)
+        if (src.p[i]) src_shared = src.p[i % N] && src.step[i] == src.step[i % N] && (((uintptr_t)src.p[i] ^ (uintptr_t)src.p[i % N]) & 3) == 0;
     const bool int_only = c->l0_integer_only && P.pure[0] != nullptr;      // (read under mesh_mu, like the table pointers: an enqueue-only mask update clears it)
 
     // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
@@ -3045,21 +3066,32 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         if (c->cfg.debug_simple_kernels == 0)
         {
             // frames per lane of the first CPW remap: three where the source is sampled about 1 : 1 (VALU-bound), two otherwise (see k_stage1_t)
-            static const int s1_env = [] { const char *e = getenv("MS_S1_NF"); return e ? atoi(e) : 0; }();
+            static const int s1_env = dev_knob("MS_S1_NF", 0);
             const int s1_nf = s1_env == 2 || s1_env == 3 ? s1_env : ((c->warp_minification > 0 && c->warp_minification < 1.5) ? 3 : 2);
-            static const int s1_lds = [] { const char *e = getenv("MS_S1_LDS"); return e ? atoi(e) : 0; }();      // occupancy A/B knob (dynamic LDS nobody touches)
+            static const int s1_lds = dev_knob("MS_S1_LDS", 0);      // occupancy A/B knob (dynamic LDS nobody touches)
 #define MS_S1_LAUNCH(AL, NF) MS_PROJ_AL_LAUNCH(k_stage1_t, AL, NF, (dim3(c->n_stage1_tiles, 1, div_up(F, NF)), dim3(WARP_BX, S1_BY), s1_lds, st), \
                     (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F)
-            if (c->warp_aligned) { if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
+#define MS_S1S_LAUNCH(NF)                                                                                                                                     \
+    do {                                                                                                                                                      \
+        const dim3 g_(c->n_stage1_tiles, 1, div_up(F, NF)), b_(WARP_BX, S1_BY);                                                                               \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_stage1_s<MS_PROJ_SPHERICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_s<MS_PROJ_CYLINDRICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+        else k_stage1_s<MS_PROJ_PLANE, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+    } while (0)
+            if (c->warp_aligned && src_shared) { if (s1_nf == 3) MS_S1S_LAUNCH(3); else MS_S1S_LAUNCH(2); }
+            else if (c->warp_aligned) { if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
             else { if (s1_nf == 3) MS_S1_LAUNCH(false, 3); else MS_S1_LAUNCH(false, 2); }
 #undef MS_S1_LAUNCH
+#undef MS_S1S_LAUNCH
         }
         else
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
-        if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
+        if (c->warp_tiled && c->cfg.debug_simple_kernels == 0 && warp_shared_knob && (c->stage_stride & 3) == 0)      // the stage images of a view: same pitch, same address modulo 4 in every frame
+            MS_WARP_S_LAUNCH(true, warp_nf(true), warp_lds, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+        else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
             MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, warp_nf(true))), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
@@ -3068,7 +3100,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         // opt-in (reserved[1] = 1 or MS_WARP_ASYNC=1): source tiles staged in LDS by asynchronous LDS-DMA, persistent waves (k_warp_a) -- bit-identical,
         // measured slower than the direct gathers on config 2 (353 vs 242 us per 16 frames: at its 1.6-2.1 x minification only 54 % of the tiles' source
         // boxes fit a staging buffer and 10 waves per CU cannot hide what 20 do; profiles/r02_warp_probes.txt)
-        static const bool env_on = [] { const char *e = getenv("MS_WARP_ASYNC"); return e && atoi(e) != 0; }();
+        static const bool env_on = dev_knob("MS_WARP_ASYNC", 0) != 0;
         bool staged = c->warp_lds_tiles > 0 && (c->cfg.warp_lds_stage == 1 || (env_on && c->cfg.warp_lds_stage != 2));
         for (int i = 0; i < F * N; ++i) staged = staged && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
         if (staged) {
@@ -3077,7 +3109,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         } else
         {
-            if (c->warp_aligned)
+            if (c->warp_aligned && src_shared)
+                MS_WARP_S_LAUNCH(false, WARP_NF, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            else if (c->warp_aligned)
                 MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else
                 MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
@@ -3103,7 +3137,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         const int ow = (std::max(c->max_pw >> l, 1) + 1) / 2, oh = (std::max(c->max_ph >> l, 1) + 1) / 2;
         if (c->down_vec[l] && c->cfg.debug_simple_kernels == 0) {   // level-l widths are multiples of 8: tile list, DOWN_ROWS (4) rows x 4 cols per lane
             const dim3 g(c->n_down_tiles[l], 3, F), b(32, 8);
-            static const int down_lds = [] { const char *e = getenv("MS_DOWN_LDS"); return e ? atoi(e) : 0; }();      // occupancy A/B knob (dynamic LDS nobody touches)
+            static const int down_lds = dev_knob("MS_DOWN_LDS", 0);      // occupancy A/B knob (dynamic LDS nobody touches)
             if (l == 0) k_down_t<true><<<g, b, down_lds, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, g0, c->g0_stride, gl, c->gl_stride);
             else        k_down_t<false><<<g, b, 0, st>>>((const DownTile *)c->down_tiles[l].p, vt, l, gl, c->gl_stride, gl, c->gl_stride);
         } else {
@@ -3134,7 +3168,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else K<L0, 2><<<G, B, 0, st>>>(__VA_ARGS__);                    \
     } while (0)
     int l_first = nb - 1;
-    static const bool bt2_off = [] { const char *e = getenv("MS_LIVE_TAIL"); return e && atoi(e) == 0; }();
+    static const bool bt2_off = dev_knob("MS_LIVE_TAIL", 1) == 0;
     const bool bt2 = F <= 2 && c->btail2_t >= 0 && !bt2_off;      // live mode (1-2 frames per call): launches dominate, the band tail starts one band finer
     const int bt_t = bt2 ? c->btail2_t : c->btail_t, bt_lds = bt2 ? c->btail2_lds : c->btail_lds, bt_strips = bt2 ? c->btail2_strips : c->btail_strips;
     if (S.mode == 0 && bt_t >= 0) {      // bands nb .. bt_t in one launch
@@ -3144,7 +3178,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             for (int l = 0; l < bt_t; ++l) { ra = std::max(ra / 2 - 1, 0); rb = std::min((rb + 1) / 2 + 1, P.qw[l + 1]); }
             s0 = std::min(ra / BTAIL_W, bt_strips - 1); s1 = std::max(std::min(div_up(rb, BTAIL_W), bt_strips), s0 + 1);
         }
-        static const int bt_rows = [] { const char *e = getenv("MS_BTAIL_ROWS"); return e ? atoi(e) : 0; }();      // (A/B: lane rows per workgroup)
+        static const int bt_rows = dev_knob("MS_BTAIL_ROWS", 0);      // (A/B: lane rows per workgroup)
         const dim3 bt_blk(64, bt_rows > 0 ? bt_rows : (F <= 2 ? 16 : 4));      // live mode: a strip's few hundred quads per band on 1024 lanes instead of 256 -- fewer serial rounds
         k_blend_tail<<<dim3(s1 - s0, 3, F), bt_blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0);
         MS_LAUNCH_CHECK();
@@ -3158,9 +3192,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     for (int l = l_first; l >= 0; --l) {
         if (c->blend_vec[l] && c->cfg.debug_simple_kernels == 0) {
             const dim3 g(c->n_blend_tiles[l], 4, F), b(32, 2);
-            static const bool no_cls = [] { const char *e = getenv("MS_BLEND_CLS"); return e && atoi(e) == 0; }();      // MS_BLEND_CLS=0: always the all-classes build (A/B)
+            static const bool no_cls = dev_knob("MS_BLEND_CLS", 1) == 0;      // MS_BLEND_CLS=0: always the all-classes build (A/B)
             // level 0 without general cells (the usual case: binary Voronoi seam masks): the build that has no general path -- 88 instead of 120 VGPRs, 5 waves per SIMD
-            static const int blend_lds = [] { const char *e = getenv("MS_BLEND_LDS"); return e ? atoi(e) : 0; }();      // occupancy A/B knob
+            static const int blend_lds = dev_knob("MS_BLEND_LDS", 0);      // occupancy A/B knob
             if (l == 0 && S.mode == 0 && int_only && !no_cls) k_blend8<true, 0, 1><<<g, b, blend_lds, st>>>((const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else if (l == 0) MS_MODE_LAUNCH2(k_blend8, true, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
             else        MS_MODE_LAUNCH2(k_blend8, false, g, b, (const BlendTile *)c->blend_tiles[l].p, vt, P, l, g0, c->g0_stride, gl, c->gl_stride, cl, c->cl_stride, out, S);
@@ -3358,6 +3392,111 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
     { std::lock_guard<std::mutex> mk(c->mesh_mu); active = c->tab_active; wait = c->tab_wait; }
     if (wait) MS_HIP(hipEventSynchronize(c->tab_ready));
     *m = ms_image{active == 1 ? c->alt.result_mask.p : c->result_mask.p, (size_t)c->pano.mask_pitch, c->pano.fw, c->pano.fh, MS_8UC1};
+    return MS_OK;
+}
+
+// ---- calibration tables as a blob (the reference recomputes its calibration at every start, timed.cpp:553) ---------------------
+// What a context's static tables are derived FROM: the configuration, per view the camera (K, R), the exposure gain and the blend mask, and the blender kind.  Every
+// table the per-frame kernels read (projection tables, weight pyramids, weight sums, owner maps, work lists) is a deterministic function of these on one build of
+// the library, so the blob stores the inputs and ms_load_tables replays ms_create / ms_set_camera / ms_set_gain / ms_build_maps / ms_set_mask / ms_init_blender
+// (or ms_init_feather).  A start-up then skips the seam-scale calibration (stitch_calib), and every rank of a multi-GPU run builds identical tables from one
+// blob.  CPW meshes are run-time state (ms_set_meshes) and are not part of it.
+namespace {
+struct TablesHeader {
+    char magic[8];            // "MSTBL01"
+    unsigned header_bytes, config_bytes;
+    int n_views, blender_kind; // 0 = multiband / plain masks (ms_init_blender), 1 = FeatherBlender weights (ms_init_feather)
+    float feather_sharpness;
+    unsigned reserved;
+    unsigned long long total_bytes, checksum;      // FNV-1a over everything behind the header
+    ms_config cfg;
+};
+struct TablesView { float K[9], R[9]; double gain; int aw, ah, roi_x, roi_y; };
+unsigned long long fnv1a(const unsigned char *p, size_t n)
+{
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
+int ms_save_tables(ms_ctx *c, void *buf, size_t cap, size_t *bytes_out)
+{
+    if (!c || !bytes_out) return fail(MS_ERR_INVALID, "ms_save_tables: null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_save_tables: call ms_init_blender / ms_init_feather first");
+    size_t need = sizeof(TablesHeader);
+    for (int v = 0; v < c->N; ++v) need += sizeof(TablesView) + (size_t)c->roi[v].width * c->roi[v].height;
+    *bytes_out = need;
+    if (!buf) return MS_OK;                          // size query
+    MS_CHECK(cap >= need, "ms_save_tables: buffer of %zu bytes, %zu needed", cap, need);
+    std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);
+    unsigned char *o = static_cast<unsigned char *>(buf);
+    TablesHeader h{};
+    memcpy(h.magic, "MSTBL01", 8);
+    h.header_bytes = (unsigned)sizeof(TablesHeader); h.config_bytes = (unsigned)sizeof(ms_config);
+    h.n_views = c->N; h.blender_kind = c->feather_sharpness >= 0.f ? 1 : 0; h.feather_sharpness = c->feather_sharpness;
+    h.total_bytes = need; h.cfg = c->cfg;
+    size_t at = sizeof(TablesHeader);
+    for (int v = 0; v < c->N; ++v) {
+        TablesView tv{};
+        memcpy(tv.K, c->K[v], sizeof(tv.K)); memcpy(tv.R, c->R[v], sizeof(tv.R));
+        tv.gain = c->gain[v]; tv.aw = c->roi[v].width; tv.ah = c->roi[v].height; tv.roi_x = c->roi[v].x; tv.roi_y = c->roi[v].y;
+        memcpy(o + at, &tv, sizeof(tv)); at += sizeof(tv);
+        // the mask ms_init_blender was given (the caller's / the seam finder's; a re-warp through a CPW mesh is run-time state like the mesh itself)
+        MS_HIP(hipMemcpy(o + at, (const uint8_t *)c->masks.p + c->mask_off[v], (size_t)tv.aw * tv.ah, hipMemcpyDeviceToHost));
+        at += (size_t)tv.aw * tv.ah;
+    }
+    h.checksum = fnv1a(o + sizeof(TablesHeader), need - sizeof(TablesHeader));
+    memcpy(o, &h, sizeof(h));
+    return MS_OK;
+}
+
+int ms_load_tables(const void *buf, size_t bytes, ms_ctx **out, ms_stream stream)
+{
+    if (!buf || !out) return fail(MS_ERR_INVALID, "ms_load_tables: null argument");
+    *out = nullptr;
+    const unsigned char *in = static_cast<const unsigned char *>(buf);
+    TablesHeader h;
+    MS_CHECK(bytes >= sizeof(h), "ms_load_tables: %zu bytes is not a table blob", bytes);
+    memcpy(&h, in, sizeof(h));
+    MS_CHECK(memcmp(h.magic, "MSTBL01", 8) == 0, "ms_load_tables: not a table blob (bad magic)");
+    MS_CHECK(h.header_bytes == sizeof(TablesHeader) && h.config_bytes == sizeof(ms_config) && h.cfg.struct_size == sizeof(ms_config),
+             "ms_load_tables: the blob was written by a library with another ms_config / header layout");
+    MS_CHECK(h.total_bytes == bytes && h.n_views >= 1 && h.n_views <= MAX_VIEWS && h.n_views == h.cfg.num_views, "ms_load_tables: truncated or inconsistent blob");
+    MS_CHECK(fnv1a(in + sizeof(h), bytes - sizeof(h)) == h.checksum, "ms_load_tables: checksum mismatch (corrupt blob)");
+    size_t at = sizeof(h);
+    for (int v = 0; v < h.n_views; ++v) {            // structure check before anything touches the device
+        TablesView tv;
+        MS_CHECK(at + sizeof(tv) <= bytes, "ms_load_tables: truncated blob");
+        memcpy(&tv, in + at, sizeof(tv));
+        MS_CHECK(tv.aw > 0 && tv.ah > 0 && at + sizeof(tv) + (size_t)tv.aw * tv.ah <= bytes, "ms_load_tables: truncated blob");
+        at += sizeof(tv) + (size_t)tv.aw * tv.ah;
+    }
+    MS_CHECK(at == bytes, "ms_load_tables: trailing bytes");
+    ms_ctx *c = nullptr;
+    if (int e = ms_create(&h.cfg, &c)) return e;
+    int err = MS_OK;
+    at = sizeof(h);
+    std::vector<size_t> mask_at((size_t)h.n_views);
+    std::vector<TablesView> tvs((size_t)h.n_views);
+    for (int v = 0; v < h.n_views && !err; ++v) {
+        memcpy(&tvs[v], in + at, sizeof(TablesView));
+        mask_at[v] = at + sizeof(TablesView);
+        at = mask_at[v] + (size_t)tvs[v].aw * tvs[v].ah;
+        err = ms_set_camera(c, v, tvs[v].K, tvs[v].R);
+        if (!err) err = ms_set_gain(c, v, tvs[v].gain);
+    }
+    if (!err) err = ms_build_maps(c, stream);
+    for (int v = 0; v < h.n_views && !err; ++v) {
+        // the warped-view rectangles are recomputed from K, R: a blob whose masks do not fit them comes from a library whose geometry differs
+        if (c->roi[v].width != tvs[v].aw || c->roi[v].height != tvs[v].ah || c->roi[v].x != tvs[v].roi_x || c->roi[v].y != tvs[v].roi_y)
+            err = fail(MS_ERR_INVALID, "ms_load_tables: view %d warps to %dx%d at (%d,%d) here, the blob holds %dx%d at (%d,%d)", v, c->roi[v].width, c->roi[v].height,
+                       c->roi[v].x, c->roi[v].y, tvs[v].aw, tvs[v].ah, tvs[v].roi_x, tvs[v].roi_y);
+        else err = ms_set_mask(c, v, in + mask_at[v], (size_t)tvs[v].aw);
+    }
+    if (!err) err = h.blender_kind == 1 ? ms_init_feather(c, h.feather_sharpness, stream) : ms_init_blender(c, stream);
+    if (err) { ms_destroy(c); return err; }
+    *out = c;
     return MS_OK;
 }
 

@@ -339,7 +339,7 @@ int launch_resize_linear_batch(const ms_image *src, ms_image *dst, int n, double
     const unsigned long long n_lanes = (unsigned long long)lpr * (unsigned)div_up(dst[0].rows, RS_ROWS);
     // downscales whose 4-pixel windows fit 24 bytes (and images whose lane index times the row length fits 32 bits: the kernel's division); else one pixel per lane
     const bool x4 = ifx >= 1.f && ifx <= 1.6f && src[0].cols >= 16 && n_lanes * lpr < 0x100000000ull &&
-                    (unsigned long long)src[0].rows * src[0].step < 0x100000000ull && (unsigned long long)dst[0].rows * dst[0].step < 0x100000000ull && getenv("MS_RESIZE_SIMPLE") == nullptr;
+                    (unsigned long long)src[0].rows * src[0].step < 0x100000000ull && (unsigned long long)dst[0].rows * dst[0].step < 0x100000000ull && dev_knob("MS_RESIZE_SIMPLE", 0) == 0;
     for (int i0 = 0; i0 < n; i0 += RESIZE_BATCH) {
         const int m = std::min(RESIZE_BATCH, n - i0);
         ResizeBatch T{};

@@ -530,6 +530,154 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_t(const WarpTile *__
                                                     g0, g0_stride, tabs);
 }
 
+// ---- round 4: the frames of a lane share EVERYTHING but the source base -------------------------------------------------------------------
+// warp_tile_direct shares the source coordinates between the frames of a lane; the ISA showed that each frame still rebuilt the tap offsets
+// (clamps, row * step, the 2-bit byte shifts), the floors, the "all taps inside" tests with their exec-mask branches, and the four bilinear
+// weights of every pixel -- about a third of the kernel's VALU cycles (profiles/r04_valu_probe.txt: clamps, conversions, v_mul_lo_u32 and
+// the three-operand forms issue at half rate on gfx950).  When the NF source images of a view have the same row step and the same address
+// modulo 4 -- the caller's frames of one camera practically always do; the host checks (stitch_impl) and launches k_warp_t otherwise -- the
+// aligned tap address of a pixel is ONE 32-bit offset for all frames, added to a per-frame SGPR base by the load itself
+// (global_load_dwordx3 v, v_off, s[base]).  So per pixel, once: floor, offset, shifts, weights, border flag; per pixel and frame: two reads,
+// four v_alignbyte, 12 conversions, 12 + 3 fmas, 6 packs.  104 VGPRs: the kernel is held at 4 waves per SIMD anyway (see stitch_impl).
+// The border test is one wave-level branch per frame (ballot over the lanes' four pixels) instead of one exec-masked region per pixel.
+template <bool CPW, int PROJ, int NF>
+__device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int nf, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
+                                                 const SrcTable &src, int src_rows, int src_cols, const MeshTable &mesh,
+                                                 const uint8_t *__restrict__ stage, long long stage_stride,
+                                                 uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
+{
+    const int v = T.view;
+    const ViewDesc &V = views[v];
+    const int x = T.x0 + 4 * tx, y = T.y0 + ty;
+    const bool active = x < V.pw && y < V.ph;
+    ms_gptr_u8 base[NF];
+    unsigned lo2 = 0u;
+#pragma unroll
+    for (int fi = 0; fi < NF; ++fi) {
+        const int f = f0 + (fi < nf ? fi : 0);      // (a missing frame of a short group is read from frame f0 again and dropped: no branch around the reads, see warp_tile_direct)
+        const uint8_t *p = CPW ? stage + (size_t)f * stage_stride + V.s1_off : src.p[f * n_views + v];
+        base[fi] = (ms_gptr_u8)((uintptr_t)p & ~(uintptr_t)3);
+        if (fi == 0) lo2 = (unsigned)(uintptr_t)p & 3u;
+    }
+    const unsigned st = CPW ? (unsigned)V.s1_pitch : src.step[f0 * n_views + v];
+    const int srows = CPW ? V.ah : src_rows, scols = CPW ? V.aw : src_cols;
+    const LevelDesc &L = V.lv[0];
+    const size_t plane = (size_t)L.h * L.pitch;
+    float xc[4], yc[4];
+    if (CPW) {
+        if (active) warp_coords4<true, PROJ>(V, mesh, v, x, y, xc, yc);
+    } else {
+        float2 ct[4], rt;
+        if (T.flags & 4) {            // interior tile: table addresses from the tile entry alone
+            float4 a, b;
+            const float2 *cp = tabs + T.ctab + 4 * tx;
+            __builtin_memcpy(&a, __builtin_assume_aligned(cp, 8), 16);
+            __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
+            ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
+            rt = tabs[T.rtab + ty];
+        } else {
+            warp_coltab4(V, min(x, V.pw - 4), ct);
+            rt = gload_f2(V.rowtab + reflect_fast(min(y, V.ph - 1) - V.top, V.ah));
+        }
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
+        }
+    }
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xc[k] = yc[k] = -1.f;
+    }
+    // once per pixel: the aligned offsets of its two tap rows, the byte shifts, the border flag
+    unsigned va[4], vb[4], sh1 = 0u, sh2 = 0u;
+    bool slow = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x1 = f2i_rd(xc[k]), y1 = f2i_rd(yc[k]);
+        slow = slow || !((unsigned)x1 < (unsigned)(scols - 2) && (unsigned)y1 < (unsigned)(srows - 1));
+        const unsigned a = lo2 + tap_offset(x1, y1, srows, scols, st), b = a + st;
+        va[k] = a & ~3u; vb[k] = b & ~3u;
+        sh1 |= (a & 3u) << (2 * k); sh2 |= (b & 3u) << (2 * k);
+    }
+    Px3 q1[2][4], q2[2][4];
+    auto issue = [&](int fi) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const ms_u32x3_a4 r1 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + va[k]);
+            const ms_u32x3_a4 r2 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + vb[k]);
+            q1[fi & 1][k] = Px3{r1.x, r1.y, r1.z};
+            q2[fi & 1][k] = Px3{r2.x, r2.y, r2.z};
+        }
+    };
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);      // frame 0's reads go out first
+    if (NF > 1) issue(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ... and while they are in flight: the weights (frame-invariant)
+    Taps t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = make_taps(xc[k], yc[k], srows, scols);
+    const bool any_slow = __builtin_amdgcn_ballot_w64(active && slow) != 0ull;
+    const float gain = V.gain;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int fi = 0; fi < NF; ++fi) {
+        const int b = fi & 1;
+        if (active && fi < nf) {
+            unsigned packed[3] = {0, 0, 0};
+            Px2 r1[4], r2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r1[k] = px3_to_px2(q1[b][k], sh1 >> (2 * k));
+                r2[k] = px3_to_px2(q2[b][k], sh2 >> (2 * k));
+            }
+            if (any_slow) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (!t[k].fast) fix_border_taps(r1[k], r2[k], t[k].x1, t[k].y1, srows, scols);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                float o[2][3];
+                blend_taps2(t[k], t[k + 1], r1[k], r2[k], r1[k + 1], r2[k + 1], o[0], o[1]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (CPW) {
+                        packed[c] = sat_u8_into(o[0][c], k, packed[c]);
+                        packed[c] = sat_u8_into(o[1][c], k + 1, packed[c]);
+                    } else {      // convertTo(gain) of the rounded remap result (timed.cpp:94)
+                        const f32x2 r = gain_pair(gain, (float)sat_u8(o[0][c]), (float)sat_u8(o[1][c]));
+                        packed[c] = sat_u8_into(r.x, k, packed[c]);
+                        packed[c] = sat_u8_into(r.y, k + 1, packed[c]);
+                    }
+                }
+            }
+            uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)y * L.pitch + x;
+            *reinterpret_cast<unsigned *>(d) = packed[0];
+            *reinterpret_cast<unsigned *>(d + plane) = packed[1];
+            *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fi + 2 < NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }      // (three frames per lane: the third frame's reads reuse frame 0's registers)
+    }
+}
+
+template <bool CPW, int PROJ, int NF>      // NF = warp_nf(CPW) frames per lane; 1 for one-frame calls (the reference's call shape: no reads for a frame that is not there)
+__global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_s(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                         SrcTable src, int src_rows, int src_cols, MeshTable mesh,
+                                                         const uint8_t *__restrict__ stage, long long stage_stride,
+                                                         uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs, int n_frames)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
+    if (CPW || (T.flags & 8))       // (a tile that samples the last row of a caller's image keeps the unaligned reads: see Px3)
+        warp_tile_shared<CPW, PROJ, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                        g0, g0_stride, tabs);
+    else
+        warp_tile_direct<CPW, PROJ, false, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                               g0, g0_stride, tabs);
+}
+
 // ---- the same tiles with the source staged in LDS by asynchronous LDS-DMA: persistent, self-pipelined waves -------------------
 // Measured on the direct kernel (profiles/r02_warp_probes.txt): the gathers cost per lane-dword the texture-address path handles
 // (an unaligned 8-byte tap read touches 3 dwords, 48 per lane and tile), and they do not overlap the kernel's other half, its VALU
@@ -832,6 +980,114 @@ __global__ void __launch_bounds__(WARP_BX * S1_BY) k_stage1_t(const WarpTile *__
     if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;
     const int f0 = (int)blockIdx.z * S1_NF, nf = min(S1_NF, n_frames - f0);
     if (AL && (T.flags & 8)) stage1_tile<PROJ, true, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+    else stage1_tile<PROJ, false, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+}
+
+// the shared-offset form of stage1_tile (see warp_tile_shared): aligned reads, offsets / shifts / weights / border flag once per pixel, per frame only the SGPR base
+template <int PROJ, int S1_NF>
+__device__ __forceinline__ void stage1_tile_shared(const WarpTile &T, int f0, int nf, const ViewDesc *__restrict__ views, int n_views,
+                                                   const SrcTable &src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
+{
+    const int v = T.view;
+    const ViewDesc &V = views[v];
+    const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
+    if (x >= V.aw || y >= V.ah) return;
+    ms_gptr_u8 base[S1_NF];
+#pragma unroll
+    for (int fi = 0; fi < S1_NF; ++fi) base[fi] = (ms_gptr_u8)((uintptr_t)src.p[(f0 + (fi < nf ? fi : 0)) * n_views + v] & ~(uintptr_t)3);
+    const unsigned lo2 = (unsigned)(uintptr_t)src.p[f0 * n_views + v] & 3u, st = src.step[f0 * n_views + v];
+    float2 ct[4];
+    if (x + 3 < V.aw) {
+        float4 a, b;
+        a = gload_f4(V.coltab + x);
+        b = gload_f4(V.coltab + x + 2);
+        ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ct[k] = gload_f2(V.coltab + min(x + k, V.aw - 1));
+    }
+    const float2 rt = gload_f2(V.rowtab + y);
+    float xc[4], yc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
+    unsigned va[4], vb[4], sh1 = 0u, sh2 = 0u;
+    bool slow = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x1 = f2i_rd(xc[k]), y1 = f2i_rd(yc[k]);
+        slow = slow || !((unsigned)x1 < (unsigned)(scols - 2) && (unsigned)y1 < (unsigned)(srows - 1));
+        const unsigned a = lo2 + tap_offset(x1, y1, srows, scols, st), b = a + st;
+        va[k] = a & ~3u; vb[k] = b & ~3u;
+        sh1 |= (a & 3u) << (2 * k); sh2 |= (b & 3u) << (2 * k);
+    }
+    Px3 q1[2][4], q2[2][4];
+    auto issue = [&](int fi) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const ms_u32x3_a4 r1 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + va[k]);
+            const ms_u32x3_a4 r2 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + vb[k]);
+            q1[fi & 1][k] = Px3{r1.x, r1.y, r1.z};
+            q2[fi & 1][k] = Px3{r2.x, r2.y, r2.z};
+        }
+    };
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (S1_NF > 1) issue(1);
+    __builtin_amdgcn_sched_barrier(0);
+    Taps t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = make_taps(xc[k], yc[k], srows, scols);
+    const bool any_slow = __builtin_amdgcn_ballot_w64(slow) != 0ull;
+    const float gain = V.gain;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int fi = 0; fi < S1_NF; ++fi) {
+        const int b = fi & 1;
+        if (fi < nf) {
+            unsigned w[3] = {0u, 0u, 0u};
+            Px2 r1[4], r2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r1[k] = px3_to_px2(q1[b][k], sh1 >> (2 * k));
+                r2[k] = px3_to_px2(q2[b][k], sh2 >> (2 * k));
+            }
+            if (any_slow) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (!t[k].fast) fix_border_taps(r1[k], r2[k], t[k].x1, t[k].y1, srows, scols);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                float o[2][3];
+                blend_taps2(t[k], t[k + 1], r1[k], r2[k], r1[k + 1], r2[k + 1], o[0], o[1]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x2 r = gain_pair(gain, (float)sat_u8(o[0][c]), (float)sat_u8(o[1][c]));
+                    const int i0 = 3 * k + c, i1 = 3 * (k + 1) + c;          // bytes of the 12 interleaved output bytes
+                    w[i0 >> 2] = sat_u8_into(r.x, i0 & 3, w[i0 >> 2]);
+                    w[i1 >> 2] = sat_u8_into(r.y, i1 & 3, w[i1 >> 2]);
+                }
+            }
+            uint8_t *d = stage + (size_t)(f0 + fi) * stage_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
+            if (x + 3 < V.aw) __builtin_memcpy(__builtin_assume_aligned(d, 4), w, 12);
+            else {
+                for (int k = 0; k < 4 && x + k < V.aw; ++k)
+                    for (int c = 0; c < 3; ++c) { const int i = 3 * k + c; d[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3))); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fi + 2 < S1_NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }
+    }
+}
+
+template <int PROJ, int S1_NF>
+__global__ void __launch_bounds__(WARP_BX * S1_BY) k_stage1_s(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                             SrcTable src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp, int n_frames)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;
+    const int f0 = (int)blockIdx.z * S1_NF, nf = min(S1_NF, n_frames - f0);
+    if (T.flags & 8) stage1_tile_shared<PROJ, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
     else stage1_tile<PROJ, false, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
 }
 

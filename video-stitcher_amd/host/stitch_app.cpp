@@ -430,13 +430,15 @@ int main(int argc, char **argv)
                         HIPCHECK(hipMemcpy2DAsync(full_imgs[i].data, full_imgs[i].step, imgs.v[i].p, (size_t)o.w * 3, (size_t)o.w * 3, o.h,
                                                   hipMemcpyHostToDevice, upload_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
                 }
-                if (o.nv12) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47)
-                    std::vector<ms_image> a(o.views), d(o.views);
-                    for (int i = 0; i < o.views; ++i) { a[i] = msshim::wrap(nv12_imgs[i]); d[i] = msshim::wrap(full_imgs[i]); }
-                    msshim::check(ms_nv12_to_bgr_batch(a.data(), d.data(), o.views, (ms_stream)upload_stream));
-                }
                 HIPCHECK(hipEventRecord(up_done[ib], upload_stream));
                 HIPCHECK(hipStreamWaitEvent(stitch_stream, up_done[ib], 0));
+                if (o.nv12) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47).
+                                          // On the STITCH stream (round 4): the upload stream then carries nothing but the copies, so the PCIe link -- the limit of
+                                          // this path -- never waits for a kernel; the conversion (one latency-bound launch) rides in front of the frame's stitch
+                    std::vector<ms_image> a(o.views), d(o.views);
+                    for (int i = 0; i < o.views; ++i) { a[i] = msshim::wrap(nv12_imgs[i]); d[i] = msshim::wrap(full_imgs[i]); }
+                    msshim::check(ms_nv12_to_bgr_batch(a.data(), d.data(), o.views, (ms_stream)stitch_stream));
+                }
             }
             if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)
                 msshim::cuda::resize(full_imgs, small_imgs, cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);      // all views, one launch

@@ -99,6 +99,11 @@ struct Shared {                                // what the rank threads share: t
     ms_dist_info info{};
     int bands = 0, i_rows = 0, recalibrations = 0;
     std::vector<int> views_read;
+    // where each rank's time went (the first real multi-GPU run should explain itself): GPU time of the stitch kernels (events on the
+    // stitch stream), time of the gather on the communication stream (events; on the host transport this is host-staged copies), host time blocked in the
+    // mesh exchange / the column-shard exchange / the sink's consume loop
+    struct RankTimes { double stitch_gpu_ms = 0, gather_stream_ms = 0, mesh_exchange_host_ms = 0, shard_exchange_host_ms = 0, consume_host_ms = 0, wall_ms = 0; };
+    std::vector<RankTimes> times;
 };
 
 void rank_main(const Options &o, int rank, Shared &sh)
@@ -233,6 +238,11 @@ void rank_main(const Options &o, int rank, Shared &sh)
     bool have_pending = false;
     int applied_rounds = 0;
 
+    Shared::RankTimes rt;
+    std::vector<hipEvent_t> ev_s0, ev_s1, ev_g0, ev_g1;
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    auto new_event = [&](std::vector<hipEvent_t> &v, hipStream_t s) { hipEvent_t e; HIPC(hipEventCreate(&e)); HIPC(hipEventRecord(e, s)); v.push_back(e); };
     std::vector<unsigned char> host_frame(rank == 0 && o.checksum ? frame_bytes : 0);
     std::vector<unsigned long long> sums;
     HIPC(hipStreamSynchronize(st));
@@ -240,6 +250,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
     const auto t0 = std::chrono::steady_clock::now();
     for (long long k = 0; k < n_batches; ++k) {
         const long long first = k * batch_frames;                  // global index of this batch's first frame
+        const auto t_mesh = tick();
         if (o.cpw && o.recalib_every > 0) {
             // 1. a pending update whose swap frame has come is applied by every rank at the same batch boundary
             if (have_pending) {
@@ -260,6 +271,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
             MSC(ms_dist_mesh_exchange(dist, 0, up, &pending, per_mesh * N, &have, st));
             if (have) { if (have_pending) throw Fail("a second mesh update arrived before the first was applied"); have_pending = true; }
         }
+        rt.mesh_exchange_host_ms += ms_since(t_mesh);
         // 3. this group's F frames of the batch: t = first + j * groups + group
         const int b = (int)(k & 1);
         unsigned char *mine = mine2[b];
@@ -274,7 +286,10 @@ void rank_main(const Options &o, int rank, Shared &sh)
             }
             outs[j] = ms_image{mine + j * frame_bytes, (size_t)o.out_w, o.out_w, i_rows * 3 / 2, MS_8UC1};
         }
+        new_event(ev_s0, st);
         MSC(ms_stitch_i420(ctx, F, views.data(), outs.data(), st));
+        new_event(ev_s1, st);
+        const auto t_shard = tick();
         // 4. column shards: windows to the group's first rank
         if (S > 1) {
             if (rank != leader) {
@@ -287,10 +302,12 @@ void rank_main(const Options &o, int rank, Shared &sh)
                 for (int s2 = 1; s2 < S; ++s2) move_window(mine, from_shard[s2], bound(s2), bound(s2 + 1), false);
             }
         }
+        rt.shard_exchange_host_ms += ms_since(t_shard);
         // 5. frame-parallel gather: the leaders' slabs to the sink (rank 0), on the communication stream behind this batch's kernels
         HIPC(hipEventRecord(stitched[b], st));
         if (groups > 1 && (rank == 0 || rank == leader)) {
             HIPC(hipStreamWaitEvent(cs, stitched[b], 0));
+            new_event(ev_g0, cs);
             if (rank == 0) {
                 MSC(ms_dist_group_begin(dist));
                 for (int g = 1; g < groups; ++g) MSC(ms_dist_recv(dist, from_group[g], slab_bytes, g * S, MS_DIST_MEM_DEVICE, cs));
@@ -298,8 +315,10 @@ void rank_main(const Options &o, int rank, Shared &sh)
             } else
                 MSC(ms_dist_send(dist, mine, slab_bytes, 0, MS_DIST_MEM_DEVICE, cs));
             HIPC(hipEventRecord(sent[b], cs));
+            new_event(ev_g1, cs);
             sent_used[b] = true;
         }
+        const auto t_cons = tick();
         // 6. consume() on the sink: the frames of the batch in display order
         if (rank == 0 && o.checksum) {
             HIPC(hipStreamSynchronize(st));
@@ -313,6 +332,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
                     sums.push_back(fnv(host_frame.data(), frame_bytes));
                 }
         }
+        rt.consume_host_ms += ms_since(t_cons);
     }
     HIPC(hipStreamSynchronize(st));
     HIPC(hipStreamSynchronize(cs));
@@ -320,11 +340,16 @@ void rank_main(const Options &o, int rank, Shared &sh)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     running.store(false);
     if (recalibrater.joinable()) recalibrater.join();
+    rt.wall_ms = secs * 1e3;
+    for (size_t i = 0; i < ev_s0.size(); ++i) { float t = 0; HIPC(hipEventElapsedTime(&t, ev_s0[i], ev_s1[i])); rt.stitch_gpu_ms += t; }
+    for (size_t i = 0; i < ev_g0.size(); ++i) { float t = 0; HIPC(hipEventElapsedTime(&t, ev_g0[i], ev_g1[i])); rt.gather_stream_ms += t; }
+    for (auto *v : {&ev_s0, &ev_s1, &ev_g0, &ev_g1}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     if (rank == 0) {
         std::lock_guard<std::mutex> lk(sh.mu);
         sh.frame_sums = sums; sh.seconds = secs; sh.info = info; sh.bands = pg.num_bands; sh.i_rows = i_rows; sh.recalibrations = applied_rounds;
     }
-    { std::lock_guard<std::mutex> lk(sh.mu); if ((int)sh.views_read.size() < o.gpus) sh.views_read.resize(o.gpus); sh.views_read[rank] = __builtin_popcount(need); }
+    { std::lock_guard<std::mutex> lk(sh.mu); if ((int)sh.views_read.size() < o.gpus) sh.views_read.resize(o.gpus); sh.views_read[rank] = __builtin_popcount(need);
+      if ((int)sh.times.size() < o.gpus) sh.times.resize(o.gpus); sh.times[rank] = rt; }
     ms_dist_destroy(dist);
     ms_destroy(ctx);
     for (unsigned char *p : src) if (p) (void)hipFree(p);
@@ -392,14 +417,23 @@ int main(int argc, char **argv)
         reads += (r ? ", " : "") + std::to_string(sh.views_read[r]);
     }
     devs += "]"; pcis += "]"; reads += "]";
+    std::string times = "[";
+    for (int r = 0; r < o.gpus; ++r) {
+        char b[320];
+        const Shared::RankTimes &t = sh.times[r];
+        snprintf(b, sizeof(b), "%s{\"rank\": %d, \"wall_ms\": %.2f, \"stitch_gpu_ms\": %.2f, \"gather_stream_ms\": %.2f, \"mesh_exchange_host_ms\": %.2f, \"shard_exchange_host_ms\": %.2f, \"consume_host_ms\": %.2f}",
+                 r ? ", " : "", r, t.wall_ms, t.stitch_gpu_ms, t.gather_stream_ms, t.mesh_exchange_host_ms, t.shard_exchange_host_ms, t.consume_host_ms);
+        times += b;
+    }
+    times += "]";
     const long long frames_done = o.checksum ? (long long)sh.frame_sums.size() : o.frames;
     printf("{\"app\": \"stitch_dist\", \"gpus\": %d, \"col_shards\": %d, \"groups\": %d, \"share_gpu\": %s, \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, "
            "\"cpw\": %s, \"recalib_every\": %d, \"recalibrations_applied\": %d, \"batch\": %d, \"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
            "\"dist\": {\"transport\": \"%s\", \"nranks\": %d, \"comm_nranks\": %d, \"rccl_version\": %d, \"devices\": %s, \"pci_bus_ids\": %s}, "
-           "\"views_read_per_rank\": %s, \"i420_rows\": %d, \"first_frame_checksum\": \"%016llx\", \"last_frame_checksum\": \"%016llx\", \"checksum_all\": \"%016llx\"}\n",
+           "\"views_read_per_rank\": %s, \"per_rank\": %s, \"i420_rows\": %d, \"first_frame_checksum\": \"%016llx\", \"last_frame_checksum\": \"%016llx\", \"checksum_all\": \"%016llx\"}\n",
            o.gpus, o.col_shards, o.gpus / o.col_shards, o.share_gpu ? "true" : "false", o.views, o.w, o.h, o.out_w, o.out_h, sh.bands,
            o.cpw ? "true" : "false", o.recalib_every, sh.recalibrations, o.batch, frames_done, sh.seconds, frames_done / sh.seconds,
            sh.info.transport == MS_DIST_RCCL ? "rccl" : "host", sh.info.nranks, sh.info.comm_nranks, sh.info.rccl_version, devs.c_str(), pcis.c_str(),
-           reads.c_str(), sh.i_rows, sh.frame_sums.empty() ? 0ull : sh.frame_sums.front(), sh.frame_sums.empty() ? 0ull : sh.frame_sums.back(), all);
+           reads.c_str(), times.c_str(), sh.i_rows, sh.frame_sums.empty() ? 0ull : sh.frame_sums.front(), sh.frame_sums.empty() ? 0ull : sh.frame_sums.back(), all);
     return 0;
 }

@@ -41,7 +41,7 @@ class Config(C.Structure):
                 ("out_width", C.c_int), ("out_height", C.c_int), ("max_frames", C.c_int),
                 ("view_shards", C.c_int), ("view_shard_index", C.c_int), ("cpu_flavour_remap", C.c_int),
                 ("debug_simple_kernels", C.c_int), ("warp_lds_stage", C.c_int), ("raster_tile_order", C.c_int),
-                ("col_shards", C.c_int), ("col_shard_index", C.c_int), ("update_mask_margin", C.c_int), ("reserved", C.c_int * 1)]
+                ("col_shards", C.c_int), ("col_shard_index", C.c_int), ("update_mask_margin", C.c_int), ("self_check", C.c_int)]
 
 
 class SeamParams(C.Structure):
@@ -93,6 +93,7 @@ EXPORTS = [
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
+    "ms_save_tables", "ms_load_tables",
 ]
 
 _lib = None
@@ -577,12 +578,33 @@ class Compositor:
         cfg.warp_lds_stage = 0 if lds_stage is None else (1 if lds_stage else 2)   # True: warp source tiles staged in LDS by LDS-DMA (opt-in, measured slower); False forces the direct gathers even under MS_WARP_ASYNC=1
         cfg.view_shards = shards; cfg.view_shard_index = shard_index   # view sharding
         cfg.col_shards = col_shards; cfg.col_shard_index = col_shard_index   # pano-column sharding
+        cfg.self_check = 1 if os.environ.get("MS_CHECK_DIVIDE", "0") not in ("", "0") else 0   # (this binding is test / bench infrastructure: the LIBRARY reads no environment; tests/conftest.py sets the variable)
         cfg.update_mask_margin = update_mask_margin   # > 0: ms_update_mask is enqueue-only (double-buffered tables, work lists planned with this margin)
         cfg.cpu_flavour_remap = 1 if cv_remap else 0   # cv::remap's CPU arithmetic for the projection warp (needs simple_kernels, no CPW)
         self._ctx = C.c_void_p()
         _chk(load().ms_create(C.byref(cfg), C.byref(self._ctx)))
         self.cfg = cfg
         self.n = num_views
+
+    def save_tables(self):
+        """ms_save_tables: the calibration of this (ready) context as bytes"""
+        n = C.c_size_t(0)
+        _chk(load().ms_save_tables(self._ctx, None, C.c_size_t(0), C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        _chk(load().ms_save_tables(self._ctx, buf, C.c_size_t(n.value), C.byref(n)))
+        return bytes(buf)
+
+    @classmethod
+    def from_tables(cls, blob):
+        """ms_load_tables: a ready context rebuilt from save_tables() bytes (no ms_init_blender call needed)"""
+        self = cls.__new__(cls)
+        self._ctx = C.c_void_p()
+        b = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _chk(load().ms_load_tables(b, C.c_size_t(len(blob)), C.byref(self._ctx), _stream()))
+        self.cfg = Config.from_buffer_copy(blob[48:48 + C.sizeof(Config)])      # TablesHeader: 48 bytes in front of the ms_config
+        import struct
+        self.n = struct.unpack_from("<i", blob, 16)[0]      # TablesHeader::n_views
+        return self
 
     def close(self):
         if self._ctx:
