@@ -824,6 +824,9 @@ def main():
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255); b = torch.empty_like(a)
         for _ in range(3):
             ms.calib_copy(a, b)
+        for shape in (0, 1, 2):      # ... and the per-frame kernels' own access shapes over the same GiB (every line touched once: 1 GiB of HBM traffic each)
+            for _ in range(2):
+                ms.calib_shape(a, shape)
         torch.cuda.synchronize()
         del a, b
 

@@ -507,6 +507,10 @@ MS_API int ms_stitch_timed(ms_ctx *ctx, int n_frames, const ms_image *views, ms_
 MS_API int ms_calib_copy(const void *src, void *dst, size_t bytes, ms_stream stream);
 /* ... and its read-only companion (the read side alone sustains more than a copy: the per-frame kernels read 3-5x what they write). */
 MS_API int ms_calib_read(const void *src, size_t bytes, ms_stream stream);
+/* Counter calibration on the access shapes of the per-frame kernels: every 128-byte line of `buf` is touched exactly once, so a launch moves `bytes` of HBM traffic
+ * whatever the shape -- 0: one dword-aligned 12-byte read per lane at a 24-byte stride (k_warp_t's tap read), 1: one 8-byte read per lane (the band kernels' row
+ * windows), 2: dword stores in 32-byte runs, four passes per line (k_warp_t's plane stores).  tools/profile_traffic.sh records what FETCH_SIZE / WRITE_SIZE report. */
+MS_API int ms_calib_shape(void *buf, size_t bytes, int shape, ms_stream stream);
 
 /* Self-test of the shared-reciprocal division used by the band kernels (normalizeUsingWeightKernel32F,
  * multiband_blend.cu:85-100 divides three channels by the same w + 1e-5): for each of the n HOST denominators,

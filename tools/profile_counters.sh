@@ -37,7 +37,7 @@ for f in sorted(glob.glob(out + "/p*.txt")):
                 rows.setdefault(m.group(1).strip(), {})[m.group(2)] = (float(m.group(3)), float(m.group(5)))
 with open("gpurun_out/counters_%s.txt" % tag, "w") as fo:
     for k, d in rows.items():
-        if not any(t in k for t in ("k_warp_t", "k_warp_a", "k_calib", "k_blend", "k_down", "k_stage1", "k_remap", "k_single", "k_resize_linear3")):
+        if not any(t in k for t in ("k_warp_t", "k_warp_s", "k_warp_a", "k_calib", "k_blend", "k_down", "k_stage1", "k_remap", "k_single", "k_resize_linear3")):
             continue
         fo.write(k + "\n")
         for c, (v, dur) in sorted(d.items()):

@@ -40,7 +40,7 @@ def main(tag):
     clk = 2.33e9
     rows = []
     for k, v in traffic["kernels"].items():
-        if k in ("k_warp", "k_blend_l0", "k_down_l0", "k_remap_gain") or v["launches"] < 20 or "calib" in k or not k.startswith(("k_warp_t", "k_blend", "k_down", "k_stage1", "k_remap", "k_single", "k_resize_linear3")):      # (aliases, calibration-time kernels)
+        if k in ("k_warp", "k_blend_l0", "k_down_l0", "k_remap_gain") or v["launches"] < 20 or "calib" in k or not k.startswith(("k_warp_t", "k_warp_s", "k_blend", "k_down", "k_stage1", "k_remap", "k_single", "k_resize_linear3")):      # (aliases, calibration-time kernels)
             continue
         c = next((d for n, d in ctr.items() if short(n) == k), {})
         waves = c.get("SQ_WAVES", 0)
@@ -51,7 +51,7 @@ def main(tag):
         rows.append((us * v["launches"], k, v["launches"], us, v["hbm_bytes_per_launch"], waves, valu / waves if waves else None, busy, occ))
     rows.sort(reverse=True)
     # launches per ms_stitch call: 1 for the per-frame kernels of the compositor; the per-frame resize of the shipped configuration needs ceil(views x F / 64) launches per call
-    calls = max([r[2] for r in rows if r[1].startswith(("k_warp_t", "k_stage1_t"))] or [1])
+    calls = max([r[2] for r in rows if r[1].startswith(("k_warp_t", "k_warp_s", "k_stage1_t", "k_stage1_s"))] or [1])
     lines = ["# Per-kernel report (%s): %s, %d frames per launch, one context / one stream" % (tag, traffic.get("config", "cfg2"), F), "",
              "Sources: `%s_kernel_trace.txt`/`%s_traffic.json` (rocprofv3 kernel trace; FETCH_SIZE x2.0 + WRITE_SIZE x1.0, calibrated on a 1 GiB copy),"
              " `%s_counters.txt` (SQ counters), `%s_bench.json` (bench.py line).  VALU busy = VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.33 GHz)." % (tag, tag, tag, tag), "",

@@ -55,6 +55,18 @@ def main(out, tag, cfg, frames):
                            "fetch_factor": f_r, "write_factor": f_w,
                            "FETCH_SIZE_KB_reported": cal_r[0][0] if cal_r else None, "WRITE_SIZE_KB_reported": cal_w[0][0] if cal_w else None,
                            "read_factor": f_r, "write_factor": f_w}, "kernels": {}}
+    # the same GiB through the per-frame kernels' access shapes (k_calib_shape<0 / 1 / 2>: every 128-byte line touched once, so 1 GiB of HBM traffic each)
+    labels = ["12 B / lane reads at a 24-byte stride (k_warp_t's tap read)", "8 B / lane contiguous reads (band kernels' row windows)",
+              "dword stores in 32-byte runs, four passes per 128-byte line (k_warp_t's plane stores)"]
+    cal = []
+    for i, lab in enumerate(labels):
+        fr = [v for k, v in fetch.items() if "k_calib_shape<%d>" % i in k]
+        wr = [v for k, v in write.items() if "k_calib_shape<%d>" % i in k]
+        fkb, wkb = (fr[0][0] if fr else None), (wr[0][0] if wr else None)
+        cal.append({"shape": lab, "true_bytes": int(GiB), "FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb,
+                    "fetch_factor_this_shape": (GiB / (fkb * 1024.0) if (fkb and i < 2) else None),
+                    "write_factor_this_shape": (GiB / (wkb * 1024.0) if (wkb and i == 2) else None)})
+    res["calibration"]["access_shapes"] = cal
     names = {"k_warp": "k_warp_t<false>", "k_remap_gain": "k_remap_gain"}
     order = sorted(set(fetch) | set(write))
     for k in order:
@@ -66,23 +78,23 @@ def main(out, tag, cfg, frames):
     # bench.py names its per-level launches k_down_l<l> / k_blend_l<l>; map the dominant ones by kernel template
     alias = {}
     for k, v in res["kernels"].items():
-        if k.startswith("k_warp_t<false") or k.startswith("k_warp<false>"):
+        if k.startswith(("k_warp_t<false", "k_warp_s<false", "k_warp<false>")):
             alias["k_warp"] = v
         if k.startswith("k_blend8<true, 0>") or k.startswith("k_blend8<true>"):
             alias["k_blend_l0"] = v
-        if k.startswith("k_stage1_t"):
+        if k.startswith(("k_stage1_t", "k_stage1_s")):
             alias["k_remap_gain"] = v          # bench.py's name of the first CPW remap (timed.cpp:90-94)
         if k.startswith("k_resize_linear3"):
             alias["k_resize_batch"] = v        # bench.py's name of the per-frame cuda::resize launch (shipped configuration)
-        if k.startswith("k_warp_t<true"):
+        if k.startswith(("k_warp_t<true", "k_warp_s<true")):
             alias["k_warp"] = v                # CPW contexts: the level-0 kernel is the mesh remap of the stage image
         if k.startswith("k_down_t<unsigned char>") or k.startswith("k_down_t<true>"):
             alias["k_down_l0"] = v
     res["kernels"].update(alias)
     # HBM bytes of one ms_stitch call (all per-frame kernels): what bench.py's frame_roofline.frac_traffic divides by the GPU time
-    per_frame = ("k_resize_linear3", "k_warp_t", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
+    per_frame = ("k_resize_linear3", "k_warp_t", "k_warp_s", "k_stage1_s", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
                  "k_blend<", "k_blend_top", "k_single_band")
-    steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t", "k_warp_a", "k_warp<"))] or [1])
+    steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t", "k_warp_s", "k_warp_a", "k_warp<"))] or [1])
     res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()
                                         if (k.startswith(per_frame) or k == "k_down") and k not in alias))
     res["calls"] = steps

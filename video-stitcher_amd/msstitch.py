@@ -93,7 +93,7 @@ EXPORTS = [
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
-    "ms_save_tables", "ms_load_tables",
+    "ms_save_tables", "ms_load_tables", "ms_calib_shape",
 ]
 
 _lib = None
@@ -179,6 +179,11 @@ def device_count():
 def calib_copy(src, dst):
     n = src.numel() * src.element_size()
     _chk(load().ms_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), _stream()))
+
+
+def calib_shape(buf, shape):
+    """ms_calib_shape: every 128-byte line of `buf` (uint8 tensor, 128-byte aligned) touched once with access shape 0 / 1 / 2 (PMC calibration)"""
+    _chk(load().ms_calib_shape(C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), int(shape), _stream()))
 
 
 def calib_read(src):
