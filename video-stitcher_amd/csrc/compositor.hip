@@ -1725,13 +1725,25 @@ bool any_in(const Bits &s, int w, int h, int x0, int y0, int tw, int th)
 // Workgroup b runs on XCD b % 8 (observed dispatch order; performance only).  Reorder a tile list so that each
 // XCD receives a CONTIGUOUS run of spatially adjacent tiles: neighbouring tiles share source rows / halo rows, and
 // only then do those re-reads hit in that XCD's private 4 MiB L2 instead of going back to HBM.
+// chunk > 0 (round 4): instead of eight long runs -- eight XCDs at eight far-apart places of the frame -- chunks of `chunk` raster-consecutive tiles are dealt round-robin to
+// the XCDs, so that at any time the whole chip works inside one compact window of a few tile rows (horizontal neighbours still share an XCD; the vertical halos
+// now meet in the Infinity Cache instead of an L2).  A few per cent either way depending on the list: the callers say which lists use it.
 template <typename T>
-static void xcd_order(std::vector<T> &tiles)
+static void xcd_order(std::vector<T> &tiles, int chunk = 0)
 {
     const size_t n = tiles.size(), per = (n + 7) / 8;
     if (n < 16) return;
     std::vector<T> out;
     out.reserve(n);
+    if (chunk > 0) {
+        std::vector<std::vector<T>> q(8);
+        for (size_t i = 0; i < n; ++i) q[(i / (size_t)chunk) % 8].push_back(tiles[i]);
+        for (size_t i = 0; out.size() < n; ++i)
+            for (int k = 0; k < 8; ++k) if (i < q[k].size()) out.push_back(q[k][i]);
+        // (queues of unequal length: the tail of the list loses the b mod 8 alignment -- a few tiles)
+        tiles.swap(out);
+        return;
+    }
     std::vector<char> used(n, 0);
     for (size_t b = 0; out.size() < n; ++b) {
         const size_t src = (b % 8) * per + b / 8;
@@ -1851,7 +1863,9 @@ static int build_plan(ms_ctx *c)
         c->needed_mask = 0;
         for (const WarpTile &t : tiles) c->needed_mask |= 1u << t.view;
         if (!windowed || !c->warp_tiled) c->needed_mask = 0xffffffffu;      // (the full-grid fallback kernels touch every view)
-        if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
+        // (chunks of 8 tiles dealt round-robin: measured, profiles/r04_warp_experiments.txt -- config 2 k_warp 402 -> 388 us per 32 frames, config 5 -2..-5 %; the CPW mesh remap
+        //  of the shipped rig +1.5 %, so CPW contexts keep the eight long runs)
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles, dev_knob("MS_XCD_CHUNK_WARP", c->cfg.enable_cpw ? 0 : 8));
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
         c->warp_lds_tiles = 0;
@@ -1917,7 +1931,7 @@ static int build_plan(ms_ctx *c)
         {   // reachable tiles first, each part in XCD order on its own: when the others exit early every XCD still gets an equal share
             std::vector<WarpTile> a, b;
             for (const WarpTile &t : tiles) ((t.flags & 2) ? a : b).push_back(t);
-            if (c->cfg.raster_tile_order == 0) { xcd_order(a); xcd_order(b); }
+            if (c->cfg.raster_tile_order == 0) { xcd_order(a, dev_knob("MS_XCD_CHUNK_S1", 8)); xcd_order(b, dev_knob("MS_XCD_CHUNK_S1", 8)); }
             tiles = a;
             tiles.insert(tiles.end(), b.begin(), b.end());
         }
@@ -1941,7 +1955,7 @@ static int build_plan(ms_ctx *c)
                     for (int x0 = 0; x0 < Lo.w; x0 += DOWN_TW)
                         if (any_in(Nd[v][l + 1], Lo.w, Lo.h, x0, y0, DOWN_TW, DOWN_TH)) tiles.push_back(DownTile{(short)v, 0, (short)x0, (short)y0});
             }
-        if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles, dev_knob(l == 0 ? "MS_XCD_CHUNK_DOWN0" : "MS_XCD_CHUNK_DOWN", 0));
         c->n_down_tiles[l] = (int)tiles.size();
         if (int e = c->down_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(DownTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->down_tiles[l].p, tiles.data(), tiles.size() * sizeof(DownTile), hipMemcpyHostToDevice));
@@ -1960,7 +1974,7 @@ static int build_plan(ms_ctx *c)
                     }
                     tiles.push_back(BlendTile{(short)x0, (short)y0, m});
                 }
-        if (c->cfg.raster_tile_order == 0) xcd_order(tiles);
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles, dev_knob(l == 0 ? "MS_XCD_CHUNK_BLEND0" : "MS_XCD_CHUNK_BLEND", (l == 0 && c->pano.qw[0] <= 4096) ? 8 : 0));      // (level 0 of config 2 / 3 / shipped: -2 %; config 5's 7680-wide panorama: +4 % with chunks, kept on long runs)
         c->n_blend_tiles[l] = (int)tiles.size();
         if (int e = c->blend_tiles[l].alloc(std::max<size_t>(1, tiles.size()) * sizeof(BlendTile))) return e;
         if (!tiles.empty()) MS_HIP(hipMemcpy(c->blend_tiles[l].p, tiles.data(), tiles.size() * sizeof(BlendTile), hipMemcpyHostToDevice));
