@@ -908,6 +908,9 @@ def main():
             # the same with the cameras' NV12 uploaded (half the bytes) and cvtColor(YUV2BGR_NV12) on the device -- a per-camera CPU step in the reference (networking.cpp:45-47)
             pr = subprocess.run(cmd + ["--nv12"], capture_output=True, text=True, timeout=180)
             pcie["nv12_ingest_value"] = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])["frames_per_s"]
+            if not cpw and not shipped:      # ... and with no conversion pass at all: the warp samples the NV12 planes (ms_stitch_nv12; contexts without CPW / per-frame resize)
+                pr = subprocess.run(cmd + ["--nv12-direct"], capture_output=True, text=True, timeout=180)
+                pcie["nv12_direct_value"] = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])["frames_per_s"]
         except Exception as e:      # the number is optional; never fail the bench line on it
             pcie = {"error": str(e)[:200]}
 

@@ -745,3 +745,57 @@ def test_second_stream_is_ordered_behind_the_first(ms, cuda):
     torch.cuda.synchronize()
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     comp.close()
+
+
+@pytest.mark.parametrize("rig,proj,mask_mode,nf", [("mini6", None, 1, 3), ("mini6", "cyl", 0, 2), ("cfg2", None, 1, 2), ("mini4", "cyl", 0, 1)])
+def test_nv12_direct_equals_convert_then_stitch(ms, cuda, rig, proj, mask_mode, nf):
+    """ms_stitch_nv12 (APP/networking.cpp:45-47 + timed.cpp:56-152): the warp samples the cameras' NV12 planes and converts every tap itself --
+    bit-identical to ms_nv12_to_bgr_batch followed by ms_stitch, for noise frames (every clamp of the conversion is exercised), batches of 1 / 2 / 3 frames,
+    spherical and cylindrical rigs, and with mask mode 0 (whole warped views: samples on and beyond the image border, BORDER_CONSTANT 0)."""
+    pj = {None: None, "cyl": ms.PROJ_CYLINDRICAL}[proj]
+    comp, cfg, _ = make_rig(ms, rig, max_frames=nf, mask_mode=mask_mode, projection=pj)
+    rng = np.random.default_rng(77)
+    nv = [[to_dev(rng.integers(0, 256, (cfg["h"] * 3 // 2, cfg["w"]), dtype=np.uint8)) for _ in range(cfg["n"])] for _ in range(nf)]
+    # one structured frame too: the synthetic camera pattern
+    nv[0] = [to_dev(synth.nv12_frame(cfg["w"], cfg["h"], i)) for i in range(cfg["n"])]
+    bgr = [[ms.nv12_to_bgr(t) for t in fr] for fr in nv]
+    pg = comp.pano_geom()
+
+    def outs():
+        return ([torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device="cuda") for _ in range(nf)],
+                [torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device="cuda") for _ in range(nf)])
+    a8, a16 = outs()
+    comp.stitch(bgr, out8u=a8, out16s=a16)
+    b8, b16 = outs()
+    comp.stitch_nv12(nv, out8u=b8, out16s=b16)
+    torch.cuda.synchronize()
+    for f in range(nf):
+        assert torch.equal(a16[f], b16[f]), "frame %d: 16S panorama differs" % f
+        assert torch.equal(a8[f], b8[f])
+    assert int(a16[0].abs().max()) > 0
+    # an ROI view of a larger buffer (row step != width) works too; frames of a view with different steps are refused
+    big = [torch.zeros((cfg["h"] * 3 // 2, cfg["w"] + 64), dtype=torch.uint8, device="cuda") for _ in range(cfg["n"])]
+    roi = []
+    for i in range(cfg["n"]):
+        big[i][:, 32:32 + cfg["w"]] = nv[0][i]
+        roi.append(big[i][:, 32:32 + cfg["w"]])
+    c8, c16 = outs()
+    comp.stitch_nv12([roi], out8u=c8[:1], out16s=c16[:1])
+    torch.cuda.synchronize()
+    assert torch.equal(c16[0], a16[0])
+    if nf >= 2:
+        with pytest.raises(ms.MsError):
+            comp.stitch_nv12([roi, nv[1]], out8u=c8[:2], out16s=c16[:2])
+    comp.close()
+
+
+def test_nv12_direct_is_refused_where_it_does_not_apply(ms, cuda):
+    comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)
+    for i in range(cfg["n"]):
+        g = comp.view_geom(i).roi
+        mx, my = synth.mesh(g.width, g.height, 9, 11)
+        comp.set_mesh(i, mx, my)
+    nv = [[to_dev(synth.nv12_frame(cfg["w"], cfg["h"], i)) for i in range(cfg["n"])]]
+    with pytest.raises(ms.MsError):
+        comp.stitch_nv12(nv, out8u=[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device="cuda")])
+    comp.close()

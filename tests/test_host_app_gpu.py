@@ -38,12 +38,14 @@ def test_host_app_matches_python_binding(ms, cuda, tmp_path, rig):
     comp.close()
 
 
-def test_host_app_nv12_ingest(ms, cuda, tmp_path):
-    """--nv12: cameras deliver NV12, the host uploads half the bytes and cvtColor(YUV2BGR_NV12) (networking.cpp:45-47) runs on the device."""
+@pytest.mark.parametrize("flag", ["--nv12", "--nv12-direct"])
+def test_host_app_nv12_ingest(ms, cuda, tmp_path, flag):
+    """--nv12: cameras deliver NV12, the host uploads half the bytes and cvtColor(YUV2BGR_NV12) (networking.cpp:45-47) runs on the device;
+    --nv12-direct: no conversion pass, the warp samples the planes (ms_stitch_nv12).  Same panorama either way."""
     cfg = synth.CONFIGS["mini6"]
     info, dump = run_app(tmp_path, "--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]),
-                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 8, "--nv12")
-    assert info["nv12"] is True
+                         "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"], "--frames", 8, flag)
+    assert info["nv12"] is True and info["nv12_direct"] is (flag == "--nv12-direct")
     got = np.fromfile(dump, np.uint8).reshape(cfg["out_h"], cfg["out_w"], 3)
     comp, _, _ = make_rig(ms, "mini6")
     out8 = torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device=cuda)

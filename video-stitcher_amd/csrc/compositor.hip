@@ -2987,7 +2987,7 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
     } while (0)
 
 static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, hipStream_t st,
-                       int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{}, ms_image *out_i420 = nullptr)
+                       int cap, const char **names, float *ms_out, int *n_rec, ShardArgs S = ShardArgs{}, ms_image *out_i420 = nullptr, bool nv12 = false)
 {
     if (!c) return fail(MS_ERR_INVALID, "null context");
     std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);      // a synchronous table rebuild on another thread (ms_update_mask without a margin) waits for this enqueue, and vice versa
@@ -3004,6 +3004,10 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     for (int i = 0; i < F * N && S.mode != 2; ++i) {
         if (!((c->own_mask >> (i % N)) & 1u)) continue;       // another shard's view: not read
         if (!((c->needed_mask >> (i % N)) & 1u)) continue;    // column sharding: no pixel of this view reaches the window
+        if (nv12)
+            MS_CHECK(views[i].data && views[i].type == MS_8UC1 && views[i].rows == c->cfg.src_height * 3 / 2 && views[i].cols == c->cfg.src_width && views[i].step == views[i % N].step,
+                     "ms_stitch_nv12: view %d must be the NV12 planes of a %dx%d frame (8UC1, %d rows), every frame of a view with the same step", i, c->cfg.src_width, c->cfg.src_height, c->cfg.src_height * 3 / 2);
+        else
         MS_CHECK(views[i].data && views[i].type == MS_8UC3 && views[i].rows == c->cfg.src_height && views[i].cols == c->cfg.src_width,
                  "ms_stitch: view %d must be 8UC3 %dx%d", i, c->cfg.src_width, c->cfg.src_height);
         src.p[i] = (const uint8_t *)views[i].data;
@@ -3038,6 +3042,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         if (!(P.nb >= 1 && c->blend_vec[0] && c->cfg.debug_simple_kernels == 0 && S.mode == 0 && (P.out_w & 1) == 0 && P.i_rows > 0))
             return fail(MS_ERR_UNSUPPORTED, "ms_stitch_i420: needs the tiled level-0 band kernel (>= 1 band, pano width a multiple of 8, no view sharding) and an even canvas width");
     }
+    if (nv12 && !(c->cfg.enable_cpw == 0 && c->warp_tiled && c->cfg.debug_simple_kernels == 0 && c->cfg.cpu_flavour_remap == 0 && S.mode == 0 &&
+                  (c->cfg.src_width & 1) == 0 && (c->cfg.src_height & 1) == 0 && c->cfg.src_width >= 4))
+        return fail(MS_ERR_UNSUPPORTED, "ms_stitch_nv12: the NV12-sampling warp covers the tiled projection warp without CPW (even frame sizes); convert with ms_nv12_to_bgr_batch otherwise");
     MeshTable mesh{};
     const bool cpw = c->cfg.enable_cpw != 0;
     DispTable disp{};
@@ -3148,7 +3155,18 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         static const bool env_on = dev_knob("MS_WARP_ASYNC", 0) != 0;
         bool staged = c->warp_lds_tiles > 0 && (c->cfg.warp_lds_stage == 1 || (env_on && c->cfg.warp_lds_stage != 2));
         for (int i = 0; i < F * N; ++i) staged = staged && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
-        if (staged) {
+        if (nv12) {        // the cameras' NV12 planes sampled directly (k_warp_nv12): no BGR image in between
+            const dim3 b_(WARP_BX, WARP_WY);
+#define MS_NV12_LAUNCH(NF_)                                                                                                                                           \
+    do {                                                                                                                                                              \
+        const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, NF_));                                                                                            \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_nv12<MS_PROJ_SPHERICAL, NF_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        else k_warp_nv12<MS_PROJ_PLANE, NF_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+    } while (0)
+            if (F == 1) MS_NV12_LAUNCH(1); else MS_NV12_LAUNCH(2);
+#undef MS_NV12_LAUNCH
+        } else if (staged) {
             const long long items = (long long)c->n_warp_tiles * F;
             const int grid = (int)std::min<long long>(items, (long long)c->n_cus * (160 * 1024 / (2 * WA_BUF_BYTES)));
             MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
@@ -3271,6 +3289,11 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
 int ms_stitch(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out8u, ms_image *out16s, ms_stream stream)
 {
     return stitch_impl(c, n_frames, views, out8u, out16s, as_stream(stream), 0, nullptr, nullptr, nullptr);
+}
+
+int ms_stitch_nv12(ms_ctx *c, int n_frames, const ms_image *views_nv12, ms_image *out8u, ms_image *out16s, ms_stream stream)
+{
+    return stitch_impl(c, n_frames, views_nv12, out8u, out16s, as_stream(stream), 0, nullptr, nullptr, nullptr, ShardArgs{}, nullptr, true);
 }
 
 int ms_stitch_i420(ms_ctx *c, int n_frames, const ms_image *views, ms_image *out_i420, ms_stream stream)

@@ -678,6 +678,155 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_s(const WarpTile *__
                                                g0, g0_stride, tabs);
 }
 
+// the 1-D projection tables of a lane for tile T: column terms of its 4 pixels, row term of its row (see warp_tile_direct)
+__device__ __forceinline__ void warp_tabs_load(const WarpTile &T, const ViewDesc *__restrict__ views, const float2 *__restrict__ tabs, int tx, int ty, float2 ct[4], float2 &rt)
+{
+    if (T.flags & 4) {            // interior tile: table addresses from the tile entry alone
+        float4 a, b;
+        const float2 *cp = tabs + T.ctab + 4 * tx;
+        __builtin_memcpy(&a, __builtin_assume_aligned(cp, 8), 16);
+        __builtin_memcpy(&b, __builtin_assume_aligned(cp + 2, 8), 16);
+        ct[0] = make_float2(a.x, a.y); ct[1] = make_float2(a.z, a.w); ct[2] = make_float2(b.x, b.y); ct[3] = make_float2(b.z, b.w);
+        rt = tabs[T.rtab + ty];
+    } else {
+        const ViewDesc &V = views[T.view];
+        warp_coltab4(V, min(T.x0 + 4 * tx, V.pw - 4), ct);
+        rt = gload_f2(V.rowtab + reflect_fast(min(T.y0 + ty, V.ph - 1) - V.top, V.ah));
+    }
+}
+
+// ---- round 4: the projection warp sampling the cameras' NV12 frames directly --------------------------------------------
+// The capture threads of the reference convert every camera frame with cvtColor(COLOR_YUV2BGR_NV12) before the stitcher sees it (APP/networking.cpp:45-47,
+// defs.h:10-17); ms_nv12_to_bgr[_batch] does that on the device as a pass of its own (18.7 MB read + 37.3 MB written per 6 x 1080p frame, which k_warp_t then reads
+// again).  Here the warp reads the Y plane and the interleaved UV plane itself: every bilinear tap is converted with the SAME integer formula (nv12_bgr below =
+// nv12_to_bgr_cell of prims.hip = YUV420sp2RGB888Invoker of imgproc/src/color.cpp) and the four converted taps go through the same fp32 bilinear in the same order,
+// so the result is bit-identical to ms_nv12_to_bgr_batch + ms_stitch (tests/test_compositor_gpu.py::test_nv12_direct_*).  Per pixel and frame: two 2-byte reads
+// (Y of the two tap rows), two 4-byte reads (the UV pairs under them) -- 12 bytes instead of 24, no BGR image at all.  Offsets, weights and flags are per pixel,
+// shared by the frames of a lane (the frames of a view must share their row step: checked by the host).
+typedef unsigned short ms_u16_a1 __attribute__((aligned(1)));
+typedef unsigned ms_u32_a2 __attribute__((aligned(2)));
+struct NvRGB { float b, g, r; };
+__device__ __forceinline__ NvRGB nv12_bgr(unsigned Y, unsigned uvp)      // uvp: U in bits 0..7, V in bits 8..15
+{
+    constexpr int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
+    const int u = (int)(uvp & 0xffu) - 128, v = (int)((uvp >> 8) & 0xffu) - 128;
+    const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+    const int yy = max(0, (int)Y - 16) * CY;
+    NvRGB o;
+    o.b = (float)min(max((yy + buv) >> SH, 0), 255);
+    o.g = (float)min(max((yy + guv) >> SH, 0), 255);
+    o.r = (float)min(max((yy + ruv) >> SH, 0), 255);
+    return o;
+}
+// one tap with an explicit bounds test (border samples only): BORDER_CONSTANT 0 in BGR space, as the remap of the converted image would see it
+__device__ __forceinline__ NvRGB nv12_tap_checked(ms_gptr_u8 base, unsigned st, int rows, int cols, int xx, int yy)
+{
+    NvRGB z{0.f, 0.f, 0.f};
+    if ((unsigned)xx >= (unsigned)cols || (unsigned)yy >= (unsigned)rows) return z;
+    const unsigned Y = base[(unsigned)yy * st + (unsigned)xx];
+    const unsigned o = (unsigned)(rows + (yy >> 1)) * st + (unsigned)(xx & ~1);
+    return nv12_bgr(Y, (unsigned)base[o] | ((unsigned)base[o + 1] << 8));
+}
+template <int PROJ, int NF>
+__global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                            SrcTable src, int rows, int cols, uint8_t *__restrict__ g0, long long g0_stride,
+                                                            const float2 *__restrict__ tabs, int n_frames)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
+    const int tx = (int)threadIdx.x, ty = (int)(threadIdx.y + blockIdx.y * WARP_WY);
+    const int v = T.view;
+    const ViewDesc &V = views[v];
+    const int x = T.x0 + 4 * tx, y = T.y0 + ty;
+    const bool active = x < V.pw && y < V.ph;
+    ms_gptr_u8 base[NF];
+#pragma unroll
+    for (int fi = 0; fi < NF; ++fi) base[fi] = (ms_gptr_u8)(uintptr_t)src.p[(f0 + (fi < nf ? fi : 0)) * n_views + v];
+    const unsigned st = src.step[f0 * n_views + v];
+    const LevelDesc &L = V.lv[0];
+    const size_t plane = (size_t)L.h * L.pitch;
+    float xc[4], yc[4];
+    {
+        float2 ct[4], rt;
+        warp_tabs_load(T, views, tabs, tx, ty, ct, rt);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xc[k] = yc[k] = -1.f;
+        }
+    }
+    // once per pixel: offsets of the two Y reads and the two UV reads, which UV pair each tap column takes, the border flag
+    unsigned oy[4], ou1[4], ou2[4], sel = 0u;
+    bool slow = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x1 = f2i_rd(xc[k]), y1 = f2i_rd(yc[k]);
+        slow = slow || !((unsigned)x1 < (unsigned)(cols - 1) && (unsigned)y1 < (unsigned)(rows - 1));
+        const int x1c = min(max(x1, 0), cols - 2), y1c = min(max(y1, 0), rows - 2);
+        const int p0 = min(x1c & ~1, cols - 4);                  // the 4-byte UV window [p0, p0 + 4) stays inside the row
+        oy[k] = (unsigned)y1c * st + (unsigned)x1c;
+        ou1[k] = (unsigned)(rows + (y1c >> 1)) * st + (unsigned)p0;
+        ou2[k] = (unsigned)(rows + ((y1c + 1) >> 1)) * st + (unsigned)p0;
+        sel |= ((unsigned)(((x1c & ~1) - p0) >> 1) | ((unsigned)((((x1c + 1) & ~1) - p0) >> 1) << 1)) << (2 * k);      // bit 0: pair of tap column x1, bit 1: of x1 + 1
+    }
+    unsigned qy1[2][4], qy2[2][4], qu1[2][4], qu2[2][4];
+    auto issue = [&](int fi) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qy1[fi & 1][k] = *(const MS_GLOBAL_AS ms_u16_a1 *)(base[fi] + oy[k]);
+            qy2[fi & 1][k] = *(const MS_GLOBAL_AS ms_u16_a1 *)(base[fi] + oy[k] + st);
+            qu1[fi & 1][k] = *(const MS_GLOBAL_AS ms_u32_a2 *)(base[fi] + ou1[k]);
+            qu2[fi & 1][k] = *(const MS_GLOBAL_AS ms_u32_a2 *)(base[fi] + ou2[k]);
+        }
+    };
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NF > 1) issue(1);
+    __builtin_amdgcn_sched_barrier(0);
+    Taps t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = make_taps(xc[k], yc[k], rows + 1, cols + 1);      // (weights only; `fast` of Taps is not used here: see `slow`)
+    const bool any_slow = __builtin_amdgcn_ballot_w64(active && slow) != 0ull;
+    const float gain = V.gain;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int fi = 0; fi < NF; ++fi) {
+        const int b = fi & 1;
+        if (active && fi < nf) {
+            unsigned packed[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned s0 = (sel >> (2 * k)) & 1u, s1 = (sel >> (2 * k + 1)) & 1u;
+                const unsigned u1 = qu1[b][k], u2 = qu2[b][k];
+                NvRGB a11 = nv12_bgr(qy1[b][k] & 0xffu, s0 ? (u1 >> 16) : u1), a12 = nv12_bgr(qy1[b][k] >> 8, s1 ? (u1 >> 16) : u1);
+                NvRGB a21 = nv12_bgr(qy2[b][k] & 0xffu, s0 ? (u2 >> 16) : u2), a22 = nv12_bgr(qy2[b][k] >> 8, s1 ? (u2 >> 16) : u2);
+                if (any_slow) {
+                    const int x1 = f2i_rd(xc[k]), y1 = f2i_rd(yc[k]);
+                    if (!((unsigned)x1 < (unsigned)(cols - 1) && (unsigned)y1 < (unsigned)(rows - 1))) {      // a tap outside the image: every tap again, with its bounds test
+                        a11 = nv12_tap_checked(base[fi], st, rows, cols, x1, y1);     a12 = nv12_tap_checked(base[fi], st, rows, cols, x1 + 1, y1);
+                        a21 = nv12_tap_checked(base[fi], st, rows, cols, x1, y1 + 1); a22 = nv12_tap_checked(base[fi], st, rows, cols, x1 + 1, y1 + 1);
+                    }
+                }
+                // the fp32 bilinear of remap.cu / filters.hpp in the reference's tap order (blend_taps), per channel
+                float o[3];
+                o[0] = fma_single(a22.b, t[k].w22, fma_single(a21.b, t[k].w21, fma_single(a12.b, t[k].w12, fma_single(a11.b, t[k].w11, 0.f))));
+                o[1] = fma_single(a22.g, t[k].w22, fma_single(a21.g, t[k].w21, fma_single(a12.g, t[k].w12, fma_single(a11.g, t[k].w11, 0.f))));
+                o[2] = fma_single(a22.r, t[k].w22, fma_single(a21.r, t[k].w21, fma_single(a12.r, t[k].w12, fma_single(a11.r, t[k].w11, 0.f))));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) packed[c] = sat_u8_into(fma_single(gain, (float)sat_u8(o[c]), 0.f), k, packed[c]);      // convertTo(gain) of the rounded remap result (timed.cpp:94)
+            }
+            uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)y * L.pitch + x;
+            *reinterpret_cast<unsigned *>(d) = packed[0];
+            *reinterpret_cast<unsigned *>(d + plane) = packed[1];
+            *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fi + 2 < NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }
+    }
+}
+
 // ---- the same tiles with the source staged in LDS by asynchronous LDS-DMA: persistent, self-pipelined waves -------------------
 // Measured on the direct kernel (profiles/r02_warp_probes.txt): the gathers cost per lane-dword the texture-address path handles
 // (an unaligned 8-byte tap read touches 3 dwords, 48 per lane and tile), and they do not overlap the kernel's other half, its VALU

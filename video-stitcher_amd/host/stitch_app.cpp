@@ -16,7 +16,7 @@
 //   recalibrate thread (timed.cpp:414-463)       recalibrate(): ms_set_mesh per view from its own stream
 //
 // Usage: stitch_app [--views 6] [--size 1920x1080] [--out 3840x1920] [--hfov 90] [--bands 5] [--frames 300] [--cpw]
-//                   [--i420] [--nv12] [--dump pano.bin] [--no-upload] [--solve-mesh]
+//                   [--i420] [--nv12 | --nv12-direct] [--dump pano.bin] [--no-upload] [--solve-mesh]
 //                   [--reference-calib [--work-megapix 0.6] [--seam-megapix 0.01] [--compose-megapix 1.4]]
 // --reference-calib runs msshim::stitch_calib (calibration.cpp:252-311): the reference's rig and scale bookkeeping, cylindrical warper, seam-scale
 // gains + Voronoi seams from the first frames, the num_bands rule, and -- with the default COMPOSE_MEGAPIX -- cuda::resize of every frame.
@@ -75,6 +75,7 @@ struct Options {
     int views = 6, w = 1920, h = 1080, out_w = 3840, out_h = 1920, bands = 5, frames = 300;
     double hfov = 90.0;
     bool cpw = false, i420 = false, upload = true, nv12 = false, solve_mesh = false;
+    bool nv12_direct = false;         // --nv12-direct: no cvtColor pass at all, the warp samples the NV12 planes (ms_stitch_nv12)
     int consume_w = 0, consume_h = 0;           // > 0: consume()'s resize + black bars + BGR2YUV_I420 on the device (timed.cpp:251-316), OUTPUT_WIDTH x OUTPUT_HEIGHT
     int update_mask = 0;                        // > 0: mb->update_mask(idx, ...) after every mesh swap (timed.cpp:598-605, commented out there), enqueue-only with this margin
     bool reference_calib = false;               // stitch_calib as the reference ships it: cylindrical warper, megapixel budgets of defs.h, seam-scale pipeline
@@ -183,6 +184,7 @@ int main(int argc, char **argv)
         else if (k == "--i420") o.i420 = true;
         else if (k == "--no-upload") o.upload = false;
         else if (k == "--nv12") o.nv12 = true;
+        else if (k == "--nv12-direct") { o.nv12 = true; o.nv12_direct = true; }
         else if (k == "--dump") o.dump = next();
         else if (k == "--reference-calib") o.reference_calib = true;
         else if (k == "--work-megapix") o.work_mp = atof(next());
@@ -248,10 +250,15 @@ int main(int argc, char **argv)
         // ---- capture side: the newest frame of every camera, in pinned memory ----------------------------------------
         Lockable<std::vector<HostFrame>> imgs;
         imgs.v.resize(o.views);
+        // the cameras' frames sit back to back in ONE pinned block (view i at i * host_frame_bytes): a frame set then crosses PCIe as one copy -- six separate
+        // 3 MB NV12 copies per frame cost the link 10 % in per-copy overhead (2 420 frames/s against the 2 670 the bytes allow; round 4)
+        const size_t host_frame_bytes = o.nv12 ? (size_t)o.w * o.h * 3 / 2 : (size_t)o.w * o.h * 3;
+        unsigned char *host_slab = nullptr;
+        HIPCHECK(hipHostMalloc((void **)&host_slab, host_frame_bytes * o.views, hipHostMallocDefault));
         for (int i = 0; i < o.views; ++i) {
             HostFrame &f = imgs.v[i];
             f.w = o.w; f.h = o.h;
-            HIPCHECK(hipHostMalloc((void **)&f.p, (size_t)o.w * o.h * 3, hipHostMallocDefault));
+            f.p = host_slab + (size_t)i * host_frame_bytes;
             if (o.nv12) synth_nv12(f.p, o.w, o.h, i);          // (h * 3/2 rows of w bytes)
             else if (o.solve_mesh) synth_scene_frame(f.p, o.w, o.h, i, o.views, o.hfov, warp_scale, (i % 2 ? 1.0 : -1.0) * std::max(1.5, warp_scale / 200.0));   // odd / even cameras see the scene +-3 px apart
             else synth_frame(f.p, o.w, o.h, i);
@@ -275,9 +282,24 @@ int main(int argc, char **argv)
         bool buf_used[2] = {false, false};
         for (int b = 0; b < 2; ++b) {
             full_imgs_b[b].resize(o.views);
+            if (!o.nv12) {     // BGR cameras: the same one-block layout (rows of w * 3 bytes), one copy per frame set
+                unsigned char *slab = nullptr;
+                HIPCHECK(hipMalloc((void **)&slab, host_frame_bytes * o.views));
+                for (int i = 0; i < o.views; ++i) {
+                    DevMat &m = full_imgs_b[b][i];
+                    m.rows = o.h; m.cols = o.w; m.flags = MS_8UC3; m.step = (size_t)o.w * 3; m.data = slab + (size_t)i * host_frame_bytes;
+                }
+            } else
             for (auto &m : full_imgs_b[b]) m.create(o.h, o.w, MS_8UC3, 3);
             nv12_imgs_b[b].resize(o.nv12 ? o.views : 0);
-            for (auto &m : nv12_imgs_b[b]) m.create(o.h * 3 / 2, o.w, MS_8UC1, 1);
+            if (o.nv12) {      // one device block for the N NV12 frames of a set (rows of exactly `w` bytes, like the pinned block): filled by ONE copy per frame set
+                unsigned char *slab = nullptr;
+                HIPCHECK(hipMalloc((void **)&slab, host_frame_bytes * o.views));
+                for (int i = 0; i < o.views; ++i) {
+                    DevMat &m = nv12_imgs_b[b][i];
+                    m.rows = o.h * 3 / 2; m.cols = o.w; m.flags = MS_8UC1; m.step = (size_t)o.w; m.data = slab + (size_t)i * host_frame_bytes;
+                }
+            }
             HIPCHECK(hipEventCreateWithFlags(&up_done[b], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&buf_free[b], hipEventDisableTiming));
         }
@@ -422,17 +444,13 @@ int main(int argc, char **argv)
             if (o.upload || t == 0) {
                 std::lock_guard<std::mutex> lk(imgs.mu);                                  // imgs.lock() ... imgs.unlock()
                 if (buf_used[ib]) HIPCHECK(hipStreamWaitEvent(upload_stream, buf_free[ib], 0));     // the stitch of frame t-2 has read this buffer
-                for (int i = 0; i < o.views; ++i) {
-                    if (o.nv12) {         // half the PCIe bytes: upload NV12, convert on the device
-                        HIPCHECK(hipMemcpy2DAsync(nv12_imgs[i].data, nv12_imgs[i].step, imgs.v[i].p, (size_t)o.w, (size_t)o.w, o.h * 3 / 2,
-                                                  hipMemcpyHostToDevice, upload_stream));
-                    } else
-                        HIPCHECK(hipMemcpy2DAsync(full_imgs[i].data, full_imgs[i].step, imgs.v[i].p, (size_t)o.w * 3, (size_t)o.w * 3, o.h,
-                                                  hipMemcpyHostToDevice, upload_stream));      // GpuMat::upload(Mat, stream), timed.cpp:68
-                }
+                if (o.nv12)               // half the PCIe bytes: upload NV12 (all cameras in one copy), convert on the device / in the warp
+                    HIPCHECK(hipMemcpyAsync(nv12_imgs[0].data, host_slab, host_frame_bytes * o.views, hipMemcpyHostToDevice, upload_stream));
+                else                      // GpuMat::upload(Mat, stream) of every camera (timed.cpp:68), as one copy
+                    HIPCHECK(hipMemcpyAsync(full_imgs[0].data, host_slab, host_frame_bytes * o.views, hipMemcpyHostToDevice, upload_stream));
                 HIPCHECK(hipEventRecord(up_done[ib], upload_stream));
                 HIPCHECK(hipStreamWaitEvent(stitch_stream, up_done[ib], 0));
-                if (o.nv12) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47).
+                if (o.nv12 && !o.nv12_direct) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47).
                                           // On the STITCH stream (round 4): the upload stream then carries nothing but the copies, so the PCIe link -- the limit of
                                           // this path -- never waits for a kernel; the conversion (one latency-bound launch) rides in front of the frame's stitch
                     std::vector<ms_image> a(o.views), d(o.views);
@@ -443,7 +461,9 @@ int main(int argc, char **argv)
             if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)
                 msshim::cuda::resize(full_imgs, small_imgs, cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);      // all views, one launch
                 comp.stitch_one(small_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
-            } else
+            } else if (o.nv12_direct)
+                comp.stitch_one_nv12(nv12_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);      // the warp converts each tap itself: no BGR frames on the device at all
+            else
                 comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
             if (o.i420) {
                 ms_image rows{s->pano8u.data + (size_t)ya * s->pano8u.step, s->pano8u.step, o.out_w, yb - ya, MS_8UC3};
@@ -508,10 +528,10 @@ int main(int argc, char **argv)
             if (!f || fwrite(last_pano.data(), 1, last_pano.size(), f) != last_pano.size()) { fprintf(stderr, "cannot write %s\n", o.dump.c_str()); return 2; }
             fclose(f);
         }
-        printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"upload\": %s, "
+        printf("{\"app\": \"stitch_app\", \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, \"cpw\": %s, \"i420\": %s, \"nv12\": %s, \"nv12_direct\": %s, \"upload\": %s, "
                "\"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"recalibrations\": %d, \"mesh_solver_iterations\": %d, \"max_mesh_displacement_px\": %.2f, "
                "\"orb_keypoints\": %lld, \"ratio_matches\": %lld, \"ransac_inliers\": %lld, \"update_mask_margin\": %d, \"update_mask_equals_sync_rebuild\": %s, \"consume_image_height\": %d, \"consume_checksum\": \"%016llx\", \"checksum\": \"%016llx\"}\n",
-               o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.upload ? "true" : "false",
+               o.views, o.w, o.h, o.out_w, o.out_h, pg.num_bands, o.cpw ? "true" : "false", o.i420 ? "true" : "false", o.nv12 ? "true" : "false", o.nv12_direct ? "true" : "false", o.upload ? "true" : "false",
                consumed, secs, consumed / secs, recalibrations.load(), solver_iterations.load(), (double)max_disp.load(),
                total_keypoints.load(), total_matches.load(), total_inliers.load(), o.update_mask, selfcheck < 0 ? "null" : (selfcheck ? "true" : "false"), consume_image_height, consume_checksum, checksum);
     } catch (const msshim::Error &e) {

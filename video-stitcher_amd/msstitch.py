@@ -93,7 +93,7 @@ EXPORTS = [
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
-    "ms_save_tables", "ms_load_tables", "ms_calib_shape",
+    "ms_save_tables", "ms_load_tables", "ms_calib_shape", "ms_stitch_nv12",
 ]
 
 _lib = None
@@ -363,9 +363,10 @@ def nv12_to_bgr(src, dst=None):
     return dst
 
 
-def nv12_to_bgr_batch(srcs):
+def nv12_to_bgr_batch(srcs, dsts=None):
     """cvtColor(YUV2BGR_NV12) of n cameras of one geometry in one launch; returns the list of BGR tensors."""
-    dsts = [_new((t.shape[0] * 2 // 3, t.shape[1], 3), _torch().uint8) for t in srcs]
+    if dsts is None:
+        dsts = [_new((t.shape[0] * 2 // 3, t.shape[1], 3), _torch().uint8) for t in srcs]
     n = len(srcs)
     a = (Image * n)(*[img(t) for t in srcs]); b = (Image * n)(*[img(t) for t in dsts])
     _chk(load().ms_nv12_to_bgr_batch(a, b, n, _stream()))
@@ -757,6 +758,20 @@ class Compositor:
         """frames: list (per frame) of lists (per view) of uint8 HxWx3 cuda tensors."""
         n, views, o8, o16 = self._tables(frames, out8u, out16s)
         _chk(load().ms_stitch(self._ctx, n, views, o8, o16, _stream()))
+
+    def stitch_nv12(self, frames_nv12, out8u=None, out16s=None):
+        """ms_stitch_nv12: frames_nv12 = list (per frame) of lists (per view) of uint8 (H * 3 / 2) x W cuda tensors (the cameras' NV12 planes)"""
+        n, views, o8, o16 = self._tables(frames_nv12, out8u, out16s)
+        _chk(load().ms_stitch_nv12(self._ctx, n, views, o8, o16, _stream()))
+
+    def prepared_nv12(self, frames_nv12, out8u=None, out16s=None):
+        n, views, o8, o16 = self._tables(frames_nv12, out8u, out16s)
+        fn, ctx = load().ms_stitch_nv12, self._ctx
+
+        def run(stream=None):
+            _chk(fn(ctx, n, views, o8, o16, stream if stream is not None else _stream()))
+        run.keepalive = (frames_nv12, out8u, out16s, views, o8, o16)
+        return run
 
     def prepared(self, frames, out8u=None, out16s=None):
         """Pre-marshal the descriptor tables once; returns a zero-overhead callable for timed loops."""

@@ -115,6 +115,16 @@ public:
         if (out16s) o16 = wrap(*out16s);
         check(ms_stitch(ctx_, (int)(v.size() / n_), v.data(), out8u ? &o8 : nullptr, out16s ? &o16 : nullptr, s));
     }
+    // stitch_one on the cameras' NV12 frames (defs.h:10-17; the capture threads' cvtColor(YUV2BGR_NV12), networking.cpp:45-47, folded into the warp): nv12_imgs[i] = 8UC1 (rows * 3 / 2) x cols
+    template <class Mat> void stitch_one_nv12(const std::vector<Mat> &nv12_imgs, Mat *out8u, Mat *out16s, ms_stream s = nullptr)
+    {
+        std::vector<ms_image> v;
+        for (const Mat &m : nv12_imgs) v.push_back(wrap(m));
+        ms_image o8{}, o16{};
+        if (out8u) o8 = wrap(*out8u);
+        if (out16s) o16 = wrap(*out16s);
+        check(ms_stitch_nv12(ctx_, (int)(v.size() / n_), v.data(), out8u ? &o8 : nullptr, out16s ? &o16 : nullptr, s));
+    }
     // stitch_one + consume()'s cvtColor(BGR2YUV_I420) (timed.cpp:308-316) in one: i420[f] = contiguous 8UC1 (rows * 3 / 2) x out_w, rows from i420Rows()
     template <class Mat> void stitch_one_i420(const std::vector<Mat> &full_imgs, std::vector<Mat> &i420, ms_stream s = nullptr)
     {
