@@ -1759,6 +1759,10 @@ static bool sharded_ctx(const ms_ctx *c) { return c->own_mask != ((c->N >= 32) ?
 // k_owner_map for every band that has a map, into `pure` (laid out by build_plan), from the weights `vt` points at
 static int launch_owner_maps(ms_ctx *c, const ViewDesc *vt, uint8_t *pure, hipStream_t st)
 {
+    // whoever rewrites the owner maps invalidates what the host knows about them: the integer-only level-0 build (k_blend8<true, 0, 1>, which has NO general path and
+    // leaves a general cell unwritten) may only run after the caller has looked at the new level-0 map again (build_plan does; the enqueue-only mask update never
+    // sees its maps on the host and stays on the all-classes build).  Cleared HERE so that a future caller cannot forget.
+    c->l0_integer_only = false;
     for (int l = 0; l < c->pano.nb; ++l) {
         if (!c->pure_off[l]) continue;
         const int pw_ = div_up(c->pano.qw[l], 64), ph_ = div_up(c->pano.qh[l], 16);
