@@ -3090,6 +3090,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     bool src_shared = warp_shared_knob && S.mode != 2;
     for (int i = N; i < F * N && src_shared; ++i)
         if (src.p[i]) src_shared = src.p[i % N] && src.step[i] == src.step[i % N] && (((uintptr_t)src.p[i] ^ (uintptr_t)src.p[i % N]) & 3) == 0;
+    bool src_steps_equal = warp_shared_knob && S.mode != 2;
+    for (int i = N; i < F * N && src_steps_equal; ++i)
+        if (src.p[i]) src_steps_equal = src.p[i % N] && src.step[i] == src.step[i % N];
     const bool int_only = c->l0_integer_only && P.pure[0] != nullptr;      // (read under mesh_mu, like the table pointers: an enqueue-only mask update clears it)
 
     // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
@@ -3180,7 +3183,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
                 MS_WARP_S_LAUNCH(false, WARP_NF, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (c->warp_aligned)
                 MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
-            else
+            else if (src_steps_equal && F > 1 && dev_knob("MS_WARP_SHARED_U", 1)) {      // the unaligned-read form with shared offsets (config 5): only the row step has to agree
+                const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), b_(WARP_BX, WARP_WY);
+                if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_s<false, MS_PROJ_SPHERICAL, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_s<false, MS_PROJ_CYLINDRICAL, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                else k_warp_s<false, MS_PROJ_PLANE, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            } else
                 MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         }
     } else if (c->cfg.cpu_flavour_remap != 0) {

@@ -540,7 +540,9 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_t(const WarpTile *__
 // (global_load_dwordx3 v, v_off, s[base]).  So per pixel, once: floor, offset, shifts, weights, border flag; per pixel and frame: two reads,
 // four v_alignbyte, 12 conversions, 12 + 3 fmas, 6 packs.  104 VGPRs: the kernel is held at 4 waves per SIMD anyway (see stitch_impl).
 // The border test is one wave-level branch per frame (ballot over the lanes' four pixels) instead of one exec-masked region per pixel.
-template <bool CPW, int PROJ, int NF>
+// AL = false: the unaligned 8-byte tap reads of warp_tile_direct (strong minification, config 5: every tap read is isolated and the aligned form's extra registers cost
+// more than its dwords save) with the same sharing -- the offset needs only the frames' common row step, whatever their alignment.
+template <bool CPW, int PROJ, int NF, bool AL = true>
 __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int nf, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
                                                  const SrcTable &src, int src_rows, int src_cols, const MeshTable &mesh,
                                                  const uint8_t *__restrict__ stage, long long stage_stride,
@@ -551,13 +553,15 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
     const int x = T.x0 + 4 * tx, y = T.y0 + ty;
     const bool active = x < V.pw && y < V.ph;
     ms_gptr_u8 base[NF];
+    const uint8_t *ubase[NF];
     unsigned lo2 = 0u;
 #pragma unroll
     for (int fi = 0; fi < NF; ++fi) {
         const int f = f0 + (fi < nf ? fi : 0);      // (a missing frame of a short group is read from frame f0 again and dropped: no branch around the reads, see warp_tile_direct)
         const uint8_t *p = CPW ? stage + (size_t)f * stage_stride + V.s1_off : src.p[f * n_views + v];
         base[fi] = (ms_gptr_u8)((uintptr_t)p & ~(uintptr_t)3);
-        if (fi == 0) lo2 = (unsigned)(uintptr_t)p & 3u;
+        ubase[fi] = p;
+        if (fi == 0 && AL) lo2 = (unsigned)(uintptr_t)p & 3u;
     }
     const unsigned st = CPW ? (unsigned)V.s1_pitch : src.step[f0 * n_views + v];
     const int srows = CPW ? V.ah : src_rows, scols = CPW ? V.aw : src_cols;
@@ -596,17 +600,23 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
         const int x1 = f2i_rd(xc[k]), y1 = f2i_rd(yc[k]);
         slow = slow || !((unsigned)x1 < (unsigned)(scols - 2) && (unsigned)y1 < (unsigned)(srows - 1));
         const unsigned a = lo2 + tap_offset(x1, y1, srows, scols, st), b = a + st;
-        va[k] = a & ~3u; vb[k] = b & ~3u;
+        va[k] = AL ? (a & ~3u) : a; vb[k] = AL ? (b & ~3u) : b;
         sh1 |= (a & 3u) << (2 * k); sh2 |= (b & 3u) << (2 * k);
     }
-    Px3 q1[2][4], q2[2][4];
+    Px3 q1[AL ? 2 : 1][AL ? 4 : 1], q2[AL ? 2 : 1][AL ? 4 : 1];
+    Px2 u1[AL ? 1 : 2][AL ? 1 : 4], u2[AL ? 1 : 2][AL ? 1 : 4];
     auto issue = [&](int fi) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const ms_u32x3_a4 r1 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + va[k]);
-            const ms_u32x3_a4 r2 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + vb[k]);
-            q1[fi & 1][k] = Px3{r1.x, r1.y, r1.z};
-            q2[fi & 1][k] = Px3{r2.x, r2.y, r2.z};
+            if (AL) {
+                const ms_u32x3_a4 r1 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + va[k]);
+                const ms_u32x3_a4 r2 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + vb[k]);
+                q1[AL ? fi & 1 : 0][AL ? k : 0] = Px3{r1.x, r1.y, r1.z};
+                q2[AL ? fi & 1 : 0][AL ? k : 0] = Px3{r2.x, r2.y, r2.z};
+            } else {
+                u1[AL ? 0 : fi & 1][AL ? 0 : k] = load_px2(ubase[fi], va[k]);
+                u2[AL ? 0 : fi & 1][AL ? 0 : k] = load_px2(ubase[fi], vb[k]);
+            }
         }
     };
     issue(0);
@@ -628,8 +638,10 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
             Px2 r1[4], r2[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                r1[k] = px3_to_px2(q1[b][k], sh1 >> (2 * k));
-                r2[k] = px3_to_px2(q2[b][k], sh2 >> (2 * k));
+                if (AL) {
+                    r1[k] = px3_to_px2(q1[AL ? b : 0][AL ? k : 0], sh1 >> (2 * k));
+                    r2[k] = px3_to_px2(q2[AL ? b : 0][AL ? k : 0], sh2 >> (2 * k));
+                } else { r1[k] = u1[AL ? 0 : b][AL ? 0 : k]; r2[k] = u2[AL ? 0 : b][AL ? 0 : k]; }
             }
             if (any_slow) {
 #pragma unroll
@@ -662,7 +674,7 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
     }
 }
 
-template <bool CPW, int PROJ, int NF>      // NF = warp_nf(CPW) frames per lane; 1 for one-frame calls (the reference's call shape: no reads for a frame that is not there)
+template <bool CPW, int PROJ, int NF, bool AL = true>      // NF = warp_nf(CPW) frames per lane; 1 for one-frame calls (the reference's call shape: no reads for a frame that is not there)
 __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_s(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                          SrcTable src, int src_rows, int src_cols, MeshTable mesh,
                                                          const uint8_t *__restrict__ stage, long long stage_stride,
@@ -670,7 +682,10 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_s(const WarpTile *__
 {
     const WarpTile T = tiles[blockIdx.x];
     const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
-    if (CPW || (T.flags & 8))       // (a tile that samples the last row of a caller's image keeps the unaligned reads: see Px3)
+    if (!AL)
+        warp_tile_shared<CPW, PROJ, NF, false>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                               g0, g0_stride, tabs);
+    else if (CPW || (T.flags & 8))       // (a tile that samples the last row of a caller's image keeps the unaligned reads: see Px3)
         warp_tile_shared<CPW, PROJ, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
                                         g0, g0_stride, tabs);
     else
