@@ -38,4 +38,9 @@ python tools/host_enqueue.py 2>&1 | grep calls > $PO/${TAG}_host_enqueue.txt
 rm -f $PO/${TAG}_from_inputs.txt; MS_FROM_INPUTS_LOG=$PWD/$PO/${TAG}_from_inputs.txt python -m pytest tests/test_from_inputs_gpu.py -q > $PO/from_inputs.log 2>&1
 { video-stitcher_amd/stitch_dist --gpus 1 --frames 256 --batch 16 --no-checksum; video-stitcher_amd/stitch_dist --gpus 2 --share-gpu --frames 256 --batch 16 --no-checksum;
   video-stitcher_amd/stitch_dist --gpus 2 --share-gpu --col-shards 2 --frames 64 --batch 4 --views 12 --size 3840x2160 --out 7680x3840 --hfov 60 --no-checksum; } > $PO/${TAG}_stitch_dist.txt 2>&1
+# 7. round 4: every frame of the default pass distinct (96 frame sets, 3.6 GB of source: nothing survives in the Infinity Cache) beside the 8-set pool; the NV12 ingest both ways;
+#    the instruction-rate probe
+timeout 900 python bench.py --no-cpu-baseline --no-pcie --no-live --distinct 96 > $PO/${TAG}_bench_distinct96.json 2> $PO/distinct96.err
+{ python tools/time_nv12.py 32; python tools/time_nv12.py 1; } > $PO/${TAG}_nv12.txt 2>&1
+[ -x ab/valu_probe ] && ab/valu_probe > $PO/${TAG}_valu_probe.txt 2>&1
 du -sh gpurun_out; ls $PO
