@@ -54,7 +54,7 @@ def main(tag):
     calls = max([r[2] for r in rows if r[1].startswith(("k_warp_t", "k_warp_s", "k_stage1_t", "k_stage1_s"))] or [1])
     lines = ["# Per-kernel report (%s): %s, %d frames per launch, one context / one stream" % (tag, traffic.get("config", "cfg2"), F), "",
              "Sources: `%s_kernel_trace.txt`/`%s_traffic.json` (rocprofv3 kernel trace; FETCH_SIZE x2.0 + WRITE_SIZE x1.0, calibrated on a 1 GiB copy),"
-             " `%s_counters.txt` (SQ counters), `%s_bench.json` (bench.py line).  VALU busy = VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.33 GHz)." % (tag, tag, tag, tag), "",
+             " `%s_counters.txt` (SQ counters), `%s_bench.json` (bench.py line).  VALU busy = VALU instructions x 4 cycles / (1024 SIMDs x launch time x 2.33 GHz) -- an UPPER bound: on gfx950 the plain 32-bit fp32 / add / and / shift-right / move forms issue in ~2.4 cycles, everything else (conversions, packed 16-bit, three-operand integer, v_perm / v_alignbyte) in ~4.2 (`r04_valu_probe.txt`).  HBM MB = FETCH_SIZE x 2 + WRITE_SIZE: requests of the L2s to the fabric, Infinity-Cache hits included." % (tag, tag, tag, tag), "",
              "| kernel | mean launch µs | µs / frame | HBM MB / launch | HBM TB/s | waves | VALU / wave | VALU busy | waves / SIMD |", "|---|---|---|---|---|---|---|---|---|"]
     for _, k, n, us, hb, waves, vpw, busy, occ in rows:
         lines.append("| `%s` | %.1f | %.2f | %.0f | %.2f | %s | %s | %s | %s |" % (
