@@ -37,6 +37,10 @@ def test_single_gpu_line_has_the_contract_keys():
         assert r["frac_contract"] >= r["frac"] and "collected" in r["traffic_source"] and r["frac"] < 1.0
     else:
         assert r["basis"].startswith("algorithmic") and abs(r["frac"] - r["frac_contract"]) < 1e-6
+    assert r["traffic_stale"] in (True, False, None) or isinstance(r["traffic_stale"], str)      # False when the PMC summary was collected on these very kernel sources
+    fr = d["frame_roofline"]
+    assert "vs_contract_model" in fr and "wall_vs_contract_model" in fr and "frac" not in fr and "wall_frac" not in fr      # the > 1 model figures are not called fractions
+    assert d["config"]["distinct_frame_sets"] == 8 and d["pcie_inclusive_fps"].get("nv12_direct_value", 0) > 100
     c = d["ceiling"]      # the tuned streaming copy / read of this run: the measured ceiling the fractions are read against
     assert c["copy_TBps"] > 4.0 and c["read_TBps"] > c["copy_TBps"] * 0.9
 
@@ -65,6 +69,8 @@ def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     assert d["value_no_gather"] > 0 and d["gather"]["gathered_passes"] == 4 and d["verified"] is True
     # the data path is the product's own ms_dist layer (host mailbox here: the ranks share the GPU); the line says what the communicator saw
     assert d["dist"]["transport"] == "host" and d["dist"]["nranks"] == 2 and "ms_dist" in d["config"]["parallelism"]
+    # ... and the fields a reader of a first multi-GPU record needs, at the top level: what the communicator saw, every rank's own copy ceiling, how to read the three rates
+    assert d["transport"] == "host" and len(d["pci_bus_ids"]) >= 2 and len(d["rank_copy_TBps"]) == 2 and all(x and x > 1.0 for x in d["rank_copy_TBps"]) and "value_no_gather" in d["how_to_read"]
     # the default: EVERY frame gathered in the main region (`value` = the conservative number); compute-only and live-rate rates beside it
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29535",
                         "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--passes", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
