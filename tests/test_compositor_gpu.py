@@ -783,6 +783,13 @@ def test_nv12_direct_equals_convert_then_stitch(ms, cuda, rig, proj, mask_mode, 
     comp.stitch_nv12([roi], out8u=c8[:1], out16s=c16[:1])
     torch.cuda.synchronize()
     assert torch.equal(c16[0], a16[0])
+    # ... and at an odd byte offset: the planes are then not 4-byte aligned and the kernel's unaligned-read form runs (the aligned 8-byte windows are the default)
+    for i in range(cfg["n"]):
+        big[i][:, 33:33 + cfg["w"]] = nv[0][i]
+    c8, c16 = outs()
+    comp.stitch_nv12([[big[i][:, 33:33 + cfg["w"]] for i in range(cfg["n"])]], out8u=c8[:1], out16s=c16[:1])
+    torch.cuda.synchronize()
+    assert torch.equal(c16[0], a16[0])
     if nf >= 2:
         with pytest.raises(ms.MsError):
             comp.stitch_nv12([roi, nv[1]], out8u=c8[:2], out16s=c16[:2])

@@ -3164,14 +3164,18 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         for (int i = 0; i < F * N; ++i) staged = staged && ((uintptr_t)src.p[i] & 15) == 0;   // chunk copies start on 16-byte lines of the buffer
         if (nv12) {        // the cameras' NV12 planes sampled directly (k_warp_nv12): no BGR image in between
             const dim3 b_(WARP_BX, WARP_WY);
-#define MS_NV12_LAUNCH(NF_)                                                                                                                                           \
+#define MS_NV12_LAUNCH(NF_, ALN_)                                                                                                                                     \
     do {                                                                                                                                                              \
         const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, NF_));                                                                                            \
-        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_nv12<MS_PROJ_SPHERICAL, NF_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
-        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
-        else k_warp_nv12<MS_PROJ_PLANE, NF_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_nv12<MS_PROJ_SPHERICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        else k_warp_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
     } while (0)
-            if (F == 1) MS_NV12_LAUNCH(1); else MS_NV12_LAUNCH(2);
+            // aligned 8-byte windows where every plane, step and the width are multiples of 4 (cameras' frames in ordinary buffers are); the unaligned 2- / 4-byte reads otherwise
+            bool nv_al = (c->cfg.src_width & 3) == 0 && c->cfg.src_width >= 8 && dev_knob("MS_NV12_ALIGNED", 1) != 0;
+            for (int i = 0; i < F * N && nv_al; ++i) if (src.p[i]) nv_al = (((uintptr_t)src.p[i] | src.step[i]) & 3) == 0;
+            if (nv_al) { if (F == 1) MS_NV12_LAUNCH(1, true); else MS_NV12_LAUNCH(2, true); }
+            else { if (F == 1) MS_NV12_LAUNCH(1, false); else MS_NV12_LAUNCH(2, false); }
 #undef MS_NV12_LAUNCH
         } else if (staged) {
             const long long items = (long long)c->n_warp_tiles * F;

@@ -742,7 +742,10 @@ __device__ __forceinline__ NvRGB nv12_tap_checked(ms_gptr_u8 base, unsigned st, 
     const unsigned o = (unsigned)(rows + (yy >> 1)) * st + (unsigned)(xx & ~1);
     return nv12_bgr(Y, (unsigned)base[o] | ((unsigned)base[o + 1] << 8));
 }
-template <int PROJ, int NF>
+// ALN: every read an ALIGNED 8-byte window (global_load_dwordx2 at a multiple of 4) and one 64-bit shift -- an unaligned gather costs the texture-address path more than an aligned one of
+// twice the size (config 2, BGR: unaligned 8-byte tap reads 456 us, aligned 12-byte ones 375).  Needs 4-byte aligned planes, steps and widths (the host checks): then both tap rows
+// and both UV rows of a pixel share their shifts, and clamping the UV window to [row end - 8, row end) keeps the last row's reads inside the caller's buffer.
+template <int PROJ, int NF, bool ALN>
 __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
                                                             SrcTable src, int rows, int cols, uint8_t *__restrict__ g0, long long g0_stride,
                                                             const float2 *__restrict__ tabs, int n_frames)
@@ -773,7 +776,7 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile 
         }
     }
     // once per pixel: offsets of the two Y reads and the two UV reads, which UV pair each tap column takes, the border flag
-    unsigned oy[4], ou1[4], ou2[4], sel = 0u;
+    unsigned oy[4], ou1[4], ou2[4], sel = 0u, shf = 0u;
     bool slow = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -785,15 +788,31 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile 
         ou1[k] = (unsigned)(rows + (y1c >> 1)) * st + (unsigned)p0;
         ou2[k] = (unsigned)(rows + ((y1c + 1) >> 1)) * st + (unsigned)p0;
         sel |= ((unsigned)(((x1c & ~1) - p0) >> 1) | ((unsigned)((((x1c + 1) & ~1) - p0) >> 1) << 1)) << (2 * k);      // bit 0: pair of tap column x1, bit 1: of x1 + 1
+        if (ALN) {      // aligned windows: Y at oy & ~3 (both rows: the step is a multiple of 4), UV at min(ou & ~3, row end - 8); the byte shifts (<= 3 and <= 4) once per pixel
+            const unsigned ca = min((unsigned)p0 & ~3u, (unsigned)cols - 8u), su = (unsigned)p0 - ca;
+            shf |= ((oy[k] & 3u) | (su << 2)) << (5 * k);
+            oy[k] &= ~3u;
+            ou1[k] = ou1[k] - (unsigned)p0 + ca;
+            ou2[k] = ou2[k] - (unsigned)p0 + ca;
+        }
     }
+    typedef unsigned ms_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
     unsigned qy1[2][4], qy2[2][4], qu1[2][4], qu2[2][4];
+    unsigned hy1[ALN ? 2 : 1][ALN ? 4 : 1], hy2[ALN ? 2 : 1][ALN ? 4 : 1], hu1[ALN ? 2 : 1][ALN ? 4 : 1], hu2[ALN ? 2 : 1][ALN ? 4 : 1];      // ALN: the windows' upper dwords
     auto issue = [&](int fi) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            qy1[fi & 1][k] = *(const MS_GLOBAL_AS ms_u16_a1 *)(base[fi] + oy[k]);
-            qy2[fi & 1][k] = *(const MS_GLOBAL_AS ms_u16_a1 *)(base[fi] + oy[k] + st);
-            qu1[fi & 1][k] = *(const MS_GLOBAL_AS ms_u32_a2 *)(base[fi] + ou1[k]);
-            qu2[fi & 1][k] = *(const MS_GLOBAL_AS ms_u32_a2 *)(base[fi] + ou2[k]);
+            if (ALN) {
+                const ms_u32x2_a4 a = *(const MS_GLOBAL_AS ms_u32x2_a4 *)(base[fi] + oy[k]), b = *(const MS_GLOBAL_AS ms_u32x2_a4 *)(base[fi] + oy[k] + st);
+                const ms_u32x2_a4 c = *(const MS_GLOBAL_AS ms_u32x2_a4 *)(base[fi] + ou1[k]), d = *(const MS_GLOBAL_AS ms_u32x2_a4 *)(base[fi] + ou2[k]);
+                qy1[fi & 1][k] = a.x; hy1[ALN ? fi & 1 : 0][ALN ? k : 0] = a.y; qy2[fi & 1][k] = b.x; hy2[ALN ? fi & 1 : 0][ALN ? k : 0] = b.y;
+                qu1[fi & 1][k] = c.x; hu1[ALN ? fi & 1 : 0][ALN ? k : 0] = c.y; qu2[fi & 1][k] = d.x; hu2[ALN ? fi & 1 : 0][ALN ? k : 0] = d.y;
+            } else {
+                qy1[fi & 1][k] = *(const MS_GLOBAL_AS ms_u16_a1 *)(base[fi] + oy[k]);
+                qy2[fi & 1][k] = *(const MS_GLOBAL_AS ms_u16_a1 *)(base[fi] + oy[k] + st);
+                qu1[fi & 1][k] = *(const MS_GLOBAL_AS ms_u32_a2 *)(base[fi] + ou1[k]);
+                qu2[fi & 1][k] = *(const MS_GLOBAL_AS ms_u32_a2 *)(base[fi] + ou2[k]);
+            }
         }
     };
     issue(0);
@@ -814,9 +833,16 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned s0 = (sel >> (2 * k)) & 1u, s1 = (sel >> (2 * k + 1)) & 1u;
-                const unsigned u1 = qu1[b][k], u2 = qu2[b][k];
-                NvRGB a11 = nv12_bgr(qy1[b][k] & 0xffu, s0 ? (u1 >> 16) : u1), a12 = nv12_bgr(qy1[b][k] >> 8, s1 ? (u1 >> 16) : u1);
-                NvRGB a21 = nv12_bgr(qy2[b][k] & 0xffu, s0 ? (u2 >> 16) : u2), a22 = nv12_bgr(qy2[b][k] >> 8, s1 ? (u2 >> 16) : u2);
+                unsigned u1 = qu1[b][k], u2 = qu2[b][k], y1p = qy1[b][k], y2p = qy2[b][k];
+                if (ALN) {      // the wanted bytes out of the aligned windows: one 64-bit shift each
+                    const unsigned sy = 8u * ((shf >> (5 * k)) & 3u), su = 8u * ((shf >> (5 * k + 2)) & 7u);
+                    y1p = (unsigned)((((unsigned long long)hy1[ALN ? b : 0][ALN ? k : 0] << 32) | y1p) >> sy) & 0xffffu;
+                    y2p = (unsigned)((((unsigned long long)hy2[ALN ? b : 0][ALN ? k : 0] << 32) | y2p) >> sy) & 0xffffu;
+                    u1 = (unsigned)((((unsigned long long)hu1[ALN ? b : 0][ALN ? k : 0] << 32) | u1) >> su);
+                    u2 = (unsigned)((((unsigned long long)hu2[ALN ? b : 0][ALN ? k : 0] << 32) | u2) >> su);
+                }
+                NvRGB a11 = nv12_bgr(y1p & 0xffu, s0 ? (u1 >> 16) : u1), a12 = nv12_bgr(y1p >> 8, s1 ? (u1 >> 16) : u1);
+                NvRGB a21 = nv12_bgr(y2p & 0xffu, s0 ? (u2 >> 16) : u2), a22 = nv12_bgr(y2p >> 8, s1 ? (u2 >> 16) : u2);
                 if (any_slow) {
                     const int x1 = f2i_rd(xc[k]), y1 = f2i_rd(yc[k]);
                     if (!((unsigned)x1 < (unsigned)(cols - 1) && (unsigned)y1 < (unsigned)(rows - 1))) {      // a tap outside the image: every tap again, with its bounds test
