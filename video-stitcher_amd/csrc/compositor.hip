@@ -3183,7 +3183,10 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
         } else
         {
-            if (c->warp_aligned && src_shared)
+            // (with shared offsets the aligned form wins at every minification measured: config 5 -- 2.7 x, k_warp_t's unaligned territory -- 757 -> 730 / 738 -> 699 us per 16 frames;
+            //  the minification rule of build_plan still picks between k_warp_t's two forms when the frames do not share step and alignment)
+            static const int force_al = dev_knob("MS_WARP_ALIGNED", -1);
+            if ((c->warp_aligned || force_al != 0) && src_shared)
                 MS_WARP_S_LAUNCH(false, WARP_NF, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (c->warp_aligned)
                 MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
