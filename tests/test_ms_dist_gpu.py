@@ -62,6 +62,17 @@ def test_frame_parallel_ranks_deliver_the_single_gpu_frames(cuda, ranks, batch):
         assert many["dist"]["transport"] == "host" and many["share_gpu"] is True
 
 
+def test_tables_blob_broadcast_from_rank_0(cuda):
+    """--tables-from-rank0: only rank 0 calibrates; ms_save_tables -> ms_dist_broadcast -> ms_load_tables gives every other rank bit-identical tables (timed.cpp:553
+    re-runs stitch_calib at every start of every process): the frames on the sink equal those of ranks that calibrated themselves."""
+    one = run("--gpus", 1, "--frames", 16, "--batch", 4)
+    assert run("--gpus", 1, "--frames", 16, "--batch", 4, "--tables-from-rank0")["checksum_all"] == one["checksum_all"]
+    for ranks in (2, 4):
+        assert run(*multi(ranks), "--frames", 16, "--batch", 2, "--tables-from-rank0")["checksum_all"] == one["checksum_all"], ranks
+    cp = run("--gpus", 1, "--frames", 16, "--batch", 4, "--recalib-every", 8)
+    assert run(*multi(2), "--frames", 16, "--batch", 4, "--recalib-every", 8, "--tables-from-rank0")["checksum_all"] == cp["checksum_all"]
+
+
 def test_recalibration_broadcast_swaps_meshes_at_the_agreed_frame(cuda):
     """cfg3 shape: CPW on, new meshes every 8 frames from rank 0's recalibration thread, broadcast one batch ahead with the swap frame."""
     one = run("--gpus", 1, "--frames", 32, "--batch", 4, "--recalib-every", 8, "--mesh", "9x11")

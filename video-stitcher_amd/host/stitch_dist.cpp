@@ -16,7 +16,7 @@
 // checksums in display order) is what tests/test_ms_dist_gpu.py compares.
 //
 // Usage: stitch_dist [--gpus G] [--col-shards S] [--share-gpu] [--transport auto|rccl|host] [--frames T] [--batch F] [--views 6] [--size WxH]
-//                    [--out WxH] [--hfov 90] [--bands 5] [--cpw] [--recalib-every K] [--mesh NxM] [--no-checksum]
+//                    [--out WxH] [--hfov 90] [--bands 5] [--cpw] [--recalib-every K] [--mesh NxM] [--no-checksum] [--tables-from-rank0]
 // Prints one JSON line (rank 0): frames/s of the whole job, what the communicator saw (transport, nranks, devices, PCI ids), the checksums.
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -48,6 +48,7 @@ struct Options {
     double hfov = 90.0;
     bool share_gpu = false, cpw = false, checksum = true;
     bool frame_sums = false;          // --frame-sums: print every frame's checksum on stderr (diagnostic)
+    bool tables_from_rank0 = false;   // --tables-from-rank0: only rank 0 calibrates; the others build their context from its table blob (ms_save_tables -> ms_dist_broadcast -> ms_load_tables)
 };
 
 // the pattern of video-stitcher_amd/synth.py (noise off), `variant` shifts the phase so that consecutive frames differ
@@ -123,12 +124,26 @@ void rank_main(const Options &o, int rank, Shared &sh)
     c.num_bands = o.bands; c.enable_cpw = o.cpw; c.out_width = o.out_w; c.out_height = o.out_h; c.max_frames = F;
     c.col_shards = S; c.col_shard_index = shard;
     ms_ctx *ctx = nullptr;
-    MSC(ms_create(&c, &ctx));
-    ms_rig_params rp{N, o.w, o.h, o.hfov, -1.0, 0.01, -1.0};
-    ms_rig rig;
-    MSC(ms_calibrate_cameras(&rp, &rig));
-    for (int i = 0; i < N; ++i) { MSC(ms_set_camera(ctx, i, rig.K_compose[i], rig.R[i])); MSC(ms_set_gain(ctx, i, 1.0 + 0.02 * (i - (N - 1) / 2.0))); }
-    MSC(ms_build_maps(ctx, st)); MSC(ms_build_masks(ctx, 1, st)); MSC(ms_init_blender(ctx, st));
+    // the communicator comes first when the tables travel through it
+    ms_dist *dist = nullptr;
+    if (o.tables_from_rank0) MSC(ms_dist_create(&dist, rank, o.gpus, sh.id, dev));
+    if (!o.tables_from_rank0 || rank == 0) {
+        MSC(ms_create(&c, &ctx));
+        ms_rig_params rp{N, o.w, o.h, o.hfov, -1.0, 0.01, -1.0};
+        ms_rig rig;
+        MSC(ms_calibrate_cameras(&rp, &rig));
+        for (int i = 0; i < N; ++i) { MSC(ms_set_camera(ctx, i, rig.K_compose[i], rig.R[i])); MSC(ms_set_gain(ctx, i, 1.0 + 0.02 * (i - (N - 1) / 2.0))); }
+        MSC(ms_build_maps(ctx, st)); MSC(ms_build_masks(ctx, 1, st)); MSC(ms_init_blender(ctx, st));
+    }
+    if (o.tables_from_rank0) {       // timed.cpp:553 calibrates at every start; here ONE rank does and every other rank rebuilds identical tables from its blob
+        unsigned long long nbytes = 0;
+        std::vector<unsigned char> blob;
+        if (rank == 0) { size_t n = 0; MSC(ms_save_tables(ctx, nullptr, 0, &n)); blob.resize(n); MSC(ms_save_tables(ctx, blob.data(), n, &n)); nbytes = n; }
+        if (o.gpus > 1) MSC(ms_dist_broadcast(dist, &nbytes, sizeof(nbytes), 0, MS_DIST_MEM_HOST, st));
+        blob.resize((size_t)nbytes);
+        if (o.gpus > 1) MSC(ms_dist_broadcast(dist, blob.data(), blob.size(), 0, MS_DIST_MEM_HOST, st));
+        if (rank != 0) MSC(ms_load_tables(blob.data(), blob.size(), &ctx, st));
+    }
     ms_pano_geom pg;
     MSC(ms_get_pano_geom(ctx, &pg));
     int i_y0 = 0, i_rows = 0, win_b = 0, win_e = 0;
@@ -148,8 +163,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
     }
 
     // ---- the communicator ----------------------------------------------------------------------------------------------------------
-    ms_dist *dist = nullptr;
-    MSC(ms_dist_create(&dist, rank, o.gpus, sh.id, dev));
+    if (!dist) MSC(ms_dist_create(&dist, rank, o.gpus, sh.id, dev));
     ms_dist_info info;
     MSC(ms_dist_get_info(dist, &info));
 
@@ -387,10 +401,12 @@ int main(int argc, char **argv)
         else if (k == "--mesh") sscanf(next(), "%dx%d", &o.mesh_rows, &o.mesh_cols);
         else if (k == "--no-checksum") o.checksum = false;
         else if (k == "--frame-sums") o.frame_sums = true;
+        else if (k == "--tables-from-rank0") o.tables_from_rank0 = true;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "stitch_dist: no HIP device (libmsstitch has no CPU fallback)\n"); return 3; }
+    if (o.tables_from_rank0 && o.col_shards > 1) { fprintf(stderr, "stitch_dist: --tables-from-rank0 needs --col-shards 1 (a blob carries its context's column window)\n"); return 2; }
     if (o.gpus < 1 || o.gpus > MS_DIST_MAX_RANKS || o.col_shards < 1 || o.gpus % o.col_shards != 0 || o.batch < 1 || o.frames < 1) { fprintf(stderr, "stitch_dist: --gpus must be a multiple of --col-shards\n"); return 2; }
     if (!o.share_gpu && o.gpus > ndev) { fprintf(stderr, "stitch_dist: %d ranks but %d devices (use --share-gpu to put every rank on device 0 over the host transport)\n", o.gpus, ndev); return 2; }
     const long long batch_frames = (long long)(o.gpus / o.col_shards) * o.batch;
