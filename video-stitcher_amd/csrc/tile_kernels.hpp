@@ -664,6 +664,12 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
                     }
                 }
             }
+#ifdef MS_PROBE_EXTRA_VALU      // headroom probe (WRONG pixels by a hair: the extra work is folded into the result so that it cannot be dropped): N more half-rate VALU per frame
+            { unsigned e = packed[0];
+#pragma unroll
+              for (int i_ = 0; i_ < MS_PROBE_EXTRA_VALU; ++i_) e = __builtin_amdgcn_perm(e, packed[1] + i_, 0x07020500u);
+              if (e == 0x12345678u) packed[2] ^= 1u; }
+#endif
             uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)y * L.pitch + x;
             *reinterpret_cast<unsigned *>(d) = packed[0];
             *reinterpret_cast<unsigned *>(d + plane) = packed[1];
