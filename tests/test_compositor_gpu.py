@@ -532,7 +532,7 @@ def test_feather_blender_matches_oracle(ms, cuda, oracle, rig):
 
 def test_config1_cpu_flavour_remap_and_feather(ms, cuda, oracle):
     """BASELINE configs[0] as the reference's CPU pipeline computes it: spherical maps, cv::remap's fixed-point bilinear (imgwarp.cpp), gain,
-    FeatherBlender(0.02).  GPU: the reference kernels with the CPU-flavoured projection remap (ms_config.reserved[5]) + ms_init_feather."""
+    FeatherBlender(0.02).  GPU: the reference kernels with the CPU-flavoured projection remap (ms_config.cpu_flavour_remap) + ms_init_feather."""
     import math
     sc = float(np.float32(2000.0 / (2 * math.pi)))
     comp = ms.Compositor(2, (640, 480), ms.PROJ_SPHERICAL, sc, num_bands=0, out_size=(2000, 1000), simple_kernels=True, cv_remap=True)

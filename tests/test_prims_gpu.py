@@ -423,3 +423,19 @@ def test_bgr_to_gray(ms, cuda):
         assert np.array_equal(host(ms.bgr_to_gray(to_dev_roi(src, rng))), want)
     white = np.full((2, 8, 3), 255, np.uint8)
     assert (host(ms.bgr_to_gray(to_dev(white))) == 255).all()
+
+
+def test_calib_shape_touches_every_line_once(ms, cuda):
+    """ms_calib_shape (PMC calibration on the per-frame kernels' access shapes): shapes 0 / 1 only read; shape 2 writes every dword of the buffer exactly once in four 32-byte passes per line"""
+    buf = torch.full((1 << 20,), 0xAB, dtype=torch.uint8, device=cuda)
+    for shape in (0, 1):
+        ms.calib_shape(buf, shape)
+    torch.cuda.synchronize()
+    assert int((buf != 0xAB).sum()) == 0
+    ms.calib_shape(buf, 2)
+    torch.cuda.synchronize()
+    w = buf.view(torch.int32).cpu().numpy().reshape(-1, 4, 8)          # [line, quarter, dword]: value = lane index i = 8 * line + dword
+    want = (8 * np.arange(w.shape[0])[:, None, None] + np.arange(8)[None, None, :]) * np.ones((1, 4, 1), np.int64)
+    assert np.array_equal(w.astype(np.int64), want)
+    with pytest.raises(ms.MsError):
+        ms.calib_shape(buf[1:], 0)          # not 128-byte aligned
