@@ -1046,6 +1046,8 @@ def main():
                          "frac": round((traffic if traffic else kb.get(dom, 0.0)) / (kmean[dom] * 1e-3) / 8e12, 4),
                          "basis": "pmc-measured HBM bytes" if traffic else "algorithmic bytes (no PMC summary for this workload)",
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE = requests of the L2s to the fabric: Infinity-Cache hits are counted as HBM bytes (an upper bound). Since round 4 the warp / level-0 band "
+                                         "tile lists are dealt to the XCDs in chunks: 3-4 % less time for 11 % more of these bytes (125 vs 113 MB per frame) -- part of any rise of `frac` over round 3 is bytes, not speed",
                          "achieved_contract": round(achieved, 1), "frac_contract": round(achieved / 8000.0, 4),
                          "alg_bytes_per_launch": int(kb.get(dom, 0)), "mean_launch_ms": round(kmean[dom], 5),
                          "frac_of_copy_ceiling": (round(traffic / (kmean[dom] * 1e-3) / 1e12 / ceiling["copy_TBps"], 4) if (traffic and ceiling and "copy_TBps" in ceiling) else None)},

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_remap_gain(const ViewDesc *__restrict__
 
 // Gaussian level 0 of every view: (remap -> gain) or (remap through the mesh of the stage-1 image),
 // BORDER_REFLECT pad folded into the source index, planar u8 output.
-// FIX: cv::remap's CPU arithmetic for the projection remap (ms_config.reserved[5], the reference's CPU pipeline of BASELINE configs[0])
+// FIX: cv::remap's CPU arithmetic for the projection remap (ms_config.cpu_flavour_remap, the reference's CPU pipeline of BASELINE configs[0])
 template <bool CPW, bool FIX = false>
 __global__ void __launch_bounds__(256) k_warp(const ViewDesc *__restrict__ views, int n_views, SrcTable src, int src_rows, int src_cols,
                                               MeshTable mesh, const uint8_t *__restrict__ stage, long long stage_stride,
@@ -1639,7 +1639,7 @@ struct ms_ctx {
     float *mesh_stage = nullptr;       // pinned host staging of the vertex meshes
     size_t mesh_stage_floats = 0;
     int canvas_x = 0, canvas_y = 0;
-    // view sharding (ms_config.reserved[3] = shard count S, [4] = this shard's index): contiguous blocks of views per shard
+    // view sharding (ms_config.view_shards = shard count S, view_shard_index = this shard's index): contiguous blocks of views per shard
     unsigned own_mask = 0xffffffffu;
     // pano-column sharding (ms_config.col_shards / col_shard_index): the window of pano-ROI columns this context composites and the views it reads for it
     int col_begin = 0, col_end = 0;    // 0, 0 = whole panorama
@@ -3156,7 +3156,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
     } else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0) {
-        // opt-in (reserved[1] = 1 or MS_WARP_ASYNC=1): source tiles staged in LDS by asynchronous LDS-DMA, persistent waves (k_warp_a) -- bit-identical,
+        // opt-in (ms_config.warp_lds_stage = 1; MS_WARP_ASYNC=1 in a dev-knob build): source tiles staged in LDS by asynchronous LDS-DMA, persistent waves (k_warp_a) -- bit-identical,
         // measured slower than the direct gathers on config 2 (353 vs 242 us per 16 frames: at its 1.6-2.1 x minification only 54 % of the tiles' source
         // boxes fit a staging buffer and 10 waves per CU cannot hide what 20 do; profiles/r02_warp_probes.txt)
         static const bool env_on = dev_knob("MS_WARP_ASYNC", 0) != 0;
