@@ -484,7 +484,8 @@ MS_API int ms_get_mesh_maps(const ms_ctx *ctx, int view, ms_image *xmesh, ms_ima
 /* ms_stitch on the cameras' NV12 frames (APP/defs.h:10-17: the cameras deliver NV12; the capture threads run cvtColor(COLOR_YUV2BGR_NV12) per camera, networking.cpp:45-47):
  * views_nv12[f * num_views + i] = 8UC1, (src_height * 3 / 2) x src_width -- the Y plane followed by the interleaved UV plane -- every frame of a view with the same step.
  * The projection warp samples the planes itself and converts each bilinear tap with cvtColor's integer formula: bit-identical to ms_nv12_to_bgr_batch followed by
- * ms_stitch, without the BGR image (half the input bytes).  Contexts without CPW and without a per-frame resize (MS_ERR_UNSUPPORTED otherwise: convert first). */
+ * ms_stitch, without the BGR image (half the input bytes).  With CPW it is the first remap (stage 1) that samples the planes.  Frames that go through the per-frame
+ * compose-scale resize first (timed.cpp:75-85) are converted with ms_nv12_to_bgr_batch, resized and stitched from BGR. */
 MS_API int ms_stitch_nv12(ms_ctx *ctx, int n_frames, const ms_image *views_nv12, ms_image *out8u, ms_image *out16s, ms_stream stream);
 /* Encoder-ready output: the panorama as planar I420, what consume() produces with cvtColor(BGR2YUV_I420) for the encoder (APP/timed.cpp:308-316),
  * written by the level-0 band kernel itself (no 8UC3 canvas, no conversion pass: 1.5 instead of 3 + 4.5 bytes per pixel of traffic).

@@ -796,12 +796,32 @@ def test_nv12_direct_equals_convert_then_stitch(ms, cuda, rig, proj, mask_mode, 
     comp.close()
 
 
+def test_nv12_direct_with_cpw_samples_the_planes_in_stage_one(ms, cuda):
+    """CPW contexts: ms_stitch_nv12 runs the first remap (stage 1) on the NV12 planes (k_stage1_nv12) and the mesh remap on its result -- bit-identical to converting first;
+    batches of 1 and 3 frames (one- and two-frame instantiations, a short last group), a mesh beyond the stage-1 skip bound included."""
+    for amp, nf in ((6.0, 3), (40.0, 1)):
+        comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True, max_frames=nf)
+        for i in range(cfg["n"]):
+            g = comp.view_geom(i).roi
+            mx, my = synth.mesh(g.width, g.height, 9, 11, phase=0.3 * i, amp=amp)
+            comp.set_mesh(i, mx, my)
+        rng = np.random.default_rng(5)
+        nv = [[to_dev(rng.integers(0, 256, (cfg["h"] * 3 // 2, cfg["w"]), dtype=np.uint8)) for _ in range(cfg["n"])] for _ in range(nf)]
+        bgr = [[ms.nv12_to_bgr(t) for t in fr] for fr in nv]
+        pg = comp.pano_geom()
+        a16 = [torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device="cuda") for _ in range(nf)]
+        b16 = [torch.zeros_like(a16[0]) for _ in range(nf)]
+        comp.stitch(bgr, out16s=a16)
+        comp.stitch_nv12(nv, out16s=b16)
+        torch.cuda.synchronize()
+        for f in range(nf):
+            assert torch.equal(a16[f], b16[f]), (amp, f)
+        assert int(a16[0].abs().max()) > 0
+        comp.close()
+
+
 def test_nv12_direct_is_refused_where_it_does_not_apply(ms, cuda):
-    comp, cfg, _ = make_rig(ms, "mini6", enable_cpw=True)
-    for i in range(cfg["n"]):
-        g = comp.view_geom(i).roi
-        mx, my = synth.mesh(g.width, g.height, 9, 11)
-        comp.set_mesh(i, mx, my)
+    comp, cfg, _ = make_rig(ms, "mini6", simple_kernels=True)
     nv = [[to_dev(synth.nv12_frame(cfg["w"], cfg["h"], i)) for i in range(cfg["n"])]]
     with pytest.raises(ms.MsError):
         comp.stitch_nv12(nv, out8u=[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device="cuda")])

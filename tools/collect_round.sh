@@ -41,6 +41,6 @@ rm -f $PO/${TAG}_from_inputs.txt; MS_FROM_INPUTS_LOG=$PWD/$PO/${TAG}_from_inputs
 # 7. round 4: every frame of the default pass distinct (96 frame sets, 3.6 GB of source: nothing survives in the Infinity Cache) beside the 8-set pool; the NV12 ingest both ways;
 #    the instruction-rate probe
 timeout 900 python bench.py --no-cpu-baseline --no-pcie --no-live --distinct 96 > $PO/${TAG}_bench_distinct96.json 2> $PO/distinct96.err
-{ python tools/time_nv12.py 32; python tools/time_nv12.py 1; } > $PO/${TAG}_nv12.txt 2>&1
+{ python tools/time_nv12.py 32; python tools/time_nv12.py 1; python tools/time_nv12.py 32 cpw; } 2>/dev/null > $PO/${TAG}_nv12.txt
 [ -x ab/valu_probe ] && ab/valu_probe > $PO/${TAG}_valu_probe.txt 2>&1
 du -sh gpurun_out; ls $PO

@@ -16,12 +16,18 @@ import msstitch as ms      # noqa: E402
 import synth               # noqa: E402
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+CPW = len(sys.argv) > 2 and sys.argv[2] == "cpw"      # config 3: CPW on, 40 x 40 meshes (stage 1 then samples the NV12 planes)
 cfg = synth.CONFIGS["cfg2"]
-comp = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), num_bands=cfg["num_bands"], out_size=(cfg["out_w"], cfg["out_h"]), max_frames=F)
+comp = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), num_bands=cfg["num_bands"], out_size=(cfg["out_w"], cfg["out_h"]), max_frames=F,
+                     enable_cpw=CPW)
 g = synth.gains(cfg["n"])
 for i in range(cfg["n"]):
     comp.set_camera(i, *synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i)); comp.set_gain(i, g[i])
 comp.build_maps(); comp.build_masks(1); comp.init_blender()
+if CPW:
+    for i in range(cfg["n"]):
+        r = comp.view_geom(i).roi
+        comp.set_mesh(i, *synth.mesh(r.width, r.height, 40, 40, phase=0.1 * i))
 rng = np.random.default_rng(3)
 pool = [[torch.from_numpy(np.ascontiguousarray(np.roll(synth.nv12_frame(cfg["w"], cfg["h"], i), 7 * t, axis=1))).cuda() for i in range(cfg["n"])] for t in range(8)]
 nv = [pool[j % 8] for j in range(F)]
@@ -53,6 +59,6 @@ a = timed(path_a)
 b = timed(run_b)
 torch.cuda.synchronize()
 same = all(torch.equal(x, y) for x, y in zip(outa, outb))
-print(json.dumps({"frames_per_call": F, "convert_ms": round(conv, 4), "convert_then_stitch_ms": round(a, 4), "stitch_nv12_ms": round(b, 4),
+print(json.dumps({"config": "cfg3 (CPW 40x40)" if CPW else "cfg2", "frames_per_call": F, "convert_ms": round(conv, 4), "convert_then_stitch_ms": round(a, 4), "stitch_nv12_ms": round(b, 4),
                   "us_per_frame": {"convert": round(conv / F * 1e3, 2), "convert_then_stitch": round(a / F * 1e3, 2), "stitch_nv12": round(b / F * 1e3, 2)},
                   "bit_identical": bool(same)}))

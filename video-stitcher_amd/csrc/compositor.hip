@@ -3046,9 +3046,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         if (!(P.nb >= 1 && c->blend_vec[0] && c->cfg.debug_simple_kernels == 0 && S.mode == 0 && (P.out_w & 1) == 0 && P.i_rows > 0))
             return fail(MS_ERR_UNSUPPORTED, "ms_stitch_i420: needs the tiled level-0 band kernel (>= 1 band, pano width a multiple of 8, no view sharding) and an even canvas width");
     }
-    if (nv12 && !(c->cfg.enable_cpw == 0 && c->warp_tiled && c->cfg.debug_simple_kernels == 0 && c->cfg.cpu_flavour_remap == 0 && S.mode == 0 &&
+    if (nv12 && !(c->warp_tiled && c->cfg.debug_simple_kernels == 0 && c->cfg.cpu_flavour_remap == 0 && S.mode == 0 &&
                   (c->cfg.src_width & 1) == 0 && (c->cfg.src_height & 1) == 0 && c->cfg.src_width >= 4))
-        return fail(MS_ERR_UNSUPPORTED, "ms_stitch_nv12: the NV12-sampling warp covers the tiled projection warp without CPW (even frame sizes); convert with ms_nv12_to_bgr_batch otherwise");
+        return fail(MS_ERR_UNSUPPORTED, "ms_stitch_nv12: the NV12-sampling kernels cover the tiled projection warp / CPW stage 1 of even-sized frames, unsharded; convert with ms_nv12_to_bgr_batch otherwise");
+    // aligned 8-byte windows where every plane, step and the width are multiples of 4 (cameras' frames in ordinary buffers are); the unaligned 2- / 4-byte reads otherwise
+    bool nv_al = nv12 && (c->cfg.src_width & 3) == 0 && c->cfg.src_width >= 8 && dev_knob("MS_NV12_ALIGNED", 1) != 0;
+    for (int i = 0; i < F * N && nv_al; ++i) if (src.p[i]) nv_al = (((uintptr_t)src.p[i] | src.step[i]) & 3) == 0;
     MeshTable mesh{};
     const bool cpw = c->cfg.enable_cpw != 0;
     DispTable disp{};
@@ -3122,6 +3125,19 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
+        if (nv12) {        // CPW stage 1 straight from the cameras' NV12 planes (k_stage1_nv12)
+            const dim3 b_(WARP_BX, S1_BY_NV);
+#define MS_S1NV_LAUNCH(NF_, ALN_)                                                                                                                                     \
+    do {                                                                                                                                                              \
+        const dim3 g_(c->n_stage1_tiles, 1, div_up(F, NF_));                                                                                                          \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_stage1_nv12<MS_PROJ_SPHERICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+        else k_stage1_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+    } while (0)
+            if (nv_al) { if (F == 1) MS_S1NV_LAUNCH(1, true); else MS_S1NV_LAUNCH(2, true); }
+            else { if (F == 1) MS_S1NV_LAUNCH(1, false); else MS_S1NV_LAUNCH(2, false); }
+#undef MS_S1NV_LAUNCH
+        } else
         if (c->cfg.debug_simple_kernels == 0)
         {
             // frames per lane of the first CPW remap: three where the source is sampled about 1 : 1 (VALU-bound), two otherwise (see k_stage1_t)
@@ -3171,9 +3187,6 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
         else k_warp_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
     } while (0)
-            // aligned 8-byte windows where every plane, step and the width are multiples of 4 (cameras' frames in ordinary buffers are); the unaligned 2- / 4-byte reads otherwise
-            bool nv_al = (c->cfg.src_width & 3) == 0 && c->cfg.src_width >= 8 && dev_knob("MS_NV12_ALIGNED", 1) != 0;
-            for (int i = 0; i < F * N && nv_al; ++i) if (src.p[i]) nv_al = (((uintptr_t)src.p[i] | src.step[i]) & 3) == 0;
             if (nv_al) { if (F == 1) MS_NV12_LAUNCH(1, true); else MS_NV12_LAUNCH(2, true); }
             else { if (F == 1) MS_NV12_LAUNCH(1, false); else MS_NV12_LAUNCH(2, false); }
 #undef MS_NV12_LAUNCH

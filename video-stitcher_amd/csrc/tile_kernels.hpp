@@ -724,6 +724,7 @@ __device__ __forceinline__ void warp_tabs_load(const WarpTile &T, const ViewDesc
 // so the result is bit-identical to ms_nv12_to_bgr_batch + ms_stitch (tests/test_compositor_gpu.py::test_nv12_direct_*).  Per pixel and frame: two 2-byte reads
 // (Y of the two tap rows), two 4-byte reads (the UV pairs under them) -- 12 bytes instead of 24, no BGR image at all.  Offsets, weights and flags are per pixel,
 // shared by the frames of a lane (the frames of a view must share their row step: checked by the host).
+constexpr int S1_BY_NV = WARP_TH;          // lane rows of a stage-1 workgroup (= S1_BY, declared further down)
 typedef unsigned short ms_u16_a1 __attribute__((aligned(1)));
 typedef unsigned ms_u32_a2 __attribute__((aligned(2)));
 struct NvRGB { float b, g, r; };
@@ -751,18 +752,17 @@ __device__ __forceinline__ NvRGB nv12_tap_checked(ms_gptr_u8 base, unsigned st, 
 // ALN: every read an ALIGNED 8-byte window (global_load_dwordx2 at a multiple of 4) and one 64-bit shift -- an unaligned gather costs the texture-address path more than an aligned one of
 // twice the size (config 2, BGR: unaligned 8-byte tap reads 456 us, aligned 12-byte ones 375).  Needs 4-byte aligned planes, steps and widths (the host checks): then both tap rows
 // and both UV rows of a pixel share their shifts, and clamping the UV window to [row end - 8, row end) keeps the last row's reads inside the caller's buffer.
-template <int PROJ, int NF, bool ALN>
-__global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
-                                                            SrcTable src, int rows, int cols, uint8_t *__restrict__ g0, long long g0_stride,
-                                                            const float2 *__restrict__ tabs, int n_frames)
+// S1: the tile is a CPW stage-1 tile (k_stage1_t's geometry: view pixels, no reflect pad) and the result goes to the interleaved 8UC3 stage image the mesh remap samples --
+// images[i] = gain(remap(cvtColor(nv12_i), x_map, y_map)) (networking.cpp:45-47 + timed.cpp:90-94) without the BGR frame.
+template <int PROJ, int NF, bool ALN, bool S1>
+__device__ __forceinline__ void nv12_tile(const WarpTile &T, int f0, int nf, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
+                                          const SrcTable &src, int rows, int cols, uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
 {
-    const WarpTile T = tiles[blockIdx.x];
-    const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
-    const int tx = (int)threadIdx.x, ty = (int)(threadIdx.y + blockIdx.y * WARP_WY);
     const int v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * tx, y = T.y0 + ty;
-    const bool active = x < V.pw && y < V.ph;
+    const bool active = S1 ? (x < V.aw && y < V.ah) : (x < V.pw && y < V.ph);
+    if (S1 && !active) return;
     ms_gptr_u8 base[NF];
 #pragma unroll
     for (int fi = 0; fi < NF; ++fi) base[fi] = (ms_gptr_u8)(uintptr_t)src.p[(f0 + (fi < nf ? fi : 0)) * n_views + v];
@@ -772,7 +772,11 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile 
     float xc[4], yc[4];
     {
         float2 ct[4], rt;
-        warp_tabs_load(T, views, tabs, tx, ty, ct, rt);
+        if (S1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ct[k] = gload_f2(V.coltab + min(x + k, V.aw - 1));
+            rt = gload_f2(V.rowtab + y);
+        } else warp_tabs_load(T, views, tabs, tx, ty, ct, rt);
         if (active) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) warp_combine(PROJ, ct[k], rt, V.wp, xc[k], yc[k]);
@@ -835,7 +839,7 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile 
     for (int fi = 0; fi < NF; ++fi) {
         const int b = fi & 1;
         if (active && fi < nf) {
-            unsigned packed[3] = {0, 0, 0};
+            unsigned packed[3] = {0, 0, 0};      // S1: the 12 interleaved output bytes; else one dword per colour plane
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned s0 = (sel >> (2 * k)) & 1u, s1 = (sel >> (2 * k + 1)) & 1u;
@@ -862,16 +866,47 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile 
                 o[1] = fma_single(a22.g, t[k].w22, fma_single(a21.g, t[k].w21, fma_single(a12.g, t[k].w12, fma_single(a11.g, t[k].w11, 0.f))));
                 o[2] = fma_single(a22.r, t[k].w22, fma_single(a21.r, t[k].w21, fma_single(a12.r, t[k].w12, fma_single(a11.r, t[k].w11, 0.f))));
 #pragma unroll
-                for (int c = 0; c < 3; ++c) packed[c] = sat_u8_into(fma_single(gain, (float)sat_u8(o[c]), 0.f), k, packed[c]);      // convertTo(gain) of the rounded remap result (timed.cpp:94)
+                for (int c = 0; c < 3; ++c) {      // convertTo(gain) of the rounded remap result (timed.cpp:94)
+                    const int i = S1 ? 3 * k + c : 0;
+                    if (S1) packed[i >> 2] = sat_u8_into(fma_single(gain, (float)sat_u8(o[c]), 0.f), i & 3, packed[i >> 2]);
+                    else packed[c] = sat_u8_into(fma_single(gain, (float)sat_u8(o[c]), 0.f), k, packed[c]);
+                }
             }
-            uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)y * L.pitch + x;
-            *reinterpret_cast<unsigned *>(d) = packed[0];
-            *reinterpret_cast<unsigned *>(d + plane) = packed[1];
-            *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+            if (S1) {      // (g0 / g0_stride: the stage buffer and its per-frame stride)
+                uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + V.s1_off + (size_t)y * V.s1_pitch + (size_t)x * 3;   // 12 B per lane, dword aligned
+                if (x + 3 < V.aw) __builtin_memcpy(__builtin_assume_aligned(d, 4), packed, 12);
+                else {
+                    for (int k = 0; k < 4 && x + k < V.aw; ++k)
+                        for (int c = 0; c < 3; ++c) { const int i = 3 * k + c; d[i] = (uint8_t)(packed[i >> 2] >> (8 * (i & 3))); }
+                }
+            } else {
+                uint8_t *d = g0 + (size_t)(f0 + fi) * g0_stride + L.off + (size_t)y * L.pitch + x;
+                *reinterpret_cast<unsigned *>(d) = packed[0];
+                *reinterpret_cast<unsigned *>(d + plane) = packed[1];
+                *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (fi + 2 < NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }
     }
+}
+template <int PROJ, int NF, bool ALN>
+__global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_nv12(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                            SrcTable src, int rows, int cols, uint8_t *__restrict__ g0, long long g0_stride,
+                                                            const float2 *__restrict__ tabs, int n_frames)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
+    nv12_tile<PROJ, NF, ALN, false>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, rows, cols, g0, g0_stride, tabs);
+}
+template <int PROJ, int NF, bool ALN>
+__global__ void __launch_bounds__(WARP_BX * S1_BY_NV) k_stage1_nv12(const WarpTile *__restrict__ tiles, const ViewDesc *__restrict__ views, int n_views,
+                                                               SrcTable src, int rows, int cols, uint8_t *__restrict__ stage, long long stage_stride, DispTable disp, int n_frames)
+{
+    const WarpTile T = tiles[blockIdx.x];
+    if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;      // the mesh of this view moves no sample this far: stage 2 never reads this tile (k_stage1_t)
+    const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
+    nv12_tile<PROJ, NF, ALN, true>(T, f0, nf, (int)threadIdx.x, (int)threadIdx.y, views, n_views, src, rows, cols, stage, stage_stride, nullptr);
 }
 
 // ---- the same tiles with the source staged in LDS by asynchronous LDS-DMA: persistent, self-pipelined waves -------------------
