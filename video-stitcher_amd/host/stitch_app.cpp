@@ -450,7 +450,7 @@ int main(int argc, char **argv)
                     HIPCHECK(hipMemcpyAsync(full_imgs[0].data, host_slab, host_frame_bytes * o.views, hipMemcpyHostToDevice, upload_stream));
                 HIPCHECK(hipEventRecord(up_done[ib], upload_stream));
                 HIPCHECK(hipStreamWaitEvent(stitch_stream, up_done[ib], 0));
-                if (o.nv12 && !o.nv12_direct) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (the reference: per camera, on the CPU, networking.cpp:45-47).
+                if (o.nv12 && !(o.nv12_direct && !resize_in)) {             // cvtColor(YUV2BGR_NV12) of all cameras in one launch (also with --nv12-direct when the frames are resized first: the resize works on BGR) (the reference: per camera, on the CPU, networking.cpp:45-47).
                                           // On the STITCH stream (round 4): the upload stream then carries nothing but the copies, so the PCIe link -- the limit of
                                           // this path -- never waits for a kernel; the conversion (one latency-bound launch) rides in front of the frame's stitch
                     std::vector<ms_image> a(o.views), d(o.views);
@@ -461,7 +461,7 @@ int main(int argc, char **argv)
             if (resize_in) {                        // timed.cpp:75-85: cuda::resize(full_imgs[i], resized, Size(), compose_scale, compose_scale)
                 msshim::cuda::resize(full_imgs, small_imgs, cal.rig.compose_scale, cal.rig.compose_scale, (ms_stream)stitch_stream);      // all views, one launch
                 comp.stitch_one(small_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
-            } else if (o.nv12_direct)
+            } else if (o.nv12_direct)      // (resize_in is false here)
                 comp.stitch_one_nv12(nv12_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);      // the warp converts each tap itself: no BGR frames on the device at all
             else
                 comp.stitch_one(full_imgs, &s->pano8u, (DevMat *)nullptr, (ms_stream)stitch_stream);
