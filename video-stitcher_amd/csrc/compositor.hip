@@ -439,88 +439,123 @@ __global__ void __launch_bounds__(256) k_blend(const ViewDesc *__restrict__ view
 // call these launches are a third of the frame time.  Each band is computed from its views exactly as k_blend_top / k_blend do; the
 // collapsed bands above t stay in LDS (three int16 planes of the strip plus the columns pyrUp needs), only band t is stored -- it is all
 // the next (vectorised) band kernel reads.  Column ranges of a strip: band t owns [a_t, b_t); band l+1 needs [a_l/2 - 1, (b_l-1)/2 + 1].
-constexpr int BTAIL_W = 16;             // columns of band t per strip
-__host__ __device__ inline void btail_range(const int *qw, int t, int nb, int strip, int *a, int *b)
+constexpr int BTAIL_W = 16;             // columns of band t per strip (the plans' default)
+__host__ __device__ inline void btail_range(const int *qw, int t, int nb, int strip, int bw, int *a, int *b)
 {
-    a[t] = strip * BTAIL_W; b[t] = min(a[t] + BTAIL_W, qw[t]);
+    a[t] = strip * bw; b[t] = min(a[t] + bw, qw[t]);
     for (int l = t; l < nb; ++l) {
         a[l + 1] = max(a[l] / 2 - 1, 0) & ~1;
         b[l + 1] = min(((b[l] - 1) / 2 + 2 + 1) & ~1, qw[l + 1]);
     }
 }
+template <bool LIVE>      // LIVE: one or two frames per call (1024 lanes per workgroup, latency matters); otherwise the chip is full and skipped work matters
 __global__ void __launch_bounds__(1024) k_blend_tail(const ViewDesc *__restrict__ views, PanoDesc P, int t,
                                                     const uint8_t *__restrict__ gl, long long gl_stride,
-                                                    int16_t *__restrict__ cl, long long cl_stride, int strip0)
+                                                    int16_t *__restrict__ cl, long long cl_stride, int strip0, int bw)
 {
+    // Two phases.  (1) The normalised Laplacian term of EVERY band nb .. t of the strip, D_l = trunc(sum_v trunc(L_v * w_v) / den) (the coarsest: trunc(sum_v trunc(G_v * w_v) / den)),
+    // depends on the views only, not on the collapsed band below it: all bands' items are spread over the workgroup at once (one band per wave: item ranges are padded to 64, so the
+    // descriptors stay scalar), into LDS.  (2) The collapse C_l = sat(pyrUp(C_{l+1}) + D_l) runs band by band over LDS alone.  The serial chain of global round trips is that of ONE
+    // band instead of nb - t + 1 (one frame per call: 16.3 -> 11.0 us; the arithmetic and its order per pixel are unchanged).
     extern __shared__ int16_t s_c[];
+    __shared__ int s_a[MAX_LEVELS + 1], s_w[MAX_LEVELS + 1], s_off[MAX_LEVELS + 1], s_first[MAX_LEVELS + 2];
     const int nb = P.nb, f = blockIdx.z, strip = blockIdx.x + strip0, c = blockIdx.y;      // one colour plane per workgroup (strip0: first strip of a column window)
-    int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
-    btail_range(P.qw, t, nb, strip, a, b);
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x, nthr = (int)(blockDim.x * blockDim.y);      // 256 lanes per workgroup, 1024 in live mode
-    int16_t *cur = s_c, *prev = nullptr;       // cur: band l being written ((b-a) x qh), prev: band l+1
-    int prev_w = 0;
+    if (tid == 0) {
+        int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
+        btail_range(P.qw, t, nb, strip, bw, a, b);
+        int off = 0, first = 0;
+        for (int l = nb; l >= t; --l) {
+            const int lw = b[l] - a[l], lh = P.qh[l];
+            s_a[l] = a[l]; s_w[l] = lw; s_off[l] = off; s_first[l] = first;
+            off += (lw * lh + 7) & ~7;
+            first += ((l == nb ? lw * lh : (lw >> 1) * (lh >> 1)) + 63) & ~63;
+        }
+        s_first[t - 1] = first;
+    }
+    __syncthreads();
     const uint8_t *glf = gl + (size_t)f * gl_stride;
-    for (int l = nb; l >= t; --l) {
-        const int lw = b[l] - a[l], lh = P.qh[l];
+    const int total = s_first[t - 1];
+    for (int i = tid; i < total; i += nthr) {
+        const int ib = __builtin_amdgcn_readfirstlane(i);      // (a wave's 64 items belong to one band)
+        int l = nb;
+        while (l > t && ib >= s_first[l - 1]) --l;
+        l = __builtin_amdgcn_readfirstlane(l);
+        const int j = i - __builtin_amdgcn_readfirstlane(s_first[l]);
+        const int lw = __builtin_amdgcn_readfirstlane(s_w[l]), al = __builtin_amdgcn_readfirstlane(s_a[l]), lh = P.qh[l];
+        int16_t *cur = s_c + __builtin_amdgcn_readfirstlane(s_off[l]);
         if (l == nb) {
             // coarsest band: C = trunc( sum_v trunc(G * w) / den ), per pixel (view rects need not be even-aligned here)
-            for (int i = tid; i < lw * lh; i += nthr) {
-                const int y = i / lw, x = a[l] + (i - y * lw);
-                int16_t acc = 0;
-                for (int v = 0; v < P.n_views; ++v) {
-                    const LevelDesc &L = views[v].lv[l];
-                    const int lx = x - L.x_tl, ly = y - L.y_tl;
-                    if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
-                    const float w = L.wgt[(size_t)ly * L.wpitch + lx];
-                    acc = (int16_t)(acc + trunc_s16((float)(int)glf[L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx] * w));
-                }
-                const DivBy div(P.den[l][(size_t)y * P.dpitch[l] + x]);
-                cur[i] = trunc_s16(div((float)acc));
+            if (j >= lw * lh) continue;
+            const int y = j / lw, x = al + (j - y * lw);
+            const float dn = P.den[l][(size_t)y * P.dpitch[l] + x];
+            int16_t acc = 0;
+            for (int v = 0; v < P.n_views; ++v) {
+                const LevelDesc &L = views[v].lv[l];
+                const int lx = x - L.x_tl, ly = y - L.y_tl;
+                if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;
+                const float w = L.wgt[(size_t)ly * L.wpitch + lx];
+                acc = (int16_t)(acc + trunc_s16((float)(int)glf[L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx] * w));
             }
+            const DivBy div(dn);
+            cur[j] = trunc_s16(div((float)acc));
         } else {
-            // band l < nb: Laplacian of every view formed on the fly, accumulate, normalise, add pyrUp of the collapsed band l+1 (in LDS); 2x2 quads
+            // band l < nb: Laplacian of every view formed on the fly, accumulate, normalise; 2x2 quads
             const int qwl = lw >> 1, qhl = lh >> 1;
-            for (int i = tid; i < qwl * qhl; i += nthr) {
-                const int qy = i / qwl, qxl = i - qy * qwl;
-                const int x0 = a[l] + 2 * qxl, y0 = 2 * qy;
-                int16_t acc[4] = {0, 0, 0, 0};
-                for (int v = 0; v < P.n_views; ++v) {
-                    const LevelDesc &L = views[v].lv[l];
-                    const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
-                    if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;   // rects are even-aligned below level nb
-                    const LevelDesc &C = views[v].lv[l + 1];
-                    const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
-                    const float w[4] = {wp[0], wp[1], wp[L.wpitch], wp[L.wpitch + 1]};
-                    if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;     // (short)(L * 0) == 0
-                    int up[4];
-                    up_quad(glf + C.off + (size_t)c * C.h * C.pitch, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up);
-                    const uint8_t *p = glf + L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx;
-                    const int g[4] = {p[0], p[1], p[L.pitch], p[L.pitch + 1]};
+            if (j >= qwl * qhl) continue;
+            const int qy = j / qwl, qxl = j - qy * qwl;
+            const int x0 = al + 2 * qxl, y0 = 2 * qy;
+            const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
+            const float dn[4] = {dp[0], dp[1], dp[P.dpitch[l]], dp[P.dpitch[l] + 1]};
+            int16_t acc[4] = {0, 0, 0, 0};
+            for (int v = 0; v < P.n_views; ++v) {
+                const LevelDesc &L = views[v].lv[l];
+                const int lx = x0 - L.x_tl, ly = y0 - L.y_tl;
+                if (lx < 0 || ly < 0 || lx >= L.w || ly >= L.h) continue;   // rects are even-aligned below level nb
+                const LevelDesc &C = views[v].lv[l + 1];
+                const float *wp = L.wgt + (size_t)ly * L.wpitch + lx;
+                const float w[4] = {wp[0], wp[1], wp[L.wpitch], wp[L.wpitch + 1]};
+                // LIVE: no early-out on four zero weights -- the view's taps are requested together with its weights, one round trip per view ((short)(L * 0) == 0 anyway)
+                if (!LIVE && w[0] == 0.f && w[1] == 0.f && w[2] == 0.f && w[3] == 0.f) continue;
+                int up[4];
+                up_quad(glf + C.off + (size_t)c * C.h * C.pitch, C.pitch, C.h, C.w, ly >> 1, lx >> 1, up);
+                const uint8_t *p = glf + L.off + (size_t)c * L.h * L.pitch + (size_t)ly * L.pitch + lx;
+                const int g[4] = {p[0], p[1], p[L.pitch], p[L.pitch + 1]};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int lap = sat_s16(g[k] - (int)sat_s16(up[k]));
-                        acc[k] = (int16_t)(acc[k] + trunc_s16((float)lap * w[k]));
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const int lap = sat_s16(g[k] - (int)sat_s16(up[k]));
+                    acc[k] = (int16_t)(acc[k] + trunc_s16((float)lap * w[k]));
                 }
-                const float *dp = P.den[l] + (size_t)y0 * P.dpitch[l] + x0;
-                const DivBy div[4] = {DivBy(dp[0]), DivBy(dp[1]), DivBy(dp[P.dpitch[l]]), DivBy(dp[P.dpitch[l] + 1])};
-                int up[4], res[4];
-                // prev holds columns [a[l+1], b[l+1]) of band l+1: index with the global column (clamped to the band by pu_idx) minus a[l+1]
-                up_quad(prev - a[l + 1], prev_w, P.qh[l + 1], P.qw[l + 1], qy, x0 >> 1, up);
+            }
+            const DivBy div[4] = {DivBy(dn[0]), DivBy(dn[1]), DivBy(dn[2]), DivBy(dn[3])};
+            int16_t *d = cur + (size_t)y0 * lw + 2 * qxl;
+            d[0] = trunc_s16(div[0]((float)acc[0])); d[1] = trunc_s16(div[1]((float)acc[1]));
+            d[lw] = trunc_s16(div[2]((float)acc[2])); d[lw + 1] = trunc_s16(div[3]((float)acc[3]));
+        }
+    }
+    __syncthreads();
+    for (int l = nb - 1; l >= t; --l) {
+        const int lw = s_w[l], al = s_a[l], lh = P.qh[l], qwl = lw >> 1, qhl = lh >> 1;
+        int16_t *cur = s_c + s_off[l];
+        const int16_t *prev = s_c + s_off[l + 1];       // columns [a[l+1], b[l+1]) of the collapsed band l+1: index with the global column (clamped to the band by pu_idx) minus a[l+1]
+        const int prev_w = s_w[l + 1], ap = s_a[l + 1];
+        for (int i = tid; i < qwl * qhl; i += nthr) {
+            const int qy = i / qwl, qxl = i - qy * qwl;
+            const int x0 = al + 2 * qxl, y0 = 2 * qy;
+            int up[4], res[4];
+            up_quad(prev - ap, prev_w, P.qh[l + 1], P.qw[l + 1], qy, x0 >> 1, up);
+            int16_t *d = cur + (size_t)y0 * lw + 2 * qxl;
+            const int dd[4] = {d[0], d[1], d[lw], d[lw + 1]};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) res[k] = sat_s16((int)sat_s16(up[k]) + (int)trunc_s16(div[k]((float)acc[k])));
-                if (l == t) {
-                    int16_t *d = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)c * P.qh[l] * P.qpitch[l] + (size_t)y0 * P.qpitch[l] + x0;
-                    d[0] = (int16_t)res[0]; d[1] = (int16_t)res[1]; d[P.qpitch[l]] = (int16_t)res[2]; d[P.qpitch[l] + 1] = (int16_t)res[3];
-                } else {
-                    int16_t *d = cur + (size_t)y0 * lw + 2 * qxl;
-                    d[0] = (int16_t)res[0]; d[1] = (int16_t)res[1]; d[lw] = (int16_t)res[2]; d[lw + 1] = (int16_t)res[3];
-                }
+            for (int k = 0; k < 4; ++k) res[k] = sat_s16((int)sat_s16(up[k]) + dd[k]);
+            if (l == t) {
+                int16_t *o = cl + (size_t)f * cl_stride + P.coff[l] + (size_t)c * P.qh[l] * P.qpitch[l] + (size_t)y0 * P.qpitch[l] + x0;
+                o[0] = (int16_t)res[0]; o[1] = (int16_t)res[1]; o[P.qpitch[l]] = (int16_t)res[2]; o[P.qpitch[l] + 1] = (int16_t)res[3];
+            } else {
+                d[0] = (int16_t)res[0]; d[1] = (int16_t)res[1]; d[lw] = (int16_t)res[2]; d[lw + 1] = (int16_t)res[3];
             }
         }
         __syncthreads();
-        prev = cur; prev_w = lw;
-        cur = cur + (((size_t)lw * lh + 7) & ~(size_t)7);
     }
 }
 
@@ -2426,7 +2461,7 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     {   // fused coarse band chain: from the first band the vectorised kernel cannot take up to the coarsest one
         int t = 0;
         while (t < nb && c->blend_vec[t]) ++t;
-        auto plan_btail = [&](int tt, int *out_t, int *out_lds, int *out_strips) {
+        auto plan_btail = [&](int tt, int bw, int *out_t, int *out_lds, int *out_strips) {
             *out_t = -1; *out_lds = 0; *out_strips = 0;
             bool ok = tt >= 1 && tt < nb && c->cfg.debug_simple_kernels == 0;
             for (int l = tt; ok && l < nb; ++l) {          // quads: even band sizes and even-aligned view rects below the coarsest band
@@ -2437,19 +2472,19 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
                 }
             }
             if (!ok) return;
-            const int strips = div_up(P.qw[tt], BTAIL_W);
+            const int strips = div_up(P.qw[tt], bw);
             size_t need = 0;
             for (int sidx = 0; sidx < strips; ++sidx) {
                 int a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
-                btail_range(P.qw, tt, nb, sidx, a, b);
+                btail_range(P.qw, tt, nb, sidx, bw, a, b);
                 size_t bytes = 0;
-                for (int l = tt + 1; l <= nb; ++l) bytes += ((size_t)(b[l] - a[l]) * P.qh[l] + 7) / 8 * 8 * sizeof(int16_t);
+                for (int l = tt; l <= nb; ++l) bytes += ((size_t)(b[l] - a[l]) * P.qh[l] + 7) / 8 * 8 * sizeof(int16_t);      // every band of the strip, band tt included (its D term waits in LDS for the collapse)
                 need = std::max(need, bytes);
             }
             if (need <= 60 * 1024) { *out_t = tt; *out_lds = (int)need + 64; *out_strips = strips; }
         };
-        plan_btail(t, &c->btail_t, &c->btail_lds, &c->btail_strips);
-        plan_btail(t - 1, &c->btail2_t, &c->btail2_lds, &c->btail2_strips);
+        plan_btail(t, BTAIL_W, &c->btail_t, &c->btail_lds, &c->btail_strips);
+        plan_btail(t - 1, BTAIL_W, &c->btail2_t, &c->btail2_lds, &c->btail2_strips);
     }
 
     // ---- init_gpu per view, in view order: weight = mask/255 -> constant border -> nb x pyrDown,
@@ -3086,7 +3121,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     // thrash the vector cache less (same-box sweep, us per 16 frames: 5 waves 215, 4 waves 207, 3 waves 214; profiles/r03_resize_ab.txt).  The unaligned variant
     // (config 5, 61 VGPRs) and the mesh remap (98 VGPRs = 4 waves anyway) are best left alone.  MS_WARP_LDS=<bytes> overrides all three (A/B).
     static const int warp_lds_env = dev_knob("MS_WARP_LDS", -1);
-    const size_t warp_lds = warp_lds_env >= 0 ? (size_t)warp_lds_env : 0, warp_lds_al = warp_lds_env >= 0 ? (size_t)warp_lds_env : 20000;
+    const size_t warp_lds = warp_lds_env >= 0 ? (size_t)warp_lds_env : 0, warp_lds_al = warp_lds_env >= 0 ? (size_t)warp_lds_env : (F <= 2 ? 0 : 20000);      // (one or two frames per call: the chip is not full, every wave that fits helps -- 92.5 -> 91.2 us per frame)
     // k_warp_s / the shared form of k_stage1_t: every frame of a view with the same row step and the same address modulo 4 (then a pixel's aligned tap offset is one
     // 32-bit value for all frames of a lane).  True for any sane caller (frames of one camera in buffers of one shape); checked, not assumed.
     static const bool warp_shared_knob = dev_knob("MS_WARP_SHARED", 1) != 0;
@@ -3265,17 +3300,18 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     int l_first = nb - 1;
     static const bool bt2_off = dev_knob("MS_LIVE_TAIL", 1) == 0;
     const bool bt2 = F <= 2 && c->btail2_t >= 0 && !bt2_off;      // live mode (1-2 frames per call): launches dominate, the band tail starts one band finer
-    const int bt_t = bt2 ? c->btail2_t : c->btail_t, bt_lds = bt2 ? c->btail2_lds : c->btail_lds, bt_strips = bt2 ? c->btail2_strips : c->btail_strips;
+    const int bt_t = bt2 ? c->btail2_t : c->btail_t, bt_lds = bt2 ? c->btail2_lds : c->btail_lds, bt_strips = bt2 ? c->btail2_strips : c->btail_strips, bt_w = BTAIL_W;
     if (S.mode == 0 && bt_t >= 0) {      // bands nb .. bt_t in one launch
         int s0 = 0, s1 = bt_strips;
         if (c->col_end > c->col_begin) {      // column sharding: only the strips of band bt_t that hold a column the window depends on
             int ra = c->col_begin, rb = c->col_end;
             for (int l = 0; l < bt_t; ++l) { ra = std::max(ra / 2 - 1, 0); rb = std::min((rb + 1) / 2 + 1, P.qw[l + 1]); }
-            s0 = std::min(ra / BTAIL_W, bt_strips - 1); s1 = std::max(std::min(div_up(rb, BTAIL_W), bt_strips), s0 + 1);
+            s0 = std::min(ra / bt_w, bt_strips - 1); s1 = std::max(std::min(div_up(rb, bt_w), bt_strips), s0 + 1);
         }
         static const int bt_rows = dev_knob("MS_BTAIL_ROWS", 0);      // (A/B: lane rows per workgroup)
         const dim3 bt_blk(64, bt_rows > 0 ? bt_rows : (F <= 2 ? 16 : 4));      // live mode: a strip's few hundred quads per band on 1024 lanes instead of 256 -- fewer serial rounds
-        k_blend_tail<<<dim3(s1 - s0, 3, F), bt_blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0);
+        if (F <= 2) k_blend_tail<true><<<dim3(s1 - s0, 3, F), bt_blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0, bt_w);
+        else        k_blend_tail<false><<<dim3(s1 - s0, 3, F), bt_blk, bt_lds, st>>>(vt, P, bt_t, gl, c->gl_stride, cl, c->cl_stride, s0, bt_w);
         MS_LAUNCH_CHECK();
         if (int e = mark("k_blend_tail")) return e;
         l_first = bt_t - 1;
