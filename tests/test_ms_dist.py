@@ -166,3 +166,26 @@ def test_argument_errors():
         assert d.mesh_exchange(0, None, 1, 2, 2) is None
     finally:
         d.close()
+
+
+def test_host_transport_under_tsan(tmp_path):
+    """csrc/dist.cpp instrumented with ThreadSanitizer, one thread per rank (tests/dist_tsan_check.cpp): groups with two messages per peer and
+    direction, rotating broadcasts, barriers and the mesh exchange -- any data race reported by TSan fails the run ("run host tests under TSan")"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "dist_tsan")
+    lib = os.path.join(ROOT, "video-stitcher_amd")
+    cmd = [hipcc, "-x", "hip", "--offload-host-only", "--offload-arch=gfx950", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fPIE", "-Wno-unused-result", "-Wno-option-ignored",
+           os.path.join(ROOT, "tests", "dist_tsan_check.cpp"), os.path.join(lib, "csrc", "dist.cpp"), "-L" + lib, "-lmsstitch", "-Wl,-rpath," + lib, "-ldl", "-lrt", "-pthread", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "tsan" in (r.stderr or "").lower():
+        pytest.skip("no ThreadSanitizer runtime in this toolchain: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert int(subprocess.run("nm %s | grep -c __tsan" % exe, shell=True, capture_output=True, text=True).stdout or 0) > 0, "not instrumented"
+    for world, iters in ((2, 60), (3, 60), (4, 100)):
+        r = subprocess.run([exe, str(world), str(iters)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (world, r.returncode, r.stderr[-3000:])
+        assert ("ok: %d ranks x %d iterations" % (world, iters)) in r.stdout

@@ -1634,7 +1634,8 @@ struct ms_ctx {
     bool tab_wait = false;
     DevBuf mask_tmp, wm_scratch;       // re-warped mask / float weight map of the largest view
     size_t w_total = 0, wm0_total = 0, den_total = 0, pure_total = 0, pure_off[MAX_LEVELS] = {};
-    bool l0_integer_only = false;      // level 0 has an owner map without a single general cell (binary, exclusive seam masks): k_blend8's integer-only build (88 VGPRs) runs it;
+    std::atomic<bool> l0_integer_only{false};      // (atomic: launch_owner_maps clears it from the mask-update thread outside mesh_mu while ms_stitch reads it -- found by the ThreadSanitizer run of stitch_app --update-mask)
+                                                   // level 0 has an owner map without a single general cell (binary, exclusive seam masks): k_blend8's integer-only build (88 VGPRs) runs it;
                                        // counted when build_plan makes the map, dropped by the first enqueue-only mask update (whose maps the host never sees)
     bool use_eff[MAX_VIEWS] = {};
     DevBuf pure_maps;                  // owner maps of the bands (PanoDesc::pure)
@@ -3131,7 +3132,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     bool src_steps_equal = warp_shared_knob && S.mode != 2;
     for (int i = N; i < F * N && src_steps_equal; ++i)
         if (src.p[i]) src_steps_equal = src.p[i % N] && src.step[i] == src.step[i % N];
-    const bool int_only = c->l0_integer_only && P.pure[0] != nullptr;      // (read under mesh_mu, like the table pointers: an enqueue-only mask update clears it)
+    const bool int_only = c->l0_integer_only.load() && P.pure[0] != nullptr;      // (an enqueue-only mask update clears it before it publishes its tables under mesh_mu: a stale `true` can only meet the old tables)
 
     // one context has ONE set of per-batch intermediates: calls on a different stream than the previous one are ordered behind it on the GPU
     // (the reference makes a fresh cuda::Stream per stitch_online call, timed.cpp:64, and relies on the NULL stream for ordering)
