@@ -42,7 +42,7 @@ def test_single_gpu_line_has_the_contract_keys():
     assert "vs_contract_model" in fr and "wall_vs_contract_model" in fr and "frac" not in fr and "wall_frac" not in fr      # the > 1 model figures are not called fractions
     assert d["config"]["distinct_frame_sets"] == 8 and d["pcie_inclusive_fps"].get("nv12_direct_value", 0) > 100
     c = d["ceiling"]      # the tuned streaming copy / read of this run: the measured ceiling the fractions are read against
-    assert c["copy_TBps"] > 4.0 and c["read_TBps"] > c["copy_TBps"] * 0.9
+    assert c["copy_TBps"] > 3.0 and c["read_TBps"] > c["copy_TBps"] * 0.8
 
 
 def test_shipped_configuration_line():
