@@ -13,6 +13,9 @@ Observed on MI355X (profiles/r03_from_inputs.txt; MS_FROM_INPUTS_LOG=<file> appe
   config 2 (6 x 1080p -> 3840 x 1920, spherical, 5 bands) max |diff| 3 on 1 px, 2 on 294, 1 on 11 091 of 2.31 M  maps within 4.9e-4 px inside the image
   shipped rig at 480 x 270 (cylindrical, 4 bands)         max |diff| 2 on 4 px, 1 on 419 of 390 k; gains equal to 4 digits
   shipped rig at 1080p (1578 x 887 compose, 6 bands)      max |diff| 3 on 1 px, 2 on 58, 1 on 3 960 of 4.2 M; gains equal to 4 digits
+  configs[4] geometry (12 x 4K -> 7680 x 3840, 5 bands)   result mask identical, 95 border pixels of view masks flip (maps within 9.8e-4 px); away from them max |diff| 3,
+                                                          99.16 % of 5.8 M px bit-equal (round 4, profiles/r04_from_inputs.txt)
+  config 3 shape (config 2 + CPW 40 x 40, both remaps)    masks identical, max |diff| 2 on 144 px, 1 on 9 119 of 2.31 M (round 4)
 """
 import os
 
@@ -42,8 +45,8 @@ def record(name, stats):
             f.write(json.dumps({"case": name, **stats}) + "\n")
 
 
-def oracle_from_inputs(O, proj, Ks, Rs, scale, w, h, frames, gains, num_bands, masks=None):
-    """stitch_calib + stitch_one entirely in the oracle, from the camera parameters"""
+def oracle_from_inputs(O, proj, Ks, Rs, scale, w, h, frames, gains, num_bands, masks=None, meshes=None):
+    """stitch_calib + stitch_one entirely in the oracle, from the camera parameters (meshes: per view the N x M vertex meshes of the CPW, expanded by the oracle's convertMeshesToMap)"""
     n = len(Ks)
     rois = [O.warp_roi(proj, Ks[i], Rs[i], scale, w, h) for i in range(n)]
     maps = [O.build_warp_maps(proj, r[0], r[1], r[3], r[2], O.k_rinv_gpu(Ks[i], Rs[i]), scale) for i, r in enumerate(rois)]
@@ -54,7 +57,11 @@ def oracle_from_inputs(O, proj, Ks, Rs, scale, w, h, frames, gains, num_bands, m
     for i in range(n):
         b.init_view(i, masks[i])
     for i in range(n):
-        b.stitch_online(i, frames[i], maps[i][0], maps[i][1], gains[i])
+        if meshes is None:
+            b.stitch_online(i, frames[i], maps[i][0], maps[i][1], gains[i])
+        else:
+            mx, my = O.convert_mesh_to_map(meshes[i][0], meshes[i][1], rois[i][2], rois[i][3])
+            b.stitch_online(i, frames[i], maps[i][0], maps[i][1], gains[i], mx, my)
     out, mask = b.blend()
     b.close()
     return rois, maps, masks, out, mask
@@ -93,9 +100,9 @@ def view_mask_diff_in_pano(rois, pano_roi, masks_a, masks_b):
     return out
 
 
-@pytest.mark.parametrize("rig", ["mini6", "cfg2"])
+@pytest.mark.parametrize("rig", ["mini6", "cfg2", "cfg5"])
 def test_spherical_rig_from_camera_parameters(ms, cuda, oracle, rig):
-    """BASELINE configs[1] (and its small twin): K, R, frames, fixed gains -> panorama; device maps + device Voronoi vs the oracle's own."""
+    """BASELINE configs[1] (and its small twin) and the configs[4] geometry (12 x 4K -> 7680 x 3840 on one GPU): K, R, frames, fixed gains -> panorama; device maps + device Voronoi vs the oracle's own."""
     cfg = synth.CONFIGS[rig]
     n, w, h, nb = cfg["n"], cfg["w"], cfg["h"], cfg["num_bands"]
     scale = synth.warp_scale(cfg["out_w"])
@@ -119,9 +126,42 @@ def test_spherical_rig_from_camera_parameters(ms, cuda, oracle, rig):
         for g, r_ in ((gx, maps[i][0]), (gy, maps[i][1])):
             worst = max(worst, float(np.abs(g - r_)[inside].max()))
     # device sinf / cosf against glibc's: a few ulp of the coordinate -- 1e-3 px on the small rigs, 2e-3 px (16 ulp at x ~ 1900) at 1080p
-    assert worst < (1e-3 if w <= 640 else 2.5e-3), worst
+    assert worst < (1e-3 if w <= 640 else 2.5e-3 if w <= 1920 else 6e-3), worst      # (4K: 16 ulp at x ~ 3800)
     vdiff = view_mask_diff_in_pano(rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
-    compare(rig + "_spherical", host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb, extra={"max_map_diff_px": worst})
+    # 12 x 4K: 49 k border pixels of the valid-warp masks, map coordinates within 1e-3 px of the oracle's: a few dozen of them round to the other side of an image edge
+    # (95 observed), and the 96-px blend support around each is excluded from the |diff| <= 3 criterion -- 2.2 % of the panorama there, nothing on the 1080p rigs
+    compare(rig + "_spherical", host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb, extra={"max_map_diff_px": worst},
+            max_excluded=0.04 if rig == "cfg5" else 0.02)
+    comp.close()
+
+
+@pytest.mark.parametrize("rig,nm", [("mini6", (10, 10)), ("cfg2", (40, 40))])
+def test_spherical_rig_with_cpw_from_camera_parameters(ms, cuda, oracle, rig, nm):
+    """BASELINE configs[2] (config 2 + CPW 40 x 40 meshes; and the small twin with the reference's 10 x 10): the frames go through BOTH remaps
+    (timed.cpp:90-104) -- projection maps from K, R and mesh maps from the vertex meshes, each built by the oracle itself -- before the blender."""
+    cfg = synth.CONFIGS[rig]
+    n, w, h, nb = cfg["n"], cfg["w"], cfg["h"], cfg["num_bands"]
+    scale = synth.warp_scale(cfg["out_w"])
+    cams = [synth.camera(n, w, h, cfg["hfov_deg"], i) for i in range(n)]
+    gains = synth.gains(n)
+    frames = [synth.frame(w, h, i, 5) for i in range(n)]
+    comp = ms.Compositor(n, (w, h), ms.PROJ_SPHERICAL, scale, num_bands=nb, enable_cpw=True, out_size=(cfg["out_w"], cfg["out_h"]))
+    for i in range(n):
+        comp.set_camera(i, *cams[i]); comp.set_gain(i, gains[i])
+    comp.build_maps(); comp.build_masks(1); comp.init_blender()
+    meshes = []
+    for i in range(n):
+        r = comp.view_geom(i).roi
+        meshes.append(synth.mesh(r.width, r.height, nm[0], nm[1], phase=0.1 * i))
+        comp.set_mesh(i, *meshes[i])
+    pg = comp.pano_geom()
+    out16 = torch.zeros((pg.dst_roi_final.height, pg.dst_roi_final.width, 3), dtype=torch.int16, device=cuda)
+    comp.stitch([[to_dev(f) for f in frames]], out16s=[out16])
+    torch.cuda.synchronize()
+    rois, maps, masks, ref16, ref_mask = oracle_from_inputs(oracle, ms.PROJ_SPHERICAL, [c[0] for c in cams], [c[1] for c in cams], scale, w, h, frames, gains, nb, meshes=meshes)
+    assert rois == [comp.view_geom(i).roi.tuple() for i in range(n)]
+    vdiff = view_mask_diff_in_pano(rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
+    compare(rig + "_spherical_cpw_%dx%d" % nm, host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb)
     comp.close()
 
 
