@@ -53,7 +53,11 @@ def kernel_bytes(comp, cfg, n_frames, cpw):
     kb = {}
     kb["k_warp"] = cfg["n"] * 3.0 * cfg["w"] * cfg["h"] + 6.0 * sumP
     if cpw:
-        kb["k_remap_gain"] = 6.0 * A           # second gather: 3 B read + 3 B write per warped pixel
+        # "+ second gather (3 B read + 3 B write) x A".  The FIRST remap (timed as `k_remap_gain`: projection remap + gain into the 8UC3 stage image) reads the
+        # source frames and writes 3 B per warped pixel; the SECOND (timed as `k_warp`: the mesh remap writing level 0) reads those 3 B and writes the 16SC3 level 0.  Same
+        # frame total as before; round 4 priced the whole second gather against the first kernel.
+        kb["k_remap_gain"] = cfg["n"] * 3.0 * cfg["w"] * cfg["h"] + 3.0 * A
+        kb["k_warp"] = 3.0 * A + 6.0 * sumP
     for l in range(nb):
         kb["k_down_l%d" % l] = 6.0 * sumP / 4 ** l + 6.0 * sumP / 4 ** (l + 1)
     for l in range(nb + 1):
@@ -477,7 +481,7 @@ def main():
     ap.add_argument("--no-live", action="store_true", help="skip the one-frame-per-call latency measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive run of the C++ host pipeline (stitch_app)")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--gather-every", type=int, default=1, help="N>1: the main timed region gathers the slabs of every k-th pass (default 1: EVERY frame of every rank reaches "
+    ap.add_argument("--gather-every", type=int, default=0, help="N>1: the main timed region gathers the slabs of every k-th pass (default 0: the live rate, about 30 batches per second and rank; 1: EVERY frame of every rank reaches "
                     "the sink inside the timed region -- the conservative `value`; `value_live_rate_gather` and `value_no_gather` are measured beside it)")
     ap.add_argument("--frames", type=int, default=None, help="frames per pass, split evenly over --streams contexts (default 96 = 3 x 32; cfg3 / shipped: 32 on one context; cfg5: 48 = 3 x 16; 1 = live mode)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5", "shipped"],
@@ -488,6 +492,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frame sets cycled through the batch (SURVEY 8(d): 8 = 298 MB of source; 96 = every frame of the "
                                                              "default pass distinct, 3.6 GB: nothing of the source survives in the 256 MiB Infinity Cache between passes; 1 = cache-resident A/B)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-distinct", action="store_true", help="skip the second short timed region in which every frame of the pass is a distinct frame set (`value_distinct`)")
     ap.add_argument("--egress-convert", action="store_true", help="N>1 egress as 8UC3 canvas + ms_bgr_to_i420_batch instead of ms_stitch_i420 (A/B)")
     ap.add_argument("--emulate-gather", action="store_true", help="single GPU: run the per-frame egress conversion of the N>1 path without the collective (host/GPU cost of that leg)")
     ap.add_argument("--gather-format", default="i420", choices=["i420", "bgr"],
@@ -524,8 +529,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # typed as `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, the launcher the contract names), pass their
+            # output through -- rank 0 prints the one JSON line -- and return their exit code
+            import socket
+            import subprocess
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: libmsstitch has no CPU fallback"
     # MS_BENCH_SHARE_GPU=1 is a DEBUG mode for 1-GPU boxes: every rank uses cuda:0 and the process group is gloo (pano slabs
@@ -550,16 +564,23 @@ def main():
     # The data path of N > 1 (the gather of the finished slabs on rank 0) goes through the product's own multi-GPU layer, ms_dist (csrc/dist.cpp: RCCL
     # send / recv over xGMI; the host mailbox when MS_BENCH_SHARE_GPU puts every rank on one device).  torch.distributed stays for what the bench contract
     # prescribes around the timed region (barrier, max over ranks) and to hand the communicator's id to the ranks.
-    D, dist_info = None, None
-    if world > 1:
+    dd = {"D": None, "info": None}      # the ms_dist communicator comes up AFTER the compute-only region (bring_up_dist below): whatever the transport does, that number exists
+
+    def bring_up_dist():
         import msdist
+        # MS_BENCH_RCCL_LIB: ms_dist_set_rccl_library (tests put the loopback implementation of tests/fake_rccl.cpp there: the RCCL branch of csrc/dist.cpp
+        # with N > 1 ranks on a one-GPU box); with it MS_BENCH_SHARE_GPU keeps gloo for torch.distributed but ms_dist takes the RCCL transport
+        transport = msdist.HOST if share else msdist.RCCL
+        if os.environ.get("MS_BENCH_RCCL_LIB"):
+            msdist.set_rccl_library(os.environ["MS_BENCH_RCCL_LIB"])
+            transport = msdist.RCCL
         # The bring-up is decided by ALL ranks together: rank 0's id (or its failure) is broadcast, and after the collective creation the ranks agree (MIN over a flag)
         # on whether every one of them has a communicator -- a rank that fell back alone would wait for ever in the first gather.
-        why = None
+        D, dist_info, why = None, None, None
         box = [None]
         if rank == 0:
             try:
-                box = [msdist.unique_id(world, msdist.HOST if share else msdist.RCCL)]
+                box = [msdist.unique_id(world, transport)]
             except Exception as e:
                 why = str(e)[:160]
         dist.broadcast_object_list(box, src=0)
@@ -575,6 +596,7 @@ def main():
             if D is not None:
                 D.close()
             D, dist_info = None, {"transport": "torch.distributed (ms_dist did not come up on every rank: %s)" % (why or "another rank failed")}
+        dd["D"], dd["info"] = D, dist_info
 
     shipped = args.config == "shipped"
     cpw = args.config in ("cfg3", "shipped")
@@ -711,7 +733,7 @@ def main():
     runs = [make_run(b) for b in range(2)]
     gl = [[torch.empty_like(slabs[0]) for _ in range(world)] for _ in range(2)] if (gather and rank == 0) else [None, None]
     pending = [None, None]
-    comm_stream = torch.cuda.Stream(device=dev) if (gather and D is not None) else None      # the sends / receives overlap the next pass's kernels
+    comm_stream = torch.cuda.Stream(device=dev) if gather else None      # the sends / receives overlap the next pass's kernels
     comm_done = [None, None]
     y0 = pg.canvas_y
 
@@ -722,7 +744,7 @@ def main():
                               for i in range(cfg["n"])])
     recal = {"frames": 0, "count": 0}
 
-    state = {"pass": 0, "gather_every": max(1, args.gather_every), "gather_on": True, "last_b": 0, "gathered": 0}
+    state = {"pass": 0, "gather_every": max(1, args.gather_every), "gather_on": True, "last_b": 0, "gathered": 0, "last_gather_b": None}
 
     def step(s):
         for _ in range(args.passes):
@@ -755,12 +777,12 @@ def main():
                     slabs[b][j].copy_(outs[b][j][y0:y0 + fh], non_blocking=True)
             if not do_gather:
                 pass
-            elif D is not None:      # ms_dist: one grouped exchange, G - 1 point-to-point transfers into the sink (RCCL: enqueued; host mailbox: blocking)
+            elif dd["D"] is not None:      # ms_dist: one grouped exchange, G - 1 point-to-point transfers into the sink (RCCL: enqueued; host mailbox: blocking)
                 if to_i420:
                     torch.cuda.current_stream().wait_event(egress_done[b])
                 comm_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(comm_stream):
-                    D.gather_slabs(slabs[b], gl[b], sink=0)
+                    dd["D"].gather_slabs(slabs[b], gl[b], sink=0)
                     comm_done[b] = torch.cuda.Event(); comm_done[b].record(comm_stream)
             elif share:
                 if to_i420:
@@ -772,6 +794,7 @@ def main():
                 pending[b], _ = df.gather_slabs(slabs[b], rank, world, dst=0, async_op=True, out=gl[b])
             if do_gather:
                 state["gathered"] += 1
+                state["last_gather_b"] = b
 
     def drain():
         for b in range(2):
@@ -804,21 +827,62 @@ def main():
             el = float(t.item())
         return el, state["gathered"] - g0_
 
-    # N > 1: `value` is the CONSERVATIVE rate -- every frame of every rank delivered to the sink inside the timed region (what the sink's inbound xGMI links
-    # bound at benchmark rate).  Beside it: the compute-only rate (no collective) and the rate with a live-rate egress (about 30 batches per second and rank:
-    # BASELINE configs[3] is a 30 fps stream, whose gather leaves the links idle).  --gather-every k > 1 makes the main region gather every k-th pass instead.
-    no_gather, live_gather = None, None
+    # N > 1 (BASELINE configs[3]: a live-rate stream, frame-parallel over G GPUs, the finished equirect frames gathered on one GPU): three timed regions.
+    #   1. compute only (no collective) -- BEFORE the ms_dist communicator exists, so this number survives whatever the transport does;
+    #   2. the MAIN region = `value`: exactly K steps, every frame stitched, and the egress of a live stream: the slabs of about 30 batches per second and
+    #      rank travel to the sink (configs[3] asks for ONE 30 fps stream: this is ~100x its bytes and still leaves the links idle) -- `--gather-every k`
+    #      (k >= 1) makes the main region gather every k-th pass instead;
+    #   3. `value_full_gather`: every frame of every rank delivered to the ONE sink at benchmark rate -- bound by that GPU's inbound xGMI links
+    #      (7 x ~55 GB/s ~ 100 k frames/s of 3.6 MB slabs), not by the compositor; reported beside `value`, never instead of it.
+    # A watchdog covers 2 and 3: a transport that hangs (first real multi-GPU run: RCCL has never seen N > 1 here) costs the missing numbers, not the line.
+    no_gather, full_gather, dist_incomplete = None, None, None
+    watchdog = {"deadline": None, "stage": None, "partial": None}
     if gather:
         state["gather_on"] = False
         el_ng, _ = timed_region(max(1, args.steps // 2), args.warmup)
         no_gather = world * F * args.passes * max(1, args.steps // 2) / el_ng
         state["gather_on"] = True
-        keep = state["gather_every"]
-        state["gather_every"] = max(1, int(round(no_gather / world / 30.0 / F)))
-        el_lv, n_lv = timed_region(max(1, args.steps // 2), max(1, args.warmup // 2))
-        live_gather = (world * F * args.passes * max(1, args.steps // 2) / el_lv, state["gather_every"], n_lv)
-        state["gather_every"] = keep
+        import threading
+
+        def minimal_line(note):
+            v = watchdog["partial"] if watchdog["partial"] else (no_gather, None)
+            return {"metric": "stitched frames/sec, 6x1080p->4K equirect (ms/frame = 1000/value*n_gpus)", "value": round(v[0], 2), "unit": "frames/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": (round(v[1] / args.steps * 1e3, 4) if v[1] else None), "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / int16+fp32 pyramid arithmetic", "data": "synthetic",
+                    "config": {"workload": "%s, frame-parallel x%d" % (args.config, world), "frames_per_pass": F, "passes_per_step": args.passes},
+                    "value_no_gather": round(no_gather, 2), "incomplete": note, "dist": dd["info"]}
+
+        def watch():
+            while True:
+                time.sleep(1.0)
+                dl = watchdog["deadline"]
+                if dl is None:
+                    return
+                if time.time() > dl:
+                    if rank == 0:
+                        print(json.dumps(minimal_line("the multi-GPU transport did not finish '%s' within its deadline: `value` is %s; the process was ended by the bench's watchdog"
+                                                      % (watchdog["stage"], "the main region's (live-rate egress)" if watchdog["partial"] else "the COMPUTE-ONLY rate (no frame left its GPU)"))), flush=True)
+                    os._exit(0)
+        watchdog["deadline"] = time.time() + float(os.environ.get("MS_BENCH_WATCHDOG_S", "300"))
+        watchdog["stage"] = "communicator bring-up"
+        threading.Thread(target=watch, daemon=True).start()
+        bring_up_dist()
+        watchdog["stage"] = "main region (live-rate egress)"
+        if args.gather_every <= 0:
+            state["gather_every"] = max(1, int(round(no_gather / world / 30.0 / F)))
     elapsed, n_gathered = timed_region(args.steps, args.warmup)
+    if gather:
+        main_every = state["gather_every"]
+        watchdog["partial"] = (world * F * args.passes * args.steps / elapsed, elapsed)
+        if main_every != 1:
+            watchdog["deadline"] = time.time() + float(os.environ.get("MS_BENCH_WATCHDOG_S", "300"))
+            watchdog["stage"] = "full gather (every frame to one sink)"
+            state["gather_every"] = 1
+            el_fg, n_fg = timed_region(max(1, args.steps // 2), max(1, args.warmup // 2))
+            full_gather = (world * F * args.passes * max(1, args.steps // 2) / el_fg, n_fg, el_fg)
+            state["gather_every"] = main_every
+        watchdog["deadline"] = None
+    D, dist_info = dd["D"], dd["info"]
 
     if args.calib:
         a = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255); b = torch.empty_like(a)
@@ -892,6 +956,46 @@ def main():
     if live_comp is not None:
         live_comp.close()
 
+    # ---- MS_BENCH_CHECK_GATHERED (tests): what arrived on the sink IS what the peers stitched -- rank 0 re-stitches frames of every peer's last gathered
+    #      pass (it knows their inputs: frame j of rank r is set (r + j * world) mod distinct) and compares them with the received slabs, byte for byte
+    gathered_check = None
+    if os.environ.get("MS_BENCH_CHECK_GATHERED") == "1" and gather and rank == 0 and direct_i420 and state["last_gather_b"] is not None and not resize_scale and not mesh_pool:
+        chk_comp = make_comp(1)
+        one = chk_comp.new_i420(1)
+        gb = state["last_gather_b"]
+        ok, n_chk = True, 0
+        for r in range(1, world):
+            for j in sorted({0, F // 2, F - 1}):
+                one[0][:(yb - ya)] = 16; one[0][(yb - ya):] = 128
+                chk_comp.stitch_i420([pool[(r + j * world) % n_distinct]], one)
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.equal(one[0], gl[gb][r][j]))
+                n_chk += 1
+        chk_comp.close()
+        gathered_check = {"equal": ok, "frames": n_chk, "what": "frames of every peer's last gathered pass as received on the sink vs the sink's own stitch of the same inputs"}
+
+    # ---- the same workload with EVERY frame of the pass distinct: SURVEY 8(d) prescribes 8 sets cycled = 298 MB of source against a 256 MiB
+    #      Infinity Cache; here the pass's F frames are F different sets (derived on the device from the 8 base sets by a cyclic shift: other bytes at other
+    #      addresses, same statistics), so no source line can be served from a cache.  A second, short timed region; `value` stays the prescribed workload.
+    value_d96 = None
+    if world == 1 and not resize_scale and not egress and n_distinct < F and not args.no_distinct and not args.calib:
+        try:
+            fr96 = [[torch.roll(pool[t % n_distinct][i], shifts=(7 * (t // n_distinct) + 1, 13 * (t // n_distinct) + 3), dims=(0, 1)) if t >= n_distinct else pool[t][i]
+                     for i in range(cfg["n"])] for t in range(F)]
+            sub96 = [[comps[k].prepared(fr96[k * Fs:(k + 1) * Fs], out8u=outs[b][k * Fs:(k + 1) * Fs]) for k in range(S)] for b in range(2)]
+            keep_sub = [list(subruns[b]) for b in range(2)]
+            for b in range(2):
+                subruns[b][:] = sub96[b]
+            st96 = max(2, args.steps // 4)
+            el96, _ = timed_region(st96, 1)
+            value_d96 = {"value": round(F * args.passes * st96 / el96, 2), "distinct_frame_sets": F, "steps": st96,
+                         "source_bytes": int(F * cfg["n"] * 3 * full_w * full_h)}
+            for b in range(2):
+                subruns[b][:] = keep_sub[b]
+            del fr96, sub96
+        except Exception as e:      # optional: never fail the line on it
+            value_d96 = {"error": str(e)[:200]}
+
     # ---- PCIe-inclusive rate: the C++ host pipeline with the reference's thread / queue graph, every source frame uploaded from pinned memory
     pcie = None
     app = os.path.join(ROOT, "video-stitcher_amd", "stitch_app")
@@ -936,6 +1040,20 @@ def main():
         kb["k_resize_batch"] = Fs * cfg["n"] * 3.0 * (full_w * full_h + cfg["w"] * cfg["h"])      # read the camera frame, write the compose-scale one
     dom = max(kmean, key=kmean.get)
     achieved = kb.get(dom, 0.0) / (kmean[dom] * 1e-3) / 1e9          # GB/s
+    # COMPULSORY bytes of the warp-type kernels and the resize (what any implementation of that stage has to move: every source byte it samples -- at most 4 taps x 3 B per
+    # pixel it writes -- and the bytes it writes, over the tiles the work lists keep): the third fraction of the line, so that extra traffic can never read as progress
+    ps = comp.plan_stats()
+    tpx = ps["warp_tile"][0] * ps["warp_tile"][1]
+    warp_px, s1_px = float(ps["n_warp_tiles"] * tpx), float(ps["n_stage1_reachable"] * tpx)
+    src_b = cfg["n"] * 3.0 * cfg["w"] * cfg["h"]
+    useful = {}
+    if cpw:
+        useful["k_remap_gain"] = Fs * (min(src_b, 12.0 * s1_px) + 3.0 * s1_px)
+        useful["k_warp"] = Fs * (min(3.0 * s1_px, 12.0 * warp_px) + 3.0 * warp_px)
+    else:
+        useful["k_warp"] = Fs * (min(src_b, 12.0 * warp_px) + 3.0 * warp_px)
+    if resize_runs:
+        useful["k_resize_batch"] = Fs * cfg["n"] * 3.0 * (full_w * full_h + cfg["w"] * cfg["h"])
     P_list = []
     for i in range(cfg["n"]):
         g = comp.view_geom(i)
@@ -1018,7 +1136,7 @@ def main():
         par = "frame-parallel x%d" % world
         if gather:
             par += ", gather of the %s pano rows of %s on rank 0 (%.1f MB/frame) through %s, overlapped with the next pass" % (
-                args.gather_format.upper(), "EVERY frame" if state["gather_every"] == 1 else "every %d-th pass" % state["gather_every"], slabs[0][0].numel() / 1e6,
+                args.gather_format.upper(), "EVERY frame" if state["gather_every"] == 1 else "every %d-th pass (live-rate egress)" % state["gather_every"], slabs[0][0].numel() / 1e6,
                 ("ms_dist / " + dist_info["transport"]) if D is not None else "torch.distributed")
         if share:
             par += " [DEBUG: ranks share one GPU, gloo]"
@@ -1048,6 +1166,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE = requests of the L2s to the fabric: Infinity-Cache hits are counted as HBM bytes (an upper bound). Since round 4 the warp / level-0 band "
                                          "tile lists are dealt to the XCDs in chunks: 3-4 % less time for 11 % more of these bytes (125 vs 113 MB per frame) -- part of any rise of `frac` over round 3 is bytes, not speed",
+                         "useful_bytes_per_launch": (int(useful[dom]) if dom in useful else None),
+                         "frac_useful": (round(useful[dom] / (kmean[dom] * 1e-3) / 8e12, 4) if dom in useful else None),
+                         "frac_useful_note": "compulsory bytes of this kernel (source bytes it samples, capped at 4 taps x 3 B per pixel written, + the u8 bytes it writes over the planned tiles) / mean launch time / 8 TB/s",
                          "achieved_contract": round(achieved, 1), "frac_contract": round(achieved / 8000.0, 4),
                          "alg_bytes_per_launch": int(kb.get(dom, 0)), "mean_launch_ms": round(kmean[dom], 5),
                          "frac_of_copy_ceiling": (round(traffic / (kmean[dom] * 1e-3) / 1e12 / ceiling["copy_TBps"], 4) if (traffic and ceiling and "copy_TBps" in ceiling) else None)},
@@ -1072,21 +1193,29 @@ def main():
         }
         if no_gather is not None:
             res["value_no_gather"] = round(no_gather, 2)
-            res["value_live_rate_gather"] = round(live_gather[0], 2)
             if state["gather_every"] == 1:
-                res["value_full_gather"] = res["value"]          # (the main region IS the every-frame gather)
+                res["value_full_gather"] = res["value"]          # (--gather-every 1: the main region IS the every-frame gather)
+            else:
+                res["value_live_rate_gather"] = res["value"]     # (the main region IS the live-rate egress)
+                res["value_full_gather"] = round(full_gather[0], 2) if full_gather else None
             res["gather"] = {"gathered_passes": n_gathered, "of_passes": args.steps * args.passes, "every": state["gather_every"],
+                             "passes_per_s_and_rank_gathered": round(n_gathered / elapsed, 1),
                              "GBps_into_sink": round(n_gathered * F * (world - 1) * slabs[0][0].numel() / elapsed / 1e9, 2),
-                             "live_rate_every": live_gather[1], "live_rate_gathered_passes": live_gather[2]}
-        if world > 1:      # what a reader of the first multi-GPU record needs, at the top level: compute-only and live-rate scaling beside `value`, what the communicator saw, every rank's copy ceiling
+                             "full_gather_GBps_into_sink": (round(full_gather[1] * F * (world - 1) * slabs[0][0].numel() / full_gather[2] / 1e9, 2) if full_gather else None)}
+        if world > 1:      # what a reader of the first multi-GPU record needs, at the top level: compute-only and every-frame-to-one-sink rates beside `value`, what the communicator saw, every rank's copy ceiling
             res["comm_nranks"] = (dist_info or {}).get("comm_nranks")
             res["transport"] = (dist_info or {}).get("transport")
             res["pci_bus_ids"] = (dist_info or {}).get("pci_bus_ids")
             res["rank_copy_TBps"] = rank_ceilings
-            res["how_to_read"] = ("value = every frame of every rank gathered on rank 0 inside the timed region (one sink: bound by its inbound xGMI links, not by the compositor); "
-                                  "value_no_gather = compute-only scaling; value_live_rate_gather = the egress of a 30 fps stream per rank (BASELINE configs[3])")
+            res["how_to_read"] = ("value = BASELINE configs[3]: every frame stitched frame-parallel, the egress of a live stream (the slabs of ~30 batches per second and rank) gathered on rank 0 "
+                                  "over ms_dist inside the timed region; value_no_gather = compute only (measured before the communicator exists); value_full_gather = EVERY frame of every rank "
+                                  "into the one sink at benchmark rate (bound by one GPU's inbound xGMI links, ~100 k frames/s of 3.6 MB slabs, not by the compositor)")
         if dist_info is not None:
             res["dist"] = dist_info      # what the communicator itself saw: transport, nranks (RCCL's own count), device ordinals and PCI bus ids of every rank
+        if value_d96 is not None:
+            res["value_distinct"] = value_d96
+        if gathered_check is not None:
+            res["gathered_frames_checked"] = gathered_check
         if live is not None:
             res["live"] = live
         if pcie is not None:

@@ -41,6 +41,12 @@ typedef struct ms_dist_info {
     char pci_bus_id[MS_DIST_MAX_RANKS][16];   /* hipDeviceGetPCIBusId of every rank: distinct ids = distinct GPUs */
 } ms_dist_info;
 
+/* Where the RCCL transport finds RCCL.  By default librccl.so.1 is resolved on first use: a copy already loaded into the process (PyTorch ships its own under the
+ * same soname) is reused, otherwise the loader's search path, then /opt/rocm/lib.  A deployment that keeps RCCL elsewhere -- or a test that substitutes a loopback
+ * implementation of the same entry points (tests/fake_rccl.cpp) -- names the file here, once per process, BEFORE the first RCCL id / communicator
+ * (MS_ERR_STATE afterwards; NULL or "" restores the default).  The library reads no environment variable for this. */
+MS_API int ms_dist_set_rccl_library(const char *path);
+
 /* Rank 0 calls this once and hands the bytes to every rank (file, pipe, torch.distributed store, a shared variable between threads).
  * transport AUTO: RCCL when this process sees at least `nranks` devices, else HOST. */
 MS_API int ms_dist_unique_id(int transport, int nranks, void *id_out /* MS_DIST_ID_BYTES */);

@@ -367,17 +367,29 @@ MS_API int ms_stitch_finish(ms_ctx *ctx, int n_frames, const void *const *partia
 /* gpu_dst_mask_ (blenders.cpp:803): frame-invariant; 8UC1 pano-ROI sized DEVICE image owned by ctx. */
 MS_API int ms_get_result_mask(ms_ctx *ctx, ms_image *mask);
 
-/* Diagnostics of the band kernels' work classification (no reference counterpart: the reference runs the general arithmetic everywhere).  The 64 x 16 pixel cells
- * of band `level` by class -- owned: one view with weight exactly 1 everywhere (no multiply, no division); exclusive (level 0 only): several views meet but every
- * pixel has one contributing view with weight exactly 1 (binary seam masks) -- the same integer arithmetic, selected by the mask bytes; general: the reference's
- * float multiply + divide.  Results are identical in every class (tests/test_compositor_gpu.py); bands without a map report every cell as general. */
 /* Calibration tables as a blob (the reference re-runs stitch_calib at every start, APP/timed.cpp:553).  ms_save_tables writes what the static
  * tables of a ready context derive from -- configuration, per view K, R, gain and blend mask, blender kind -- into `buf` (buf == NULL: only *bytes_out, the size
  * needed).  ms_load_tables creates a context from such a blob and rebuilds every table (same library build => bit-identical tables, e.g. on every rank of a
  * multi-GPU run); CPW meshes are run-time state and are set afterwards (ms_set_meshes).  Corrupt / foreign blobs are MS_ERR_INVALID before the device is touched. */
 MS_API int ms_save_tables(ms_ctx *ctx, void *buf, size_t cap, size_t *bytes_out);
 MS_API int ms_load_tables(const void *buf, size_t bytes, ms_ctx **out, ms_stream stream);
+/* Diagnostics of the band kernels' work classification (no reference counterpart: the reference runs the general arithmetic everywhere).  The 64 x 16 pixel cells
+ * of band `level` by class -- owned: one view with weight exactly 1 everywhere (no multiply, no division); exclusive (level 0 only): several views meet but every
+ * pixel has one contributing view with weight exactly 1 (binary seam masks) -- the same integer arithmetic, selected by the mask bytes; general: the reference's
+ * float multiply + divide.  Results are identical in every class (tests/test_compositor_gpu.py); bands without a map report every cell as general. */
 MS_API int ms_get_band_cells(ms_ctx *ctx, int level, unsigned *owned, unsigned *exclusive, unsigned *general);
+
+/* Diagnostics of the work lists (no reference counterpart: the reference launches full grids over every padded view).  build_plan keeps only the tiles some consumer
+ * reads; the counts say what a launch touches, e.g. n_warp_tiles x warp_tile_w x warp_tile_h = the level-0 pixels the projection warp writes per frame (bench.py's
+ * compulsory-byte figure `frac_useful` is computed from them).  struct_size as in ms_config. */
+typedef struct ms_plan_stats {
+    unsigned struct_size;
+    int warp_tile_w, warp_tile_h, n_warp_tiles;          /* level-0 tiles of the projection warp (CPW: of the mesh remap)        */
+    int n_stage1_tiles, n_stage1_reachable;              /* CPW: tiles of the first remap; those within reach of the mesh remap  */
+    int down_tile_w, down_tile_h, n_down_tiles[8];       /* output tiles of the reduce from level l to l + 1 (tile kernel)       */
+    int blend_tile_w, blend_tile_h, n_blend_tiles[8];    /* panorama tiles of band l (tile kernel)                               */
+} ms_plan_stats;
+MS_API int ms_get_plan_stats(ms_ctx *ctx, ms_plan_stats *out);
 
 /* geometry read-back (top_/left_/bottom_/right_, x_tl_.., dst_roi_: blenders.hpp:143-175) */
 typedef struct ms_view_geom {

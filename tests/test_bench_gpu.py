@@ -37,12 +37,16 @@ def test_single_gpu_line_has_the_contract_keys():
         assert r["frac_contract"] >= r["frac"] and "collected" in r["traffic_source"] and r["frac"] < 1.0
     else:
         assert r["basis"].startswith("algorithmic") and abs(r["frac"] - r["frac_contract"]) < 1e-6
-    assert r["traffic_stale"] in (True, False, None) or isinstance(r["traffic_stale"], str)      # False when the PMC summary was collected on these very kernel sources
+    # False when the PMC summary was collected on these very kernel sources, True once csrc/ has moved on (the line must then say so), None only without a summary
+    assert r["traffic_stale"] in (True, False) if r["traffic"] else r["traffic_stale"] is None
+    assert 0.0 < r["frac_useful"] <= r["frac"] + 1e-6 or not r["traffic"]      # compulsory bytes of the kernel / time / peak: extra traffic can never read as progress
     fr = d["frame_roofline"]
     assert "vs_contract_model" in fr and "wall_vs_contract_model" in fr and "frac" not in fr and "wall_frac" not in fr      # the > 1 model figures are not called fractions
     assert d["config"]["distinct_frame_sets"] == 8 and d["pcie_inclusive_fps"].get("nv12_direct_value", 0) > 100
     c = d["ceiling"]      # the tuned streaming copy / read of this run: the measured ceiling the fractions are read against
-    assert c["copy_TBps"] > 3.0 and c["read_TBps"] > c["copy_TBps"] * 0.8
+    # measured spread of the tuned copy over the boxes of four rounds: 5.08 - 6.18 TB/s (profiles/r04_bench_repeats.txt, r03_copy_probe.txt), read 6.6 - 7.2:
+    # 4.0 / 0.9 are the thresholds of round 2, kept (they had been loosened without a measured reason)
+    assert c["copy_TBps"] > 4.0 and c["read_TBps"] > c["copy_TBps"] * 0.9
 
 
 def test_shipped_configuration_line():
@@ -58,6 +62,9 @@ def test_shipped_configuration_line():
     assert d["cpu_baseline"]["value"] > 0 and "cv::resize" in d["cpu_baseline"]["flavour"]
 
 
+FAKE_RCCL = os.path.join(ROOT, "tests", "_fake_rccl", "libfake_rccl.so")
+
+
 def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     env = dict(os.environ, MS_BENCH_SHARE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
@@ -67,17 +74,42 @@ def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "gather" in d["config"]["parallelism"] and "x2" in d["config"]["parallelism"]
     assert d["value_no_gather"] > 0 and d["gather"]["gathered_passes"] == 4 and d["verified"] is True
+    assert d["value_full_gather"] == d["value"] and d["gather"]["every"] == 1 and "EVERY frame" in d["config"]["parallelism"]      # --gather-every 1: the main region IS the every-frame gather
     # the data path is the product's own ms_dist layer (host mailbox here: the ranks share the GPU); the line says what the communicator saw
     assert d["dist"]["transport"] == "host" and d["dist"]["nranks"] == 2 and "ms_dist" in d["config"]["parallelism"]
     # ... and the fields a reader of a first multi-GPU record needs, at the top level: what the communicator saw, every rank's own copy ceiling, how to read the three rates
     assert d["transport"] == "host" and len(d["pci_bus_ids"]) >= 2 and len(d["rank_copy_TBps"]) == 2 and all(x and x > 1.0 for x in d["rank_copy_TBps"]) and "value_no_gather" in d["how_to_read"]
-    # the default: EVERY frame gathered in the main region (`value` = the conservative number); compute-only and live-rate rates beside it
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29535",
-                        "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--passes", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_plain_invocation_spawns_ranks():
+    """`python bench.py --gpus 2` AS TYPED (no launcher, no WORLD_SIZE): bench.py spawns the ranks itself, rank 0 prints the one line, exit code 0 (the
+    first real multi-GPU run must not die on plumbing).  The default N > 1 line: `value` = BASELINE configs[3]'s shape (every frame stitched, a live stream's egress
+    gathered), the compute-only and the every-frame-to-one-sink rates beside it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MS_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--passes", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1, p.stdout[-2000:]
+    d = last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["value"] > 0 and "incomplete" not in d
+    assert d["value_live_rate_gather"] == d["value"] and d["value_no_gather"] > 0 and d["value_full_gather"] > 0
+    assert d["gather"]["every"] >= 1 and d["gather"]["gathered_passes"] >= 1 and "configs[3]" in d["how_to_read"]
+
+
+def test_rccl_branch_with_two_ranks_over_the_loopback_library():
+    """The RCCL branch of csrc/dist.cpp (ncclCommInitRank, the all-gather of rccl_attach, grouped ncclRecv on the sink / ncclSend on the peers, on the bench's
+    communication stream with its event ordering) with TWO ranks: a one-GPU box cannot do that with the real library (it refuses two ranks on one device), so the
+    entry points are served by tests/fake_rccl.cpp -- stream-ordered, asynchronous like NCCL, bytes through shared memory.  Proves call order, grouping and
+    stream / event ordering of the callers; RCCL over xGMI itself stays unmeasured."""
+    assert os.path.isfile(FAKE_RCCL), "tests/_fake_rccl/libfake_rccl.so is built by __graft_entry__.build()"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MS_BENCH_SHARE_GPU="1", MS_BENCH_RCCL_LIB=FAKE_RCCL, MS_BENCH_CHECK_GATHERED="1")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--passes", "3", "--no-cpu-baseline", "--no-live"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)
-    assert d["verified"] is True and d["value"] > 0 and d["value_no_gather"] > 0 and d["value_full_gather"] == d["value"] and d["value_live_rate_gather"] > 0
-    assert d["gather"]["every"] == 1 and d["gather"]["gathered_passes"] == d["gather"]["of_passes"] and "EVERY frame" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 2 and d["verified"] is True and "incomplete" not in d
+    assert d["transport"] == "rccl" and d["comm_nranks"] == 2 and d["dist"]["rccl_version"] == 29999      # (29999 = the loopback library's version: not a real RCCL)
+    assert d["value_full_gather"] > 0 and d["gathered_frames_checked"]["equal"] is True, d.get("gathered_frames_checked")
 
 
 def test_view_sharded_ranks_exchange_partials_and_match_the_unsharded_frame():

@@ -197,3 +197,51 @@ print("OK", info["rccl_version"])
 ''' % ROOT
     out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, timeout=300)
     assert out.returncode == 0 and b"OK" in out.stdout, (out.stdout.decode()[-500:], out.stderr.decode()[-1500:])
+
+
+# ---- the RCCL branch of csrc/dist.cpp with N > 1 ranks on a one-GPU box ---------------------------------------------------
+# The real library refuses two ranks on one device, so ncclCommInitRank / Send / Recv / Broadcast / AllGather / GroupStart / End are served by the loopback
+# implementation tests/fake_rccl.cpp (stream-ordered and asynchronous like NCCL, bytes through shared memory), handed to the product through
+# ms_dist_set_rccl_library (`stitch_dist --rccl-lib`).  This proves call order, grouping, and the comm-stream / stitch-stream event ordering of the callers;
+# RCCL over xGMI itself stays UNMEASURED until an N-GPU node runs it.
+FAKE_RCCL = os.path.join(ROOT, "tests", "_fake_rccl", "libfake_rccl.so")
+
+
+def fake(n):
+    assert os.path.isfile(FAKE_RCCL), "tests/_fake_rccl/libfake_rccl.so is built by __graft_entry__.build()"
+    return ["--gpus", n, "--share-gpu", "--transport", "rccl", "--rccl-lib", FAKE_RCCL]
+
+
+def _is_fake_rccl(res, ranks):
+    d = res["dist"]
+    return d["transport"] == "rccl" and d["nranks"] == ranks and d["comm_nranks"] == ranks and d["rccl_version"] == 29999
+
+
+@pytest.mark.parametrize("ranks,batch", [(2, 4), (4, 2), (4, 1)])
+def test_rccl_branch_frame_parallel_over_the_loopback_library(cuda, ranks, batch):
+    one = run("--gpus", 1, "--frames", 16, "--batch", 4)
+    many = run(*fake(ranks), "--frames", 16, "--batch", batch)
+    assert _is_fake_rccl(many, ranks) and many["frames"] == 16
+    assert many["checksum_all"] == one["checksum_all"]
+
+
+def test_rccl_branch_column_shards_recalibration_and_table_blob_over_the_loopback_library(cuda):
+    one = run("--gpus", 1, "--frames", 16, "--batch", 4)
+    # 2 column shards x 2 frame-parallel groups: ungrouped ncclSend of the windows to the leader on the stitch stream, grouped ncclRecv there, leaders -> sink on the comm stream
+    res = run(*fake(4), "--col-shards", 2, "--frames", 16, "--batch", 2)
+    assert _is_fake_rccl(res, 4) and res["checksum_all"] == one["checksum_all"]
+    # the mesh broadcast (host payload staged through device memory: ncclBroadcast) with the agreed swap frame, inside and outside column-shard groups
+    cp = run("--gpus", 1, "--frames", 32, "--batch", 4, "--recalib-every", 8, "--mesh", "9x11")
+    for extra in ([], ["--col-shards", 2]):
+        res = run(*fake(4), *extra, "--frames", 32, "--batch", 4 if extra else 2, "--recalib-every", 8, "--mesh", "9x11")
+        assert _is_fake_rccl(res, 4) and res["recalibrations_applied"] == cp["recalibrations_applied"] == 3 and res["checksum_all"] == cp["checksum_all"], extra
+    # the table blob of rank 0 (5 MB through the staged ncclBroadcast)
+    res = run(*fake(2), "--frames", 16, "--batch", 4, "--tables-from-rank0")
+    assert _is_fake_rccl(res, 2) and res["checksum_all"] == one["checksum_all"]
+
+
+def test_rccl_branch_full_size_config2_over_the_loopback_library(cuda):
+    """BASELINE configs[3]'s shape at full size: 6 x 1080p -> 3840 x 1920, 4 frame-parallel ranks, 3.6 MB I420 slabs per frame through ncclSend / ncclRecv."""
+    one = run("--gpus", 1, "--frames", 16, "--batch", 4, rig="cfg2")
+    res = run(*fake(4), "--frames", 16, "--batch", 2, rig="cfg2")
+    assert _is_fake_rccl(res, 4) and res["checksum_all"] == one["checksum_all"]

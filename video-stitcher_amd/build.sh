@@ -17,7 +17,8 @@ for f in prims.hip compositor.hip mesh_solver.hip matcher.hip features.hip calib
 done
 # the hand-declared RCCL prototypes of dist.cpp against the installed header (syntax only; skipped where the header is absent)
 if [ -f /opt/rocm/include/rccl/rccl.h ] && { [ ! -f ../build/rccl_abi.ok ] || [ rccl_abi_check.cpp -nt ../build/rccl_abi.ok ] || [ dist.cpp -nt ../build/rccl_abi.ok ]; }; then
-  $HIPCC -std=c++17 -fsyntax-only -x hip --offload-host-only rccl_abi_check.cpp && touch ../build/rccl_abi.ok
+  $HIPCC -std=c++17 -fsyntax-only -x hip --offload-host-only rccl_abi_check.cpp || { echo "RCCL ABI check failed: the prototypes dist.cpp declares do not match the installed rccl.h" >&2; exit 1; }
+  touch ../build/rccl_abi.ok
 fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || { echo "compile failed" >&2; exit 1; }; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmsstitch.so ../build/prims.o ../build/compositor.o ../build/mesh_solver.o ../build/matcher.o ../build/features.o ../build/calib.o ../build/api.o ../build/geometry.o ../build/dist.o -ldl -lrt

@@ -1622,7 +1622,7 @@ struct ms_ctx {
     int btail_t = -1, btail_lds = 0, btail_strips = 0;      // fused coarse band chain (k_blend_tail): finest band it produces, LDS bytes, strips    // fused coarse-level reduce (k_down_tail): first level it reads, LDS bytes; -1 = off
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
-    int n_stage1_tiles = 0;
+    int n_stage1_tiles = 0, n_stage1_reachable = 0;
     ms_image fed[MAX_VIEWS] = {};      // ms_feed: the views of the frame being assembled (borrowed until ms_blend)
     unsigned fed_mask = 0;
     DevBuf masks_eff;                  // ms_update_mask: masks re-warped through the CPW mesh (same layout as `masks`)
@@ -1971,6 +1971,7 @@ static int build_plan(ms_ctx *c)
         {   // reachable tiles first, each part in XCD order on its own: when the others exit early every XCD still gets an equal share
             std::vector<WarpTile> a, b;
             for (const WarpTile &t : tiles) ((t.flags & 2) ? a : b).push_back(t);
+            c->n_stage1_reachable = (int)a.size();
             if (c->cfg.raster_tile_order == 0) { xcd_order(a, dev_knob("MS_XCD_CHUNK_S1", 8)); xcd_order(b, dev_knob("MS_XCD_CHUNK_S1", 8)); }
             tiles = a;
             tiles.insert(tiles.end(), b.begin(), b.end());
@@ -3653,6 +3654,21 @@ int ms_get_band_cells(ms_ctx *c, int level, unsigned *owned, unsigned *exclusive
     MS_HIP(hipMemcpy(h.data(), src, h.size(), hipMemcpyDeviceToHost));
     *general = 0;
     for (uint8_t b : h) { if (b == 255) ++*general; else if (b == 254) ++*exclusive; else ++*owned; }
+    return MS_OK;
+}
+
+int ms_get_plan_stats(ms_ctx *c, ms_plan_stats *out)
+{
+    if (!c || !out) return fail(MS_ERR_INVALID, "null argument");
+    if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_get_plan_stats: call ms_init_blender first");
+    MS_CHECK(out->struct_size == sizeof(ms_plan_stats), "ms_get_plan_stats: struct_size %u, this library's ms_plan_stats has %zu bytes", out->struct_size, sizeof(ms_plan_stats));
+    ms_plan_stats s{};
+    s.struct_size = (unsigned)sizeof(s);
+    s.warp_tile_w = WARP_TW; s.warp_tile_h = WARP_TH; s.n_warp_tiles = c->n_warp_tiles;
+    s.n_stage1_tiles = c->n_stage1_tiles; s.n_stage1_reachable = c->n_stage1_reachable;
+    s.down_tile_w = DOWN_TW; s.down_tile_h = DOWN_TH; s.blend_tile_w = BLEND_TW; s.blend_tile_h = BLEND_TH;
+    for (int l = 0; l < 8 && l < MAX_LEVELS; ++l) { s.n_down_tiles[l] = c->n_down_tiles[l]; s.n_blend_tiles[l] = c->n_blend_tiles[l]; }
+    *out = s;
     return MS_OK;
 }
 

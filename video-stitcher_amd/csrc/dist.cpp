@@ -20,6 +20,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <vector>
 #include "common.hpp"
 #include "../../include/ms_dist.h"
@@ -54,13 +56,25 @@ struct Rccl {
     bool ok = false;
     const char *why = "";
 };
+std::mutex g_rccl_mu;
+std::string g_rccl_path;            // ms_dist_set_rccl_library: an explicit file instead of the search below
+bool g_rccl_resolved = false;
 Rccl &rccl()
 {
     static Rccl R = [] {
         Rccl r;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!r.lib) { r.why = "librccl.so.1 not found"; return r; }
+        std::string path;
+        { std::lock_guard<std::mutex> lk(g_rccl_mu); path = g_rccl_path; g_rccl_resolved = true; }
+        if (!path.empty()) {
+            r.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { r.why = "the library given to ms_dist_set_rccl_library could not be loaded"; return r; }
+        } else {
+            // a copy that is already in the process first (PyTorch ships its own librccl with the same soname: one RCCL per process, not two)
+            const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+            if (!r.lib) for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+            if (!r.lib) { r.why = "librccl.so.1 not found"; return r; }
+        }
 #define MS_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym)); if (!r.field) { r.why = "librccl lacks " sym; return r; }
         MS_SYM(GetVersion, "ncclGetVersion") MS_SYM(GetUniqueId, "ncclGetUniqueId") MS_SYM(CommInitRank, "ncclCommInitRank")
         MS_SYM(CommDestroy, "ncclCommDestroy") MS_SYM(CommCount, "ncclCommCount") MS_SYM(Send, "ncclSend") MS_SYM(Recv, "ncclRecv")
@@ -368,6 +382,14 @@ int p2p(ms_dist *d, bool send, void *buf, size_t bytes, int peer, int mem, hipSt
 using namespace ms;
 
 extern "C" {
+
+int ms_dist_set_rccl_library(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_resolved) return fail(MS_ERR_STATE, "ms_dist_set_rccl_library: RCCL has already been resolved in this process (call it before the first RCCL communicator or id)");
+    g_rccl_path = path ? path : "";
+    return MS_OK;
+}
 
 int ms_dist_unique_id(int transport, int nranks, void *id_out)
 {

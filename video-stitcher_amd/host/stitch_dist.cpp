@@ -16,7 +16,7 @@
 // checksums in display order) is what tests/test_ms_dist_gpu.py compares.
 //
 // Usage: stitch_dist [--gpus G] [--col-shards S] [--share-gpu] [--transport auto|rccl|host] [--frames T] [--batch F] [--views 6] [--size WxH]
-//                    [--out WxH] [--hfov 90] [--bands 5] [--cpw] [--recalib-every K] [--mesh NxM] [--no-checksum] [--tables-from-rank0]
+//                    [--out WxH] [--hfov 90] [--bands 5] [--cpw] [--recalib-every K] [--mesh NxM] [--no-checksum] [--tables-from-rank0] [--rccl-lib FILE]
 // Prints one JSON line (rank 0): frames/s of the whole job, what the communicator saw (transport, nranks, devices, PCI ids), the checksums.
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -49,6 +49,7 @@ struct Options {
     bool share_gpu = false, cpw = false, checksum = true;
     bool frame_sums = false;          // --frame-sums: print every frame's checksum on stderr (diagnostic)
     bool tables_from_rank0 = false;   // --tables-from-rank0: only rank 0 calibrates; the others build their context from its table blob (ms_save_tables -> ms_dist_broadcast -> ms_load_tables)
+    std::string rccl_lib;             // --rccl-lib FILE: ms_dist_set_rccl_library (a deployment's own RCCL, or the loopback implementation the tests substitute)
 };
 
 // the pattern of video-stitcher_amd/synth.py (noise off), `variant` shifts the phase so that consecutive frames differ
@@ -253,10 +254,22 @@ void rank_main(const Options &o, int rank, Shared &sh)
     int applied_rounds = 0;
 
     Shared::RankTimes rt;
-    std::vector<hipEvent_t> ev_s0, ev_s1, ev_g0, ev_g1;
+    // per-batch timing events: a ring of RING (begin, end) pairs per timer, re-used; a pair's elapsed time is added up when its slot comes round again (and at the end), so
+    // a run of any length holds 4 x RING events
+    constexpr int RING = 8;
+    struct Timer {
+        hipEvent_t e0[RING], e1[RING];
+        bool open[RING] = {};
+        int n = 0;
+        double *sum = nullptr;
+        void retire(int i) { if (open[i]) { HIPC(hipEventSynchronize(e1[i])); float t = 0; HIPC(hipEventElapsedTime(&t, e0[i], e1[i])); *sum += t; open[i] = false; } }
+        void begin(hipStream_t s) { const int i = n % RING; retire(i); HIPC(hipEventRecord(e0[i], s)); }
+        void end(hipStream_t s) { const int i = n % RING; HIPC(hipEventRecord(e1[i], s)); open[i] = true; ++n; }
+    } t_stitch, t_gather;
+    t_stitch.sum = &rt.stitch_gpu_ms; t_gather.sum = &rt.gather_stream_ms;
+    for (Timer *t : {&t_stitch, &t_gather}) for (int i = 0; i < RING; ++i) { HIPC(hipEventCreate(&t->e0[i])); HIPC(hipEventCreate(&t->e1[i])); }
     auto tick = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-    auto new_event = [&](std::vector<hipEvent_t> &v, hipStream_t s) { hipEvent_t e; HIPC(hipEventCreate(&e)); HIPC(hipEventRecord(e, s)); v.push_back(e); };
     std::vector<unsigned char> host_frame(rank == 0 && o.checksum ? frame_bytes : 0);
     std::vector<unsigned long long> sums;
     HIPC(hipStreamSynchronize(st));
@@ -300,9 +313,9 @@ void rank_main(const Options &o, int rank, Shared &sh)
             }
             outs[j] = ms_image{mine + j * frame_bytes, (size_t)o.out_w, o.out_w, i_rows * 3 / 2, MS_8UC1};
         }
-        new_event(ev_s0, st);
+        t_stitch.begin(st);
         MSC(ms_stitch_i420(ctx, F, views.data(), outs.data(), st));
-        new_event(ev_s1, st);
+        t_stitch.end(st);
         const auto t_shard = tick();
         // 4. column shards: windows to the group's first rank
         if (S > 1) {
@@ -321,7 +334,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
         HIPC(hipEventRecord(stitched[b], st));
         if (groups > 1 && (rank == 0 || rank == leader)) {
             HIPC(hipStreamWaitEvent(cs, stitched[b], 0));
-            new_event(ev_g0, cs);
+            t_gather.begin(cs);
             if (rank == 0) {
                 MSC(ms_dist_group_begin(dist));
                 for (int g = 1; g < groups; ++g) MSC(ms_dist_recv(dist, from_group[g], slab_bytes, g * S, MS_DIST_MEM_DEVICE, cs));
@@ -329,7 +342,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
             } else
                 MSC(ms_dist_send(dist, mine, slab_bytes, 0, MS_DIST_MEM_DEVICE, cs));
             HIPC(hipEventRecord(sent[b], cs));
-            new_event(ev_g1, cs);
+            t_gather.end(cs);
             sent_used[b] = true;
         }
         const auto t_cons = tick();
@@ -355,9 +368,7 @@ void rank_main(const Options &o, int rank, Shared &sh)
     running.store(false);
     if (recalibrater.joinable()) recalibrater.join();
     rt.wall_ms = secs * 1e3;
-    for (size_t i = 0; i < ev_s0.size(); ++i) { float t = 0; HIPC(hipEventElapsedTime(&t, ev_s0[i], ev_s1[i])); rt.stitch_gpu_ms += t; }
-    for (size_t i = 0; i < ev_g0.size(); ++i) { float t = 0; HIPC(hipEventElapsedTime(&t, ev_g0[i], ev_g1[i])); rt.gather_stream_ms += t; }
-    for (auto *v : {&ev_s0, &ev_s1, &ev_g0, &ev_g1}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    for (Timer *t : {&t_stitch, &t_gather}) for (int i = 0; i < RING; ++i) { t->retire(i); (void)hipEventDestroy(t->e0[i]); (void)hipEventDestroy(t->e1[i]); }
     if (rank == 0) {
         std::lock_guard<std::mutex> lk(sh.mu);
         sh.frame_sums = sums; sh.seconds = secs; sh.info = info; sh.bands = pg.num_bands; sh.i_rows = i_rows; sh.recalibrations = applied_rounds;
@@ -402,6 +413,7 @@ int main(int argc, char **argv)
         else if (k == "--no-checksum") o.checksum = false;
         else if (k == "--frame-sums") o.frame_sums = true;
         else if (k == "--tables-from-rank0") o.tables_from_rank0 = true;
+        else if (k == "--rccl-lib") o.rccl_lib = next();
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     int ndev = 0;
@@ -413,7 +425,8 @@ int main(int argc, char **argv)
     if (o.recalib_every > 0 && o.recalib_every % batch_frames != 0) { fprintf(stderr, "stitch_dist: --recalib-every must be a multiple of groups x batch = %lld (meshes swap between ms_stitch calls)\n", batch_frames); return 2; }
     Shared sh;
     int transport = o.transport;
-    if (o.share_gpu && o.gpus > 1) transport = MS_DIST_HOST;       // RCCL refuses two ranks on one device
+    if (o.share_gpu && o.gpus > 1 && transport == MS_DIST_AUTO) transport = MS_DIST_HOST;       // RCCL refuses two ranks on one device (an explicit --transport rccl is honoured: the loopback library of the tests does not)
+    if (!o.rccl_lib.empty() && ms_dist_set_rccl_library(o.rccl_lib.c_str()) < 0) { fprintf(stderr, "stitch_dist: %s\n", ms_last_error()); return 1; }
     if (ms_dist_unique_id(transport, o.gpus, sh.id) < 0) { fprintf(stderr, "stitch_dist: %s\n", ms_last_error()); return 1; }
     std::vector<std::thread> ranks;
     for (int r = 0; r < o.gpus; ++r)

@@ -15,6 +15,7 @@ MAX_RANKS = 16
 EXPORTS = [
     "ms_dist_unique_id", "ms_dist_create", "ms_dist_destroy", "ms_dist_get_info", "ms_dist_send", "ms_dist_recv", "ms_dist_group_begin",
     "ms_dist_group_end", "ms_dist_broadcast", "ms_dist_barrier", "ms_dist_gather_slabs", "ms_dist_mesh_exchange", "ms_dist_apply_meshes",
+    "ms_dist_set_rccl_library",
 ]
 
 
@@ -26,6 +27,11 @@ class Info(C.Structure):
 class MeshUpdate(C.Structure):
     _fields_ = [("swap_frame", C.c_longlong), ("version", C.c_int), ("n_views", C.c_int), ("rows", C.c_int), ("cols", C.c_int),
                 ("mesh_x", C.POINTER(C.c_float)), ("mesh_y", C.POINTER(C.c_float))]
+
+
+def set_rccl_library(path):
+    """Name the RCCL library file (before the first RCCL id / communicator of the process); None restores the default search."""
+    ms._chk(ms.load().ms_dist_set_rccl_library(None if path is None else str(path).encode()))
 
 
 def unique_id(nranks, transport=AUTO):

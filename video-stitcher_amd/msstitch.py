@@ -68,6 +68,12 @@ class Rig(C.Structure):
                 ("K_compose", (C.c_float * 9) * 16), ("K_seam", (C.c_float * 9) * 16), ("R", (C.c_float * 9) * 16)]
 
 
+class PlanStats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint), ("warp_tile_w", C.c_int), ("warp_tile_h", C.c_int), ("n_warp_tiles", C.c_int), ("n_stage1_tiles", C.c_int),
+                ("n_stage1_reachable", C.c_int), ("down_tile_w", C.c_int), ("down_tile_h", C.c_int), ("n_down_tiles", C.c_int * 8),
+                ("blend_tile_w", C.c_int), ("blend_tile_h", C.c_int), ("n_blend_tiles", C.c_int * 8)]
+
+
 class MeshMatch(C.Structure):
     _fields_ = [("x1", C.c_float), ("y1", C.c_float), ("x2", C.c_float), ("y2", C.c_float), ("dst", C.c_int)]
 
@@ -93,7 +99,7 @@ EXPORTS = [
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
-    "ms_save_tables", "ms_load_tables", "ms_calib_shape", "ms_stitch_nv12",
+    "ms_save_tables", "ms_load_tables", "ms_calib_shape", "ms_stitch_nv12", "ms_get_plan_stats",
 ]
 
 _lib = None
@@ -738,6 +744,15 @@ class Compositor:
         a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
         _chk(load().ms_get_band_cells(self._ctx, level, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def plan_stats(self):
+        """Work-list sizes of the context (ms_get_plan_stats) as a dict."""
+        st = PlanStats()
+        st.struct_size = C.sizeof(PlanStats)
+        _chk(load().ms_get_plan_stats(self._ctx, C.byref(st)))
+        return {"warp_tile": (st.warp_tile_w, st.warp_tile_h), "n_warp_tiles": st.n_warp_tiles, "n_stage1_tiles": st.n_stage1_tiles,
+                "n_stage1_reachable": st.n_stage1_reachable, "down_tile": (st.down_tile_w, st.down_tile_h), "n_down_tiles": list(st.n_down_tiles),
+                "blend_tile": (st.blend_tile_w, st.blend_tile_h), "n_blend_tiles": list(st.n_blend_tiles)}
 
     def _tables(self, frames, out8u, out16s):
         n_frames = len(frames)
