@@ -103,7 +103,7 @@ def test_rccl_branch_with_two_ranks_over_the_loopback_library():
     stream / event ordering of the callers; RCCL over xGMI itself stays unmeasured."""
     assert os.path.isfile(FAKE_RCCL), "tests/_fake_rccl/libfake_rccl.so is built by __graft_entry__.build()"
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MS_BENCH_SHARE_GPU="1", MS_BENCH_RCCL_LIB=FAKE_RCCL, MS_BENCH_CHECK_GATHERED="1")
+    env.update(MS_BENCH_SHARE_GPU="1", MS_BENCH_RCCL_LIB=FAKE_RCCL, MS_BENCH_CHECK_GATHERED="1", GPU_MAX_HW_QUEUES="16")      # (a hardware queue per stream: see tests/test_ms_dist_gpu.py)
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--passes", "3", "--no-cpu-baseline", "--no-live"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)

@@ -19,11 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 APP = os.path.join(ROOT, "video-stitcher_amd", "stitch_dist")
 
 
-def run(*args, rig="mini6", timeout=600):
+def run(*args, rig="mini6", timeout=600, env=None):
     cfg = synth.CONFIGS[rig]
     base = ["--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]), "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"]]
-    out = subprocess.run([APP] + [str(a) for a in base + list(args)], capture_output=True, timeout=timeout)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    out = subprocess.run([APP] + [str(a) for a in base + list(args)], capture_output=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
     return json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
 
 
@@ -212,6 +212,12 @@ def fake(n):
     return ["--gpus", n, "--share-gpu", "--transport", "rccl", "--rccl-lib", FAKE_RCCL]
 
 
+# The loopback library holds a stream with a one-lane kernel that waits for the transfer (as an RCCL kernel waits for its peer).  HIP multiplexes the streams of a
+# process over 4 hardware queues by default; with every rank of stitch_dist in ONE process on ONE device, a rank's waiting kernel would then sit in front of the
+# very kernels of another rank that it waits for -- a deadlock that separate GPUs cannot have.  Give every stream of the test process its own hardware queue.
+FAKE_ENV = dict(os.environ, GPU_MAX_HW_QUEUES="32")
+
+
 def _is_fake_rccl(res, ranks):
     d = res["dist"]
     return d["transport"] == "rccl" and d["nranks"] == ranks and d["comm_nranks"] == ranks and d["rccl_version"] == 29999
@@ -220,7 +226,7 @@ def _is_fake_rccl(res, ranks):
 @pytest.mark.parametrize("ranks,batch", [(2, 4), (4, 2), (4, 1)])
 def test_rccl_branch_frame_parallel_over_the_loopback_library(cuda, ranks, batch):
     one = run("--gpus", 1, "--frames", 16, "--batch", 4)
-    many = run(*fake(ranks), "--frames", 16, "--batch", batch)
+    many = run(*fake(ranks), "--frames", 16, "--batch", batch, env=FAKE_ENV)
     assert _is_fake_rccl(many, ranks) and many["frames"] == 16
     assert many["checksum_all"] == one["checksum_all"]
 
@@ -228,20 +234,125 @@ def test_rccl_branch_frame_parallel_over_the_loopback_library(cuda, ranks, batch
 def test_rccl_branch_column_shards_recalibration_and_table_blob_over_the_loopback_library(cuda):
     one = run("--gpus", 1, "--frames", 16, "--batch", 4)
     # 2 column shards x 2 frame-parallel groups: ungrouped ncclSend of the windows to the leader on the stitch stream, grouped ncclRecv there, leaders -> sink on the comm stream
-    res = run(*fake(4), "--col-shards", 2, "--frames", 16, "--batch", 2)
+    res = run(*fake(4), "--col-shards", 2, "--frames", 16, "--batch", 2, env=FAKE_ENV)
     assert _is_fake_rccl(res, 4) and res["checksum_all"] == one["checksum_all"]
     # the mesh broadcast (host payload staged through device memory: ncclBroadcast) with the agreed swap frame, inside and outside column-shard groups
     cp = run("--gpus", 1, "--frames", 32, "--batch", 4, "--recalib-every", 8, "--mesh", "9x11")
     for extra in ([], ["--col-shards", 2]):
-        res = run(*fake(4), *extra, "--frames", 32, "--batch", 4 if extra else 2, "--recalib-every", 8, "--mesh", "9x11")
+        res = run(*fake(4), *extra, "--frames", 32, "--batch", 4 if extra else 2, "--recalib-every", 8, "--mesh", "9x11", env=FAKE_ENV)
         assert _is_fake_rccl(res, 4) and res["recalibrations_applied"] == cp["recalibrations_applied"] == 3 and res["checksum_all"] == cp["checksum_all"], extra
-    # the table blob of rank 0 (5 MB through the staged ncclBroadcast)
-    res = run(*fake(2), "--frames", 16, "--batch", 4, "--tables-from-rank0")
-    assert _is_fake_rccl(res, 2) and res["checksum_all"] == one["checksum_all"]
+    # (--tables-from-rank0 is not run this way: rank 0 calibrates -- hipDeviceSynchronize inside -- while the other rank THREADS of the same process already hold their
+    #  streams in the loopback library's waiting kernels for the blob: a deadlock of ranks that share one device and one process, impossible with a GPU per rank.  The
+    #  large staged host broadcast is covered between PROCESSES below, the blob itself over the host transport above.)
+
+
+def _exchange_rccl(rank, world, idb, fake_lib, q):
+    """what every rank PROCESS runs over the loopback library: device buffers, ms_dist's RCCL branch"""
+    try:
+        import msdist
+        import msstitch as ms
+        msdist.set_rccl_library(fake_lib)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        d = msdist.Dist(rank, world, idb, device=0)
+        try:
+            info = d.info()
+            assert info["transport"] == "rccl" and info["nranks"] == world and info["comm_nranks"] == world and info["rccl_version"] == 29999 and info["devices"] == [0] * world
+            with pytest.raises(ms.MsError):
+                msdist.set_rccl_library(None)                 # too late: RCCL is resolved
+            nxt, prv = (rank + 1) % world, (rank - 1) % world
+            for k, n in enumerate((0, 1, 4097, (1 << 20) + 13, 3 * (1 << 20) + 5)):      # ring, incl. an empty message and several mailbox pieces
+                out = torch.full((n,), (17 * rank + k) % 251, dtype=torch.uint8, device=dev)
+                got = torch.zeros(n, dtype=torch.uint8, device=dev)
+                d.group_begin(); d.send(out, nxt); d.recv(got, prv); d.group_end()
+                torch.cuda.synchronize()
+                assert bool(torch.all(got == (17 * prv + k) % 251)), (rank, k)
+            # two sends and two receives per peer, and a send to oneself, in ONE group; the buffers are filled by kernels enqueued just before (stream order, no host sync)
+            n2 = 5 * (1 << 19)
+            a_out = [torch.empty(n2, dtype=torch.uint8, device=dev).fill_((3 + 2 * rank + 7 * r) % 251) for r in range(world)]
+            b_out = [torch.empty(n2 + 1, dtype=torch.uint8, device=dev).fill_((4 + 2 * rank + 7 * r) % 251) for r in range(world)]
+            a_in = [torch.zeros(n2, dtype=torch.uint8, device=dev) for _ in range(world)]
+            b_in = [torch.zeros(n2 + 1, dtype=torch.uint8, device=dev) for _ in range(world)]
+            d.group_begin()
+            for r in range(world):
+                d.recv(a_in[r], r); d.send(a_out[r], r); d.send(b_out[r], r); d.recv(b_in[r], r)
+            d.group_end()
+            sums = [(a_in[r].sum(dtype=torch.int64), b_in[r].sum(dtype=torch.int64)) for r in range(world)]      # consumers enqueued right behind the group
+            torch.cuda.synchronize()
+            for r in range(world):
+                assert int(sums[r][0]) == n2 * ((3 + 2 * r + 7 * rank) % 251) and int(sums[r][1]) == (n2 + 1) * ((4 + 2 * r + 7 * rank) % 251), (rank, r)
+            # broadcasts: device buffer in place; a 5 MB HOST payload (staged through device memory, the staging buffer grows: the table blob's path)
+            t = torch.arange(100000, dtype=torch.float32, device=dev) * (1.0 if rank == world - 1 else 0.0)
+            d.broadcast(t, world - 1)
+            torch.cuda.synchronize()
+            assert bool(torch.equal(t, torch.arange(100000, dtype=torch.float32, device=dev)))
+            h = (np.arange(5 * (1 << 20), dtype=np.uint32) * 2654435761 % 251).astype(np.uint8) if rank == 0 else np.zeros(5 * (1 << 20), np.uint8)
+            d.broadcast(h, 0)
+            assert np.array_equal(h, (np.arange(5 * (1 << 20), dtype=np.uint32) * 2654435761 % 251).astype(np.uint8))
+            d.barrier()
+            # the frame gather on a side stream with event ordering, as bench.py drives it
+            slab = torch.full((3, 1 << 20), 40 + rank, dtype=torch.uint8, device=dev)
+            recv = [torch.zeros_like(slab) for _ in range(world)] if rank == 0 else None
+            cs = torch.cuda.Stream(device=dev)
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                d.gather_slabs(slab, recv, sink=0)
+            cs.synchronize()
+            if rank == 0:
+                for r in range(1, world):
+                    assert bool(torch.all(recv[r] == 40 + r)), r
+            n_views, rows, cols = 3, 5, 7
+            assert d.mesh_exchange(0, None, n_views, rows, cols) is None
+            rng = np.random.default_rng(5)
+            mx, my = rng.random((n_views, rows, cols), dtype=np.float32), rng.random((n_views, rows, cols), dtype=np.float32)
+            got = d.mesh_exchange(0, (4800, 2, mx, my) if rank == 0 else None, n_views, rows, cols)
+            assert got is not None and got[0] == 4800 and got[1] == 2 and np.array_equal(got[2], mx) and np.array_equal(got[3], my)
+            d.barrier()
+        finally:
+            d.close()
+        q.put((rank, "ok"))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:] or repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_branch_between_processes_over_the_loopback_library(cuda, world):
+    """ms_dist's RCCL branch call by call, one PROCESS per rank (all on device 0): grouped and ungrouped ncclSend / ncclRecv with stream-ordered producers and
+    consumers, a send to oneself, ncclBroadcast in place and staged from host memory (5 MB), the barrier's all-gather, the frame gather on a side stream, the mesh exchange."""
+    import msdist
+    import torch.multiprocessing as mp
+    assert os.path.isfile(FAKE_RCCL)
+    ctx = mp.get_context("spawn")
+    q0 = ctx.Queue()
+
+    # (the id comes from a process that has the loopback library set: this process keeps the real RCCL for the other tests)
+    idp = ctx.Process(target=_make_fake_id, args=(world, FAKE_RCCL, q0))
+    idp.start()
+    idb = q0.get(timeout=120)
+    idp.join(timeout=60)
+    assert isinstance(idb, bytes) and msdist.id_transport(idb) == msdist.RCCL, idb
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_rccl, args=(r, world, idb, FAKE_RCCL, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert got == {r: "ok" for r in range(world)}, got
+
+
+def _make_fake_id(world, fake_lib, q):
+    try:
+        import msdist
+        msdist.set_rccl_library(fake_lib)
+        q.put(msdist.unique_id(world, msdist.RCCL))
+    except Exception as e:      # noqa: BLE001
+        q.put(repr(e))
 
 
 def test_rccl_branch_full_size_config2_over_the_loopback_library(cuda):
     """BASELINE configs[3]'s shape at full size: 6 x 1080p -> 3840 x 1920, 4 frame-parallel ranks, 3.6 MB I420 slabs per frame through ncclSend / ncclRecv."""
     one = run("--gpus", 1, "--frames", 16, "--batch", 4, rig="cfg2")
-    res = run(*fake(4), "--frames", 16, "--batch", 2, rig="cfg2")
+    res = run(*fake(4), "--frames", 16, "--batch", 2, rig="cfg2", env=FAKE_ENV)
     assert _is_fake_rccl(res, 4) and res["checksum_all"] == one["checksum_all"]

@@ -151,6 +151,8 @@ struct ms_dist {
     ms::ncclComm_t comm = nullptr;
     void *stage = nullptr;            // device staging for host-memory payloads (headers, meshes)
     size_t stage_cap = 0;
+    std::vector<void *> stage_retired;   // outgrown staging buffers, released by ms_dist_destroy: hipFree synchronises the whole device, and a rank must not wait for
+                                         // the device inside a collective (its peers' transfers may be waiting for this rank's half)
     // HOST
     ms::ShmHeader *shm = nullptr;
     size_t shm_len = 0;
@@ -312,9 +314,9 @@ int host_attach(ms_dist *d, const DistId &id)
 int stage_get(ms_dist *d, size_t n, void **out)
 {
     if (n > d->stage_cap) {
-        if (d->stage) (void)hipFree(d->stage);
+        if (d->stage) d->stage_retired.push_back(d->stage);
         d->stage = nullptr; d->stage_cap = 0;
-        const size_t want = (n + 65535) & ~(size_t)65535;
+        const size_t want = std::max<size_t>((n + 65535) & ~(size_t)65535, (size_t)1 << 20);
         MS_HIP(hipMalloc(&d->stage, want));
         d->stage_cap = want;
     }
@@ -340,11 +342,19 @@ int rccl_attach(ms_dist *d, const DistId &id)
     void *st;
     if (int e = stage_get(d, sizeof(RankInfo) * (size_t)(d->nranks + 1), &st)) return e;
     RankInfo *dev_all = static_cast<RankInfo *>(st), *dev_me = dev_all + d->nranks;
-    MS_HIP(hipMemcpy(dev_me, &me, sizeof(me), hipMemcpyHostToDevice));
-    MS_NCCL(R.AllGather(dev_me, dev_all, sizeof(RankInfo), ncclUint8, d->comm, nullptr));
-    MS_HIP(hipStreamSynchronize(nullptr));
+    // on a stream of its own: the NULL stream is shared by every thread of a process that drives this device, and it orders against every blocking stream
+    hipStream_t s0;
+    MS_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
     std::vector<RankInfo> all((size_t)d->nranks);
-    MS_HIP(hipMemcpy(all.data(), dev_all, sizeof(RankInfo) * (size_t)d->nranks, hipMemcpyDeviceToHost));
+    int err = MS_OK;
+    do {
+        if (hipMemcpyAsync(dev_me, &me, sizeof(me), hipMemcpyHostToDevice, s0) != hipSuccess || hipStreamSynchronize(s0) != hipSuccess) { err = fail(MS_ERR_HIP, "ms_dist: staging the rank record failed"); break; }
+        const int r_ = R.AllGather(dev_me, dev_all, sizeof(RankInfo), ncclUint8, d->comm, s0);
+        if (r_ != ncclSuccess) { err = fail(MS_ERR_COMM, "ncclAllGather at creation: %s", R.GetErrorString(r_)); break; }
+        if (hipMemcpyAsync(all.data(), dev_all, sizeof(RankInfo) * (size_t)d->nranks, hipMemcpyDeviceToHost, s0) != hipSuccess || hipStreamSynchronize(s0) != hipSuccess) { err = fail(MS_ERR_HIP, "ms_dist: reading the rank records failed"); break; }
+    } while (0);
+    (void)hipStreamDestroy(s0);
+    if (err) return err;
     for (int r = 0; r < d->nranks; ++r) { d->info.device[r] = all[(size_t)r].device; memcpy(d->info.pci_bus_id[r], all[(size_t)r].pci, 16); }
     return MS_OK;
 }
@@ -447,6 +457,7 @@ void ms_dist_destroy(ms_dist *d)
     if (!d) return;
     if (d->comm) (void)rccl().CommDestroy(d->comm);
     if (d->stage) (void)hipFree(d->stage);
+    for (void *p : d->stage_retired) (void)hipFree(p);
     if (d->shm) munmap(d->shm, d->shm_len);
     if (d->shm_name[0]) shm_unlink(d->shm_name);                     // rank 0 of an attach that failed (a peer never joined, a barrier timed out): nranks^2 MiB would stay in /dev/shm
     delete d;
