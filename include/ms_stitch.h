@@ -391,6 +391,15 @@ typedef struct ms_plan_stats {
 } ms_plan_stats;
 MS_API int ms_get_plan_stats(ms_ctx *ctx, ms_plan_stats *out);
 
+/* Which form of the remap kernels (a5: cuda::remap, cudawarping/src/cuda/remap.cu:56-86) the LAST ms_stitch* call of the context launched -- every form computes the
+ * same pixels; which one runs is a function of the context and of the frames handed over.  SHARED_*: the frames of a view have one row step (and, for ALIGNED, one
+ * address modulo 4), so a pixel's tap offset is built once for all frames of a call; PER_FRAME_*: they differ (e.g. per-frame ROI views of buffers of different
+ * pitch, an odd byte offset) and every frame builds its own; ALIGNED / UNALIGNED: 12-byte aligned tap windows or 8-byte unaligned ones (chosen from the rig's
+ * minification).  *stage1_kernel is MS_WARP_KERNEL_NONE without CPW.  Diagnostics for tests and profiles; no reference counterpart. */
+enum { MS_WARP_KERNEL_NONE = 0, MS_WARP_KERNEL_SIMPLE = 1, MS_WARP_KERNEL_SHARED_ALIGNED = 2, MS_WARP_KERNEL_SHARED_UNALIGNED = 3, MS_WARP_KERNEL_PER_FRAME_ALIGNED = 4,
+       MS_WARP_KERNEL_PER_FRAME_UNALIGNED = 5, MS_WARP_KERNEL_NV12 = 6, MS_WARP_KERNEL_LDS_STAGED = 7 };
+MS_API int ms_get_stitch_kernels(ms_ctx *ctx, int *warp_kernel, int *stage1_kernel);
+
 /* geometry read-back (top_/left_/bottom_/right_, x_tl_.., dst_roi_: blenders.hpp:143-175) */
 typedef struct ms_view_geom {
     ms_rect roi;                        /* corner + size of the warped view (warpRoi)        */

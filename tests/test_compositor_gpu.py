@@ -826,3 +826,85 @@ def test_nv12_direct_is_refused_where_it_does_not_apply(ms, cuda):
     with pytest.raises(ms.MsError):
         comp.stitch_nv12(nv, out8u=[torch.zeros((cfg["out_h"], cfg["out_w"], 3), dtype=torch.uint8, device="cuda")])
     comp.close()
+
+
+# ---- frames of one view that do NOT share row step / alignment: the per-frame forms of the remap kernels ---------------------------------
+# ms_stitch picks the shared-offset kernels (k_warp_s / k_stage1_s) when every frame of a view has the same row step and the same address modulo 4 -- what every
+# other test and the bench hand over.  A caller with per-frame ROI views of buffers of different pitch (cv::cuda::GpuMat ROIs: `data + y * step`, any step,
+# cuda_types.hpp:95-107) or byte-offset buffers lands in k_warp_t<., aligned>, k_warp_t<., unaligned> and the unshared k_stage1_t: same pixels
+# (cudawarping/src/cuda/remap.cu:56-86, border_interpolate.hpp:698-717), other address arithmetic.
+def _laid_out(frame_np, step_extra, offset):
+    """the frame in a flat device buffer with row step = w * 3 + step_extra, starting `offset` bytes in (torch allocations are 512-byte aligned: address mod 4 = offset mod 4)"""
+    h, w, _ = frame_np.shape
+    step = w * 3 + step_extra
+    flat = torch.full((offset + h * step + 64,), 201, dtype=torch.uint8, device="cuda")        # (201: a wrong read beyond a row shows)
+    v = flat[offset:offset + h * step].as_strided((h, w, 3), (step, 3, 1))
+    v.copy_(torch.from_numpy(np.ascontiguousarray(frame_np)).cuda())
+    assert v.data_ptr() % 4 == offset % 4 and v.stride(0) == step
+    return v
+
+
+def _layouts(kind, t):
+    if kind == "uniform":
+        return 0, 0
+    if kind == "steps":         # another row step in every frame, all 4-byte aligned
+        return 4 * (1 + t % 3) + (12 if t % 2 else 0), 4 * (t % 5)
+    if kind == "steps_odd":     # odd row steps: every ROW of a frame starts at another address modulo 4
+        return 1 + 2 * (t % 4), t % 4
+    assert kind == "offsets"    # one row step, the start addresses 0 / 1 / 2 / 3 modulo 4
+    return 8, (t % 4) if t else 0
+
+
+@pytest.mark.parametrize("rig,cpw,nf,expect", [
+    ("mini6", False, 2, "aligned"), ("mini6", False, 3, "aligned"), ("mini6", False, 32, "aligned"), ("mini6", True, 3, "aligned"), ("mini6", True, 32, "aligned"),
+    ("mini4", False, 3, None), ("mini4", True, 2, None), ("cfg2", False, 3, "aligned"), ("cfg2", True, 2, "aligned"), ("cfg5", False, 2, "unaligned")])
+def test_frames_with_unequal_row_step_or_alignment_take_the_per_frame_kernels(ms, cuda, oracle, rig, cpw, nf, expect):
+    comp, cfg, gains = make_rig(ms, rig, enable_cpw=cpw, max_frames=nf)
+    meshes = None
+    if cpw:
+        meshes = []
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            mx, my = synth.mesh(r.width, r.height, 10, 10, phase=0.2 * i, amp=4.0 if rig.startswith("mini") else 8.0)
+            comp.set_mesh(i, mx, my)
+            meshes.append(tuple(host(m) for m in comp.mesh_maps(i)))       # the dense maps of convertMeshesToMap (checked against the oracle's in test_tables_gpu.py)
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    n_sets = min(nf, 4)
+    sets = [[synth.frame(cfg["w"], cfg["h"], i, t) for i in range(cfg["n"])] for t in range(n_sets)]
+    results, kernels = {}, {}
+    for kind in ("uniform", "steps", "steps_odd", "offsets"):
+        frames = [[_laid_out(sets[t % n_sets][i], *_layouts(kind, t)) for i in range(cfg["n"])] for t in range(nf)]
+        outs = [torch.full(shape, -9, dtype=torch.int16, device=cuda) for _ in range(nf)]
+        comp.stitch(frames, out16s=outs)
+        torch.cuda.synchronize()
+        results[kind] = outs
+        kernels[kind] = comp.stitch_kernels()
+        del frames
+    # which kernels ran: the shared-offset forms for uniform frames, the per-frame forms otherwise (with CPW: the first remap; the mesh remap reads the context's own
+    # stage images and stays shared)
+    which = 1 if cpw else 0
+    assert kernels["uniform"][which].startswith("shared_"), kernels
+    if cpw:
+        assert all(k[0] == "shared_aligned" for k in kernels.values()), kernels
+    else:
+        assert all(k[1] == "none" for k in kernels.values()), kernels
+    # (uniform frames take the aligned shared form at every minification; which per-frame form a rig falls back to follows its minification: config 5 the unaligned one)
+    fb = kernels["steps"][which]
+    assert fb.startswith("per_frame_") and kernels["steps_odd"][which] == fb, kernels
+    al = fb[len("per_frame_"):]
+    assert expect is None or al == expect, kernels
+    # one row step, other start alignment: the aligned form needs the per-frame kernel; the unaligned form only needs equal steps and stays shared (the first CPW
+    # remap has no shared unaligned form)
+    assert kernels["offsets"][which] == ("per_frame_aligned" if al == "aligned" else ("per_frame_unaligned" if cpw else "shared_unaligned")), kernels
+    for kind in ("steps", "steps_odd", "offsets"):
+        for t in range(nf):
+            assert torch.equal(results[kind][t], results["uniform"][t]), (kind, t)
+    assert n_sets == 1 or not torch.equal(results["uniform"][0], results["uniform"][1])
+    # ... and against the oracle (full-size rigs: first and last frame; cfg5's oracle parity at full size is test_full_size_config5_and_config3_match_oracle)
+    if rig != "cfg5":
+        for t in (sorted({0, nf - 1}) if rig == "cfg2" else range(min(nf, n_sets))):
+            ref16, _ = run_oracle(oracle, comp, cfg, gains, sets[t % n_sets], meshes)
+            for kind in ("steps_odd", "offsets"):
+                assert np.array_equal(host(results[kind][t]), ref16), (kind, t)
+    comp.close()

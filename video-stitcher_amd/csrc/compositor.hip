@@ -1623,6 +1623,7 @@ struct ms_ctx {
     float feather_sharpness = -1.f;    // >= 0: single-band weights are FeatherBlender weight maps (ms_init_feather)
     DevBuf warp_tiles, stage1_tiles, down_tiles[MAX_LEVELS], blend_tiles[MAX_LEVELS];
     int n_stage1_tiles = 0, n_stage1_reachable = 0;
+    int last_warp_kernel = 0, last_stage1_kernel = 0;      // MS_WARP_KERNEL_* of the last ms_stitch (ms_get_stitch_kernels)
     ms_image fed[MAX_VIEWS] = {};      // ms_feed: the views of the frame being assembled (borrowed until ms_blend)
     unsigned fed_mask = 0;
     DevBuf masks_eff;                  // ms_update_mask: masks re-warped through the CPW mesh (same layout as `masks`)
@@ -3127,6 +3128,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     // k_warp_s / the shared form of k_stage1_t: every frame of a view with the same row step and the same address modulo 4 (then a pixel's aligned tap offset is one
     // 32-bit value for all frames of a lane).  True for any sane caller (frames of one camera in buffers of one shape); checked, not assumed.
     static const bool warp_shared_knob = dev_knob("MS_WARP_SHARED", 1) != 0;
+    c->last_warp_kernel = MS_WARP_KERNEL_SIMPLE; c->last_stage1_kernel = MS_WARP_KERNEL_NONE;      // (overwritten below by whichever tile kernel is launched)
     bool src_shared = warp_shared_knob && S.mode != 2;
     for (int i = N; i < F * N && src_shared; ++i)
         if (src.p[i]) src_shared = src.p[i % N] && src.step[i] == src.step[i % N] && (((uintptr_t)src.p[i] ^ (uintptr_t)src.p[i % N]) & 3) == 0;
@@ -3171,6 +3173,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
         else k_stage1_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
     } while (0)
+            c->last_stage1_kernel = MS_WARP_KERNEL_NV12;
             if (nv_al) { if (F == 1) MS_S1NV_LAUNCH(1, true); else MS_S1NV_LAUNCH(2, true); }
             else { if (F == 1) MS_S1NV_LAUNCH(1, false); else MS_S1NV_LAUNCH(2, false); }
 #undef MS_S1NV_LAUNCH
@@ -3190,21 +3193,32 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_s<MS_PROJ_CYLINDRICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
         else k_stage1_s<MS_PROJ_PLANE, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
     } while (0)
-            if (c->warp_aligned && src_shared) { if (s1_nf == 3) MS_S1S_LAUNCH(3); else MS_S1S_LAUNCH(2); }
-            else if (c->warp_aligned) { if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
-            else { if (s1_nf == 3) MS_S1_LAUNCH(false, 3); else MS_S1_LAUNCH(false, 2); }
+            if (c->warp_aligned && src_shared) { c->last_stage1_kernel = MS_WARP_KERNEL_SHARED_ALIGNED; if (s1_nf == 3) MS_S1S_LAUNCH(3); else MS_S1S_LAUNCH(2); }
+            else if (c->warp_aligned) { c->last_stage1_kernel = MS_WARP_KERNEL_PER_FRAME_ALIGNED; if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
+            else { c->last_stage1_kernel = MS_WARP_KERNEL_PER_FRAME_UNALIGNED; if (s1_nf == 3) MS_S1_LAUNCH(false, 3); else MS_S1_LAUNCH(false, 2); }
 #undef MS_S1_LAUNCH
 #undef MS_S1S_LAUNCH
         }
-        else
+        else {
+            c->last_stage1_kernel = MS_WARP_KERNEL_SIMPLE;
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
+        }
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
-        if (c->warp_tiled && c->cfg.debug_simple_kernels == 0 && warp_shared_knob && (c->stage_stride & 3) == 0)      // the stage images of a view: same pitch, same address modulo 4 in every frame
+        // the stage images of a view have the same pitch and the same address modulo 4 in every frame BY CONSTRUCTION (stage_stride is a multiple of 256): the mesh remap
+        // always takes the shared-offset form.  Its unshared twin (k_warp_t<CPW>) was unreachable in the shipped library and untested: dev-knob builds only.
+        if (c->warp_tiled && c->cfg.debug_simple_kernels == 0 && warp_shared_knob) {
+            MS_CHECK((c->stage_stride & 3) == 0, "internal: stage image stride %lld not a multiple of 4", c->stage_stride);
+            c->last_warp_kernel = MS_WARP_KERNEL_SHARED_ALIGNED;
             MS_WARP_S_LAUNCH(true, warp_nf(true), warp_lds, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
-        else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0)
+        }
+#ifdef MS_DEV_KNOBS
+        else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0) {
+            c->last_warp_kernel = MS_WARP_KERNEL_PER_FRAME_ALIGNED;
             MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, warp_nf(true))), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+        }
+#endif
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
                 vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
@@ -3224,10 +3238,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
         else k_warp_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
     } while (0)
+            c->last_warp_kernel = MS_WARP_KERNEL_NV12;
             if (nv_al) { if (F == 1) MS_NV12_LAUNCH(1, true); else MS_NV12_LAUNCH(2, true); }
             else { if (F == 1) MS_NV12_LAUNCH(1, false); else MS_NV12_LAUNCH(2, false); }
 #undef MS_NV12_LAUNCH
         } else if (staged) {
+            c->last_warp_kernel = MS_WARP_KERNEL_LDS_STAGED;
             const long long items = (long long)c->n_warp_tiles * F;
             const int grid = (int)std::min<long long>(items, (long long)c->n_cus * (160 * 1024 / (2 * WA_BUF_BYTES)));
             MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
@@ -3236,6 +3252,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             // (with shared offsets the aligned form wins at every minification measured: config 5 -- 2.7 x, k_warp_t's unaligned territory -- 757 -> 730 / 738 -> 699 us per 16 frames;
             //  the minification rule of build_plan still picks between k_warp_t's two forms when the frames do not share step and alignment)
             static const int force_al = dev_knob("MS_WARP_ALIGNED", -1);
+            c->last_warp_kernel = ((c->warp_aligned || force_al != 0) && src_shared) ? MS_WARP_KERNEL_SHARED_ALIGNED : c->warp_aligned ? MS_WARP_KERNEL_PER_FRAME_ALIGNED
+                                  : (src_steps_equal && F > 1 && dev_knob("MS_WARP_SHARED_U", 1)) ? MS_WARP_KERNEL_SHARED_UNALIGNED : MS_WARP_KERNEL_PER_FRAME_UNALIGNED;
             if ((c->warp_aligned || force_al != 0) && src_shared)
                 MS_WARP_S_LAUNCH(false, WARP_NF, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (c->warp_aligned)
@@ -3654,6 +3672,13 @@ int ms_get_band_cells(ms_ctx *c, int level, unsigned *owned, unsigned *exclusive
     MS_HIP(hipMemcpy(h.data(), src, h.size(), hipMemcpyDeviceToHost));
     *general = 0;
     for (uint8_t b : h) { if (b == 255) ++*general; else if (b == 254) ++*exclusive; else ++*owned; }
+    return MS_OK;
+}
+
+int ms_get_stitch_kernels(ms_ctx *c, int *warp_kernel, int *stage1_kernel)
+{
+    if (!c || !warp_kernel || !stage1_kernel) return fail(MS_ERR_INVALID, "null argument");
+    *warp_kernel = c->last_warp_kernel; *stage1_kernel = c->last_stage1_kernel;
     return MS_OK;
 }
 

@@ -99,7 +99,7 @@ EXPORTS = [
     "ms_get_pano_geom", "ms_get_maps", "ms_get_mask", "ms_get_weight_level", "ms_get_mesh_maps", "ms_stitch_timed",
     "ms_selftest_divide", "ms_selftest_divide_range", "ms_calib_copy", "ms_calib_read", "ms_mesh_triangle_masks", "ms_bgr_to_i420", "ms_calibrate_seam", "ms_nv12_to_bgr", "ms_partial_bytes", "ms_stitch_partial", "ms_stitch_finish", "ms_selftest_cvt_u8", "ms_init_feather", "ms_get_mesh_displacement", "ms_set_mesh_interp", "ms_feed", "ms_blend", "ms_update_mask",
     "ms_mesh_default_params", "ms_mesh_saliency", "ms_create_mesh", "ms_knn_match_hamming2", "ms_bgr_to_i420_batch", "ms_bgr_to_gray", "ms_stitch_i420", "ms_get_i420_rows", "ms_get_col_window", "ms_get_needed_views", "ms_consume_i420", "ms_resize_linear_batch", "ms_nv12_to_bgr_batch",
-    "ms_save_tables", "ms_load_tables", "ms_calib_shape", "ms_stitch_nv12", "ms_get_plan_stats",
+    "ms_save_tables", "ms_load_tables", "ms_calib_shape", "ms_stitch_nv12", "ms_get_plan_stats", "ms_get_stitch_kernels",
 ]
 
 _lib = None
@@ -744,6 +744,13 @@ class Compositor:
         a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
         _chk(load().ms_get_band_cells(self._ctx, level, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def stitch_kernels(self):
+        """(warp kernel, stage-1 kernel) of the last stitch call: ms_get_stitch_kernels, as names."""
+        names = {0: "none", 1: "simple", 2: "shared_aligned", 3: "shared_unaligned", 4: "per_frame_aligned", 5: "per_frame_unaligned", 6: "nv12", 7: "lds_staged"}
+        a, b = C.c_int(), C.c_int()
+        _chk(load().ms_get_stitch_kernels(self._ctx, C.byref(a), C.byref(b)))
+        return names[a.value], names[b.value]
 
     def plan_stats(self):
         """Work-list sizes of the context (ms_get_plan_stats) as a dict."""
