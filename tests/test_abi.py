@@ -115,3 +115,26 @@ def test_load_tables_refuses_garbage_before_touching_the_device(ms):
         b = (C.c_uint8 * max(1, len(blob))).from_buffer_copy(blob.ljust(1, b"\0"))
         rc = lib.ms_load_tables(b, C.c_size_t(len(blob)), C.byref(out), None)
         assert rc == -1 and not out.value, (rc, len(blob))      # MS_ERR_INVALID
+
+
+def test_no_v_ashr_pk_u8_i32_in_the_device_code(tmp_path):
+    """gfx950's v_ashr_pk_u8_i32 (two clamp((a >> s), 0, 255) packed into 16 bits) as ROCm 7.2's clang emits it: the v_or3_b32 that assembles the dword assumes the
+    result's upper 16 bits are zero, and on MI355X they are not -- round 5's first 8-pixel NV12 kernel wrote stray bits into every third byte (found by
+    tests/test_prims_gpu.py::test_nv12_to_bgr on the GPU; csrc/prims.hip nv12_px carries the workaround).  No GPU test can prove the ABSENCE of the pattern in kernels
+    whose tests do not happen to saturate, so the shipped code objects are disassembled here: the instruction must not occur anywhere."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "video-stitcher_amd", "libmsstitch.so")
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, "no gfx950 code object found in libmsstitch.so"
+    n_inst = 0
+    for f in objs:
+        dis = subprocess.run([objdump, "-d", f], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
+        n_inst += dis.count("\tv_")
+        assert "v_ashr_pk_u8_i32" not in dis and "v_ashr_pk_i8_i32" not in dis, f
+    assert n_inst > 10000      # (the disassembly really is the kernels)

@@ -49,12 +49,15 @@ def timed(fn, n=20):
     return float(np.median(ts))
 
 
+conv_run = ms.nv12_to_bgr_batch_prepared(flat_nv, flat_bgr)      # (descriptors marshalled once, like run_a / run_b)
+
+
 def path_a():
-    ms.nv12_to_bgr_batch(flat_nv, flat_bgr)
+    conv_run()
     run_a()
 
 
-conv = timed(lambda: ms.nv12_to_bgr_batch(flat_nv, flat_bgr))
+conv = timed(conv_run)
 a = timed(path_a)
 b = timed(run_b)
 torch.cuda.synchronize()

@@ -762,7 +762,7 @@ int launch_build_warp_maps(int proj, int tl_u, int tl_v, ms_image &mx, ms_image 
 
 // ------------------------------------------------------------------------------------------------
 // cvtColor(COLOR_YUV2BGR_NV12)  [imgproc/src/color.cpp:8738-8745 + YUV420sp2RGB888Invoker<0,0>]: the per-camera ingest the
-// reference does on the CPU (APP/networking.cpp:45-47).  One lane = 2 rows x 4 pixels: two 4-byte Y loads, one 4-byte UV load.
+// reference does on the CPU (APP/networking.cpp:45-47).  nv12_to_bgr_cell: 2 rows x 4 pixels, byte accesses (remainders, unaligned buffers); the hot form is nv12_to_bgr_cell8 below.
 __device__ __forceinline__ void nv12_to_bgr_cell(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep, int x, int y)
 {
     constexpr int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
@@ -786,36 +786,85 @@ __device__ __forceinline__ void nv12_to_bgr_cell(const uint8_t *__restrict__ src
         }
     }
 }
-__global__ void __launch_bounds__(256) k_nv12_to_bgr(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep)
+// Round 5: one lane = 2 rows x 8 pixels (the 2 x 4 form with twelve single-byte stores per lane and row ran at 1.2 TB/s).  Two 8-byte Y windows and one
+// 8-byte UV window in, 2 x 24 bytes out as three dword pairs per row: a wave reads 512 contiguous bytes per plane row and writes 1536 contiguous bytes per image row.
+// The chroma terms of a 2 x 2 block are built once.  Same integer formula, evaluated per pixel exactly as nv12_to_bgr_cell does (which stays for the right-hand
+// remainder of widths that are not multiples of 8 and for buffers that are not 4-byte aligned).
+// (the empty asm keeps clang from fusing two neighbouring clamp((a >> 20), 0, 255) into v_ashr_pk_u8_i32: as emitted by ROCm 7.2's clang for gfx950 the result's upper 16 bits
+//  are assumed zero by the v_or3_b32 that packs the dword, and on MI355X they are not -- stray bits in every third byte, found by tests/test_prims_gpu.py::test_nv12_to_bgr;
+//  tests/test_abi.py::test_no_v_ashr_pk_u8_i32_in_the_device_code guards the whole library)
+__device__ __forceinline__ unsigned nv12_px(int yy, int c) { constexpr int SH = 20; int v = min(max((yy + c) >> SH, 0), 255); asm volatile("" : "+v"(v)); return (unsigned)v; }
+__device__ __forceinline__ void nv12_to_bgr_cell8(const uint8_t *__restrict__ src, size_t sstep, int h, uint8_t *__restrict__ dst, size_t dstep, int x, int y)
 {
-    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
-    if (x >= w || y >= h) return;
+    constexpr int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
+    uint2 yw[2], uvw;
+    __builtin_memcpy(&yw[0], __builtin_assume_aligned(src + (size_t)y * sstep + x, 4), 8);
+    __builtin_memcpy(&yw[1], __builtin_assume_aligned(src + (size_t)(y + 1) * sstep + x, 4), 8);
+    __builtin_memcpy(&uvw, __builtin_assume_aligned(src + (size_t)(h + y / 2) * sstep + x, 4), 8);
+    int ruv[4], guv[4], buv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned w2 = p < 2 ? uvw.x : uvw.y;
+        const int u = (int)((w2 >> (16 * (p & 1))) & 255u) - 128, v = (int)((w2 >> (16 * (p & 1) + 8)) & 255u) - 128;
+        ruv[p] = (1 << (SH - 1)) + CVR * v; guv[p] = (1 << (SH - 1)) + CVG * v + CUG * u; buv[p] = (1 << (SH - 1)) + CUB * u;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        unsigned px[8][3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned w2 = k < 4 ? yw[r].x : yw[r].y;
+            const int yy = max(0, (int)((w2 >> (8 * (k & 3))) & 255u) - 16) * CY;
+            px[k][0] = nv12_px(yy, buv[k >> 1]); px[k][1] = nv12_px(yy, guv[k >> 1]); px[k][2] = nv12_px(yy, ruv[k >> 1]);
+        }
+        unsigned o[6];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {      // 4 pixels = 12 bytes = 3 dwords: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+            const int k = 4 * q;
+            o[3 * q] = px[k][0] | (px[k][1] << 8) | (px[k][2] << 16) | (px[k + 1][0] << 24);
+            o[3 * q + 1] = px[k + 1][1] | (px[k + 1][2] << 8) | (px[k + 2][0] << 16) | (px[k + 2][1] << 24);
+            o[3 * q + 2] = px[k + 2][2] | (px[k + 3][0] << 8) | (px[k + 3][1] << 16) | (px[k + 3][2] << 24);
+        }
+        __builtin_memcpy(__builtin_assume_aligned(dst + (size_t)(y + r) * dstep + (size_t)x * 3, 4), o, 24);
+    }
+}
+__device__ __forceinline__ void nv12_to_bgr_lane(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep, bool aligned)
+{
+    const unsigned cells_x = (unsigned)(w + 7) >> 3, id = blockIdx.x * 256u + threadIdx.x, yy = id / cells_x, cx = id - yy * cells_x;
+    const int x = 8 * (int)cx, y = 2 * (int)yy;
+    if (y >= h) return;
+    if (aligned && x + 8 <= w) { nv12_to_bgr_cell8(src, sstep, h, dst, dstep, x, y); return; }
     nv12_to_bgr_cell(src, sstep, w, h, dst, dstep, x, y);
+    if (x + 4 < w) nv12_to_bgr_cell(src, sstep, w, h, dst, dstep, x + 4, y);
+}
+__global__ void __launch_bounds__(256) k_nv12_to_bgr(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, size_t dstep, bool aligned)
+{
+    nv12_to_bgr_lane(src, sstep, w, h, dst, dstep, aligned);
 }
 // every camera of a frame in one launch (the capture threads' per-camera cvtColor, networking.cpp:45-47)
 constexpr int NV12_BATCH = 64;
 struct Nv12Batch { const uint8_t *src[NV12_BATCH]; uint8_t *dst[NV12_BATCH]; };
-__global__ void __launch_bounds__(256) k_nv12_to_bgr_batch(Nv12Batch T, size_t sstep, int w, int h, size_t dstep)
+__global__ void __launch_bounds__(256) k_nv12_to_bgr_batch(Nv12Batch T, size_t sstep, int w, int h, size_t dstep, bool aligned)
 {
-    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
-    if (x >= w || y >= h) return;
-    nv12_to_bgr_cell(T.src[blockIdx.z], sstep, w, h, T.dst[blockIdx.z], dstep, x, y);
+    nv12_to_bgr_lane(T.src[blockIdx.y], sstep, w, h, T.dst[blockIdx.y], dstep, aligned);
 }
+static unsigned nv12_grid(int w, int h) { return (unsigned)div_up((long long)((w + 7) >> 3) * (h / 2), 256); }
 int launch_nv12_to_bgr_batch(const ms_image *src, ms_image *dst, int n, hipStream_t st)
 {
     for (int i0 = 0; i0 < n; i0 += NV12_BATCH) {
         const int m = std::min(NV12_BATCH, n - i0);
         Nv12Batch T{};
-        for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; }
-        k_nv12_to_bgr_batch<<<dim3(div_up(div_up(dst[0].cols, 4), BX), div_up(dst[0].rows / 2, BY), m), dim3(BX, BY), 0, st>>>(T, src[0].step, dst[0].cols, dst[0].rows, dst[0].step);
+        size_t bits = src[0].step | dst[0].step;
+        for (int i = 0; i < m; ++i) { T.src[i] = (const uint8_t *)src[i0 + i].data; T.dst[i] = (uint8_t *)dst[i0 + i].data; bits |= (size_t)T.src[i] | (size_t)T.dst[i]; }
+        k_nv12_to_bgr_batch<<<dim3(nv12_grid(dst[0].cols, dst[0].rows), m), dim3(256), 0, st>>>(T, src[0].step, dst[0].cols, dst[0].rows, dst[0].step, (bits & 3) == 0);
         MS_LAUNCH_CHECK();
     }
     return MS_OK;
 }
 int launch_nv12_to_bgr(const ms_image &src, ms_image &dst, hipStream_t st)
 {
-    k_nv12_to_bgr<<<dim3(div_up(div_up(dst.cols, 4), BX), div_up(dst.rows / 2, BY)), dim3(BX, BY), 0, st>>>(
-        (const uint8_t *)src.data, src.step, dst.cols, dst.rows, (uint8_t *)dst.data, dst.step);
+    const size_t bits = src.step | dst.step | (size_t)src.data | (size_t)dst.data;
+    k_nv12_to_bgr<<<dim3(nv12_grid(dst.cols, dst.rows)), dim3(256), 0, st>>>((const uint8_t *)src.data, src.step, dst.cols, dst.rows, (uint8_t *)dst.data, dst.step, (bits & 3) == 0);
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
