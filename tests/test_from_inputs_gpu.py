@@ -67,8 +67,9 @@ def oracle_from_inputs(O, proj, Ks, Rs, scale, w, h, frames, gains, num_bands, m
     return rois, maps, masks, out, mask
 
 
-def compare(name, got16, got_mask, ref16, ref_mask, view_mask_diffs, halo, extra=None, max_excluded=0.02):
-    """the statistics + the reference's own criterion"""
+def compare(name, got16, got_mask, ref16, ref_mask, view_mask_diffs, halo, extra=None, max_excluded=0.02, max_view_mask_flips=None):
+    """the statistics + the reference's own criterion.  max_view_mask_flips: the COUNT of view-mask pixels that may differ between the device-built and the oracle-built
+    masks of a fixed rig: the exclusion zone below must not be able to hide a regression of the map builder."""
     assert got16.shape == ref16.shape and got_mask.shape == ref_mask.shape
     mask_diff = got_mask != ref_mask
     # pixels within the blend support of a differing mask pixel may legitimately differ by more (a seam that moved by a pixel): excluded and counted
@@ -84,6 +85,8 @@ def compare(name, got16, got_mask, ref16, ref_mask, view_mask_diffs, halo, extra
                  hist_0_to_8plus=[int(x) for x in hist], exact_fraction=float(hist[0]) / max(1, int(common.sum())))
     stats.update(extra or {})
     record(name, stats)
+    if max_view_mask_flips is not None:
+        assert stats["view_mask_diff_px"] <= max_view_mask_flips, stats
     assert stats["max_diff_far"] <= 3, stats                                        # test_blenders.cuda.cpp:90
     assert stats["result_mask_diff_px"] <= 2e-4 * common.size, stats                # masks equal except a few border / seam pixels
     assert stats["excluded_px"] <= max_excluded * common.size, stats
@@ -130,8 +133,11 @@ def test_spherical_rig_from_camera_parameters(ms, cuda, oracle, rig):
     vdiff = view_mask_diff_in_pano(rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
     # 12 x 4K: 49 k border pixels of the valid-warp masks, map coordinates within 1e-3 px of the oracle's: a few dozen of them round to the other side of an image edge
     # (95 observed), and the 96-px blend support around each is excluded from the |diff| <= 3 criterion -- 2.2 % of the panorama there, nothing on the 1080p rigs
+    # "pixel-for-pixel on integer masks" holds GIVEN THE SAME libm: the valid-warp masks are (int) truncations of sinf / cosf / atan2f results, and the device's
+    # functions differ from glibc's in the last ulps.  On the 1080p rigs no mask pixel flips (asserted: 0); on 12 x 4K exactly 95 of 49 k border pixels do
+    # (DESIGN.md section 2); the RESULT mask is identical everywhere (compare() asserts that for every rig).
     compare(rig + "_spherical", host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb, extra={"max_map_diff_px": worst},
-            max_excluded=0.04 if rig == "cfg5" else 0.02)
+            max_excluded=0.04 if rig == "cfg5" else 0.02, max_view_mask_flips=95 if rig == "cfg5" else 0)
     comp.close()
 
 
@@ -161,7 +167,7 @@ def test_spherical_rig_with_cpw_from_camera_parameters(ms, cuda, oracle, rig, nm
     rois, maps, masks, ref16, ref_mask = oracle_from_inputs(oracle, ms.PROJ_SPHERICAL, [c[0] for c in cams], [c[1] for c in cams], scale, w, h, frames, gains, nb, meshes=meshes)
     assert rois == [comp.view_geom(i).roi.tuple() for i in range(n)]
     vdiff = view_mask_diff_in_pano(rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
-    compare(rig + "_spherical_cpw_%dx%d" % nm, host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb)
+    compare(rig + "_spherical_cpw_%dx%d" % nm, host(out16), host(comp.result_mask()), ref16, ref_mask, vdiff, halo=3 * 2 ** nb, max_view_mask_flips=0)
     comp.close()
 
 
@@ -252,6 +258,7 @@ def test_shipped_configuration_from_camera_parameters(ms, cuda, oracle, size):
     vdiff = view_mask_diff_in_pano(c_rois, pg.dst_roi_final.tuple(), [host(comp.mask(i)) for i in range(n)], masks)
     # the masks are GREY along the seams here (bilinear upsizing of the seam-scale masks): a differing seam-scale mask pixel moves a whole 1 / seam_scale block
     name = "shipped_%dx%d" % (w, h)
+    assert int(vdiff.sum()) == 0, "view-mask pixels flipped on the shipped rig: %d (0 observed on MI355X since round 3)" % int(vdiff.sum())
     mask_diff = host(comp.result_mask()) != ref_mask
     d = np.abs(host(out16).astype(np.int32) - ref16.astype(np.int32)).max(axis=2)
     common = (host(comp.result_mask()) != 0) & (ref_mask != 0)
