@@ -155,15 +155,18 @@ __device__ __forceinline__ uint4 load16_a4(const void *p)
 // The coarse levels are tiny (config 2: 148x80 and smaller): a launch per level is pure latency.  Level l0 is copied into LDS as
 // bytes (every Gaussian value is in [0,255]), each further level is computed LDS -> LDS and also stored to the pyramid
 // buffer for the band kernels.  Same exact integer arithmetic as k_down.
-// Wide views are cut into strips of TAIL_STRIP columns of the coarsest level; a strip recomputes the few halo columns it needs
-// at the intermediate levels and stores only the columns it owns.
-constexpr int TAIL_STRIP = 16;
-__host__ __device__ inline void tail_range(const int *w, int l0, int nb, int strip, int *a, int *b)
+// Wide views are cut into strips of `sw` columns of the coarsest level; a strip recomputes the few halo columns it needs
+// at the intermediate levels and stores only the columns it owns.  sw = TAIL_STRIP (16) for one or two frames per call, where the launch has to be spread over
+// the chip; TAIL_STRIP_BATCH (64: a whole ordinary view per workgroup) for batches (round 5): with 16-column strips a 32-frame launch was 2 208 workgroups of
+// 1.5 KB each, every one of them a chain of cold round trips and barriers -- 45 us at 1 TB/s; a third of the workgroups with three times the work per step
+// finish in one round of the chip.
+constexpr int TAIL_STRIP = 16, TAIL_STRIP_BATCH = 64;
+__host__ __device__ inline void tail_range(const int *w, int l0, int nb, int strip, int sw, int *a, int *b)
 {
-    a[nb] = strip * TAIL_STRIP; b[nb] = min(a[nb] + TAIL_STRIP, w[nb]);
+    a[nb] = strip * sw; b[nb] = min(a[nb] + sw, w[nb]);
     for (int l = nb - 1; l >= l0; --l) { a[l] = max(2 * a[l + 1] - 2, 0); b[l] = min(2 * b[l + 1] + 2, w[l]); }
 }
-__global__ void __launch_bounds__(1024) k_down_tail(const ViewDesc *__restrict__ views, int n_views, int l0, int nb, int max_strips,
+__global__ void __launch_bounds__(1024) k_down_tail(const ViewDesc *__restrict__ views, int n_views, int l0, int nb, int max_strips, int sw,
                                                    uint8_t *__restrict__ gl, long long gl_stride, unsigned own_mask)
 {
     extern __shared__ uint8_t s_lv[];
@@ -173,8 +176,8 @@ __global__ void __launch_bounds__(1024) k_down_tail(const ViewDesc *__restrict__
     const ViewDesc &V = views[v];
     int w[MAX_LEVELS + 1], a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
     for (int l = l0; l <= nb; ++l) w[l] = V.lv[l].w;
-    if (strip * TAIL_STRIP >= w[nb]) return;
-    tail_range(w, l0, nb, strip, a, b);
+    if (strip * sw >= w[nb]) return;
+    tail_range(w, l0, nb, strip, sw, a, b);
     uint8_t *base = gl + (size_t)f * gl_stride;
     const int tx = threadIdx.x, ty = threadIdx.y;           // block 64 x 4 (64 x 16 in live mode: the same strip on four times the lanes)
     const int nthr = (int)(blockDim.x * blockDim.y);
@@ -212,8 +215,8 @@ __global__ void __launch_bounds__(1024) k_down_tail(const ViewDesc *__restrict__
         uint8_t *out = base + Lo.off + (size_t)c * Lo.h * Lo.pitch;
         const bool big = Li.h >= 3 && Li.w >= 3;           // |overshoot| <= 2 < len: BORDER_REFLECT_101 without the integer modulo
         const int lr = Li.h - 1, lc = Li.w - 1;
-        const int own_a = min((strip * TAIL_STRIP) << (nb - l - 1), Lo.w);
-        const int own_b = (strip * TAIL_STRIP + TAIL_STRIP >= w[nb]) ? Lo.w : min(((strip + 1) * TAIL_STRIP) << (nb - l - 1), Lo.w);
+        const int own_a = min((strip * sw) << (nb - l - 1), Lo.w);
+        const int own_b = (strip * sw + sw >= w[nb]) ? Lo.w : min(((strip + 1) * sw) << (nb - l - 1), Lo.w);
         // flat index over the strip's outputs: every lane works (strips are only 16..40 columns wide); i -> (y, xo) with one fp32
         // multiply: (i + 0.5) / wo is at least 0.5 / 64 away from an integer, far more than the fp32 error for i < 2^16
         const float rwo = 1.0f / (float)wo;
@@ -1616,6 +1619,7 @@ struct ms_ctx {
     // work lists (tiles that are actually needed)
     bool warp_tiled = false;
     int tail_l0 = -1, tail_lds = 0, tail_strips = 1;
+    int tail_lds_b = 0, tail_strips_b = 1, tail_sw_b = 16;      // k_down_tail for batches (F > 2): wider strips
     // the fused band kernel started one band finer: used for batches of 1-2 frames (live mode), where a launch costs more than the
     // vectorised kernel saves
     int btail2_t = -1, btail2_lds = 0, btail2_strips = 0;
@@ -2379,17 +2383,17 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
     {   // coarse levels that the tile kernel cannot take (width not a multiple of 8) go to one fused launch if a plane chain fits in LDS
         int t0 = 0;
         while (t0 < nb && c->down_vec[t0]) ++t0;
-        auto plan_tail = [&](int l0, int *out_l0, int *out_lds, int *out_strips) {
+        auto plan_tail = [&](int l0, int sw, int *out_l0, int *out_lds, int *out_strips) {
             *out_l0 = -1; *out_lds = 0; *out_strips = 1;
             if (l0 < 1 || l0 >= nb) return;          // level l0 is int16 (l0 >= 1); the u8 level 0 never starts a tail
             int need = 0, strips = 1;
             for (int v = 0; v < N; ++v) {
                 int w[MAX_LEVELS + 1], a[MAX_LEVELS + 1], b[MAX_LEVELS + 1];
                 for (int l = l0; l <= nb; ++l) w[l] = c->h_views[v].lv[l].w;
-                const int ns = div_up(w[nb], TAIL_STRIP);
+                const int ns = div_up(w[nb], sw);
                 strips = std::max(strips, ns);
                 for (int sidx = 0; sidx < ns; ++sidx) {
-                    tail_range(w, l0, nb, sidx, a, b);
+                    tail_range(w, l0, nb, sidx, sw, a, b);
                     int bytes = 0;
                     for (int l = l0; l <= nb; ++l) bytes += ((b[l] - a[l]) * c->h_views[v].lv[l].h + 15) & ~15;
                     need = std::max(need, bytes);
@@ -2397,7 +2401,10 @@ int ms_init_blender(ms_ctx *c, ms_stream stream)
             }
             if (need <= 64 * 1024) { *out_l0 = l0; *out_lds = need; *out_strips = strips; }
         };
-        plan_tail(t0, &c->tail_l0, &c->tail_lds, &c->tail_strips);
+        plan_tail(t0, TAIL_STRIP, &c->tail_l0, &c->tail_lds, &c->tail_strips);
+        int l0b = -1;
+        plan_tail(t0, TAIL_STRIP_BATCH, &l0b, &c->tail_lds_b, &c->tail_strips_b);      // the batch form (wide strips); falls back to the narrow one where a wide strip does not fit LDS
+        if (l0b != c->tail_l0) { c->tail_lds_b = c->tail_lds; c->tail_strips_b = c->tail_strips; c->tail_sw_b = TAIL_STRIP; } else c->tail_sw_b = TAIL_STRIP_BATCH;
     }
     for (int l = 0; l < nb; ++l) {
         int qw = c->bg.dst_roi.width >> l, qh = c->bg.dst_roi.height >> l;
@@ -3276,10 +3283,12 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     MS_LAUNCH_CHECK();
     if (int e = mark("k_warp")) return e;
 
-    const int dt_l0 = c->tail_l0, dt_lds = c->tail_lds, dt_strips = c->tail_strips;     // (starting the reduce tail a level finer was measured slower even for one frame)
+    static const int tail_sw_knob = dev_knob("MS_TAIL_SW", 0);      // A/B: force the strip width of the reduce tail (16 = the round-4 form)
+    const bool dt_wide = F > 2 && tail_sw_knob != TAIL_STRIP;
+    const int dt_l0 = c->tail_l0, dt_lds = dt_wide ? c->tail_lds_b : c->tail_lds, dt_strips = dt_wide ? c->tail_strips_b : c->tail_strips, dt_sw = dt_wide ? c->tail_sw_b : TAIL_STRIP;     // (starting the reduce tail a level finer was measured slower even for one frame)
     for (int l = 0; l < nb; ++l) {
         if (l == dt_l0 && c->cfg.debug_simple_kernels == 0) {
-            k_down_tail<<<dim3(F * N * 3 * dt_strips), F <= 2 ? dim3(64, 16) : blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, gl, c->gl_stride, c->own_mask & c->needed_mask);
+            k_down_tail<<<dim3(F * N * 3 * dt_strips), (F <= 2 || dt_sw > TAIL_STRIP) ? dim3(64, 16) : blk, dt_lds, st>>>(vt, N, l, nb, dt_strips, dt_sw, gl, c->gl_stride, c->own_mask & c->needed_mask);
             MS_LAUNCH_CHECK();
             if (int e = mark("k_down_tail")) return e;
             break;
