@@ -793,7 +793,7 @@ __device__ __forceinline__ void nv12_to_bgr_cell(const uint8_t *__restrict__ src
 // (the empty asm keeps clang from fusing two neighbouring clamp((a >> 20), 0, 255) into v_ashr_pk_u8_i32: as emitted by ROCm 7.2's clang for gfx950 the result's upper 16 bits
 //  are assumed zero by the v_or3_b32 that packs the dword, and on MI355X they are not -- stray bits in every third byte, found by tests/test_prims_gpu.py::test_nv12_to_bgr;
 //  tests/test_abi.py::test_no_v_ashr_pk_u8_i32_in_the_device_code guards the whole library)
-__device__ __forceinline__ unsigned nv12_px(int yy, int c) { constexpr int SH = 20; int v = min(max((yy + c) >> SH, 0), 255); asm volatile("" : "+v"(v)); return (unsigned)v; }
+__device__ __forceinline__ unsigned nv12_px(int yy, int c) { constexpr int SH = 20; int v = min(max((yy + c) >> SH, 0), 255); asm("" : "+v"(v)); return (unsigned)v; }
 __device__ __forceinline__ void nv12_to_bgr_cell8(const uint8_t *__restrict__ src, size_t sstep, int h, uint8_t *__restrict__ dst, size_t dstep, int x, int y)
 {
     constexpr int SH = 20, CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527;
@@ -902,6 +902,9 @@ int launch_bgr_to_gray(const ms_image &src, ms_image &dst, hipStream_t st)
 // cvtColor(COLOR_BGR2YUV_I420)  [imgproc/src/color.cpp:8745-8756, 9082-9160]: BT.601 fixed point (shift 20), chroma from
 // the top-left pixel of each 2x2 block, planar I420 output.  One lane = 2 rows x 4 pixels (12-byte row loads).
 __device__ __forceinline__ uint8_t clamp_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
+// the same behind an empty asm, for code that packs neighbouring clamp((a >> 20), 0, 255) into one word: they must not be fused into gfx950's v_ashr_pk_u8_i32 (see nv12_px;
+// tests/test_abi.py disassembles the library for it).  Not used where the compiler does not form the pattern: the barrier costs bgr_to_i420_cell8 its byte-insert packing (2 x slower)
+__device__ __forceinline__ unsigned clamp_u8_opaque(int v) { int r = min(max(v, 0), 255); asm("" : "+v"(r)); return (unsigned)r; }
 constexpr int I420_BATCH = 64;
 __device__ __forceinline__ void bgr_to_i420_cell(const uint8_t *__restrict__ src, size_t sstep, int w, int h, uint8_t *__restrict__ dst, int x, int y)
 {
@@ -1008,12 +1011,103 @@ __global__ void __launch_bounds__(256) k_consume_i420(const uint8_t *__restrict_
             }
         }
 }
+// Round 5: one lane = 2 rows x 4 pixels of the frame (two 2 x 2 chroma blocks).  The two BGR pixels of a tap row are ONE unaligned 8-byte read (as in the remap kernels:
+// 16 reads per lane instead of 96 byte reads), the four luma bytes of a row leave as one dword, the two chroma samples of each plane as one 16-bit store.  Same fp32
+// expressions in the same order as k_consume_i420 above (which stays for frame widths that are not multiples of 4); a pixel whose 8-byte window would leave its source
+// row (the last two source columns) takes the per-byte taps with the clamped x2.  The rig's 3840 x 1920 canvas -> 4096 x 2048: 35 us at 1.2 TB/s before (profiles/r05_f3_report.md).
+typedef unsigned pr_u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+__device__ __forceinline__ uint2 gload8_at(const uint8_t *base, unsigned off)      // uniform base + 32-bit lane offset, global address space (one VGPR of address, no 64-bit multiply-add)
+{
+    const pr_u32x2_a1 v = *(const __attribute__((address_space(1))) pr_u32x2_a1 *)(uintptr_t)(base + off);
+    return make_uint2(v.x, v.y);
+}
+__global__ void __launch_bounds__(256) k_consume_i420_x4(const uint8_t *__restrict__ src, unsigned sstep, int srows, int scols, uint8_t *__restrict__ dst,
+                                                         int out_w, int out_h, int ih, int y_off, float ify, float ifx)
+{
+    const int x = 4 * (blockIdx.x * BX + threadIdx.x), y = 2 * (blockIdx.y * BY + threadIdx.y);
+    if (x >= out_w || y >= out_h) return;
+    constexpr int SH = 20, HALF = 1 << (SH - 1);
+    constexpr int CRY = 269484, CGY = 528482, CBY = 102760, CRU = -155188, CGU = -305135, CBU = 460324, CGV = -385875, CBV = -74448;
+    uint8_t *Y = dst, *U = dst + (size_t)out_w * out_h, *V = U + (size_t)(out_w / 2) * (out_h / 2);
+    float sx[4], wx1[4], wx2[4];
+    int x1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sx[k] = (float)(x + k) * ifx; x1[k] = f2i_rd(sx[k]); wx2[k] = (float)(x1[k] + 1) - sx[k]; wx1[k] = sx[k] - (float)x1[k]; }
+    // the lane's four pixels sample non-decreasing source columns: if the last one's 8-byte window stays inside its row, all do (one branch per lane and row, not per pixel)
+    const bool lane_fast = x1[3] <= scols - 3 && x1[0] >= 0;
+    unsigned uq = 0, vq = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int yy = y + r - y_off;
+        unsigned yq = 0;
+        if (yy >= 0 && yy < ih) {
+            const float sy = (float)yy * ify;
+            const int y1 = f2i_rd(sy), y2 = y1 + 1, y2r = min(y2, srows - 1);
+            const float wy2 = (float)y2 - sy, wy1 = sy - (float)y1;
+            int px[4][3];
+            if (lane_fast) {
+                const unsigned o1 = (unsigned)y1 * sstep, o2 = (unsigned)y2r * sstep;
+                uint2 a[4], b[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] = gload8_at(src, o1 + 3u * (unsigned)x1[k]); b[k] = gload8_at(src, o2 + 3u * (unsigned)x1[k]); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float w11 = wx2[k] * wy2, w12 = wx1[k] * wy2, w21 = wx2[k] * wy1, w22 = wx1[k] * wy1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float out = 0.f;
+                        out = __builtin_fmaf(rs_byte(a[k].x, a[k].y, c), w11, out);
+                        out = __builtin_fmaf(rs_byte(a[k].x, a[k].y, 3 + c), w12, out);
+                        out = __builtin_fmaf(rs_byte(b[k].x, b[k].y, c), w21, out);
+                        out = __builtin_fmaf(rs_byte(b[k].x, b[k].y, 3 + c), w22, out);
+                        px[k][c] = sat_u8(out);
+                    }
+                }
+            } else {
+                const uint8_t *r1 = src + (size_t)y1 * sstep, *r2 = src + (size_t)y2r * sstep;
+                for (int k = 0; k < 4; ++k) {
+                    const int x2r = min(x1[k] + 1, scols - 1);
+                    const float w11 = wx2[k] * wy2, w12 = wx1[k] * wy2, w21 = wx2[k] * wy1, w22 = wx1[k] * wy1;
+                    for (int c = 0; c < 3; ++c) {
+                        float out = 0.f;
+                        out = __builtin_fmaf((float)r1[(size_t)x1[k] * 3 + c], w11, out);
+                        out = __builtin_fmaf((float)r1[(size_t)x2r * 3 + c], w12, out);
+                        out = __builtin_fmaf((float)r2[(size_t)x1[k] * 3 + c], w21, out);
+                        out = __builtin_fmaf((float)r2[(size_t)x2r * 3 + c], w22, out);
+                        px[k][c] = sat_u8(out);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int bb = px[k][0], g = px[k][1], rr = px[k][2];
+                yq |= clamp_u8_opaque((CRY * rr + CGY * g + CBY * bb + HALF + (16 << SH)) >> SH) << (8 * k);
+                if (r == 0 && (k & 1) == 0) {
+                    uq |= clamp_u8_opaque((CRU * rr + CGU * g + CBU * bb + HALF + (128 << SH)) >> SH) << (4 * k);
+                    vq |= clamp_u8_opaque((CBU * rr + CGV * g + CBV * bb + HALF + (128 << SH)) >> SH) << (4 * k);
+                }
+            }
+        } else {          // the black bars: BGR = 0
+            yq = (unsigned)((HALF + (16 << SH)) >> SH) * 0x01010101u;
+            if (r == 0) uq = vq = (unsigned)((HALF + (128 << SH)) >> SH) * 0x0101u;
+        }
+        *reinterpret_cast<unsigned *>(Y + (size_t)(y + r) * out_w + x) = yq;
+    }
+    *reinterpret_cast<unsigned short *>(U + (size_t)(y / 2) * (out_w / 2) + x / 2) = (unsigned short)uq;
+    *reinterpret_cast<unsigned short *>(V + (size_t)(y / 2) * (out_w / 2) + x / 2) = (unsigned short)vq;
+}
 int launch_consume_i420(const ms_image &src, ms_image &dst, int out_w, int out_h, int ih, int y_off, hipStream_t st)
 {
     // cv::resize with an explicit dsize: fx = dsize.width / src.cols (double), the kernel gets (float)(1 / fx)  (resize.cpp:72-81,105)
     const double fx = (double)out_w / src.cols, fy = (double)ih / src.rows;
-    k_consume_i420<<<dim3(div_up(out_w / 2, BX), div_up(out_h / 2, BY)), dim3(BX, BY), 0, st>>>(
-        (const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, out_w, out_h, ih, y_off, (float)(1.0 / fy), (float)(1.0 / fx));
+    // (the 4-pixel form: dword luma stores need out_w % 4 == 0 and a 4-byte aligned frame, its 8-byte windows at least 3 source columns)
+    if ((out_w & 3) == 0 && ((size_t)dst.data & 3) == 0 && ((size_t)out_w * out_h & 3) == 0 && ((size_t)(out_w / 2) * (out_h / 2) & 1) == 0 && src.cols >= 3 &&
+        (unsigned long long)src.rows * src.step < 0x100000000ull)
+        k_consume_i420_x4<<<dim3(div_up(out_w / 4, BX), div_up(out_h / 2, BY)), dim3(BX, BY), 0, st>>>(
+            (const uint8_t *)src.data, (unsigned)src.step, src.rows, src.cols, (uint8_t *)dst.data, out_w, out_h, ih, y_off, (float)(1.0 / fy), (float)(1.0 / fx));
+    else
+        k_consume_i420<<<dim3(div_up(out_w / 2, BX), div_up(out_h / 2, BY)), dim3(BX, BY), 0, st>>>(
+            (const uint8_t *)src.data, src.step, src.rows, src.cols, (uint8_t *)dst.data, out_w, out_h, ih, y_off, (float)(1.0 / fy), (float)(1.0 / fx));
     MS_LAUNCH_CHECK();
     return MS_OK;
 }
