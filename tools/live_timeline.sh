@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/profiles_out; mkdir -p $OUT
 D=/tmp/live_tl; rm -rf $D; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $D -- python bench.py --frames 1 --streams 1 --steps 200 --warmup 3 --passes 1 \
-    --no-cpu-baseline --no-pcie --no-verify --no-live ${BENCH_EXTRA:-} > $OUT/${TAG}_live_bench.json 2> /tmp/live_tl.err
+    --no-cpu-baseline --no-pcie --no-verify --no-live --no-distinct ${BENCH_EXTRA:-} > $OUT/${TAG}_live_bench.json 2> /tmp/live_tl.err
 python - "$D" "$OUT/${TAG}_live_timeline.json" <<'PY'
 import csv, glob, json, sys, collections
 rows = []

@@ -6,7 +6,7 @@ set -uo pipefail
 TAG=${1:-r01}; CFG=${2:-cfg2}; F=${3:-16}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/ctr_$TAG; mkdir -p $OUT
-B="python bench.py --steps 6 --warmup 2 --passes 1 --no-live --no-pcie --no-verify --no-cpu-baseline --frames $F --streams 1 --config $CFG ${BENCH_EXTRA:-}"
+B="python bench.py --steps 6 --warmup 2 --passes 1 --no-live --no-pcie --no-verify --no-cpu-baseline --no-distinct --frames $F --streams 1 --config $CFG ${BENCH_EXTRA:-}"
 i=0
 for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
          "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \

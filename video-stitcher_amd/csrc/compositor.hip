@@ -3262,7 +3262,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             c->last_warp_kernel = ((c->warp_aligned || force_al != 0) && src_shared) ? MS_WARP_KERNEL_SHARED_ALIGNED : c->warp_aligned ? MS_WARP_KERNEL_PER_FRAME_ALIGNED
                                   : (src_steps_equal && F > 1 && dev_knob("MS_WARP_SHARED_U", 1)) ? MS_WARP_KERNEL_SHARED_UNALIGNED : MS_WARP_KERNEL_PER_FRAME_UNALIGNED;
             if ((c->warp_aligned || force_al != 0) && src_shared)
-                MS_WARP_S_LAUNCH(false, WARP_NF, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                MS_WARP_S_LAUNCH(false, WARP_NF_S, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (c->warp_aligned)
                 MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (src_steps_equal && F > 1 && dev_knob("MS_WARP_SHARED_U", 1)) {      // the unaligned-read form with shared offsets (config 5): only the row step has to agree

@@ -506,6 +506,12 @@ constexpr int WARP_NF = MS_WARP_NF;
 #define MS_WARP_NF_CPW 3
 #endif
 constexpr int warp_nf(bool cpw) { return cpw ? MS_WARP_NF_CPW : WARP_NF; }
+// the aligned shared-offset projection warp (k_warp_s<false, ., ., true>: config 2): THREE frames per lane since round 5 -- with the per-frame work down to its arithmetic core
+// (round 4) a third frame amortises the per-pixel part once more: 362 -> 333 us per 30 frames on the same box; the per-frame kernels (k_warp_t) and the unaligned shared form keep WARP_NF
+#ifndef MS_WARP_NF_S
+#define MS_WARP_NF_S 3
+#endif
+constexpr int WARP_NF_S = MS_WARP_NF_S;
 // lane rows per WORKGROUP: a tile's WARP_BY lane rows are split over WARP_BY / WARP_WY workgroups (blockIdx.y).  MS_WARP_ONE_WAVE: 64-lane workgroups
 // (the waves of a tile share nothing but the tile record), as k_blend8 got in round 2.
 #ifndef MS_WARP_ONE_WAVE
@@ -688,13 +694,30 @@ __global__ void __launch_bounds__(WARP_BX * WARP_WY) k_warp_s(const WarpTile *__
 {
     const WarpTile T = tiles[blockIdx.x];
     const int f0 = (int)blockIdx.z * NF, nf = min(NF, n_frames - f0);
-    if (!AL)
-        warp_tile_shared<CPW, PROJ, NF, false>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
-                                               g0, g0_stride, tabs);
-    else if (CPW || (T.flags & 8))       // (a tile that samples the last row of a caller's image keeps the unaligned reads: see Px3)
-        warp_tile_shared<CPW, PROJ, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
-                                        g0, g0_stride, tabs);
-    else
+    if (!AL) {
+        if (NF == 3 && nf == 2)
+            warp_tile_shared<CPW, PROJ, 2, false>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                                  g0, g0_stride, tabs);
+        else if (NF >= 2 && nf == 1)
+            warp_tile_shared<CPW, PROJ, 1, false>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                                  g0, g0_stride, tabs);
+        else
+            warp_tile_shared<CPW, PROJ, NF, false>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                                   g0, g0_stride, tabs);
+    } else if (CPW || (T.flags & 8)) {     // (a tile that samples the last row of a caller's image keeps the unaligned reads: see Px3)
+        // The last frame group of a call may be short (32 frames = 10 groups of three + one of two).  warp_tile_shared issues the reads of all NF frames whatever nf is (no branch
+        // around reads: the waits stay counted), so a short group used to cost a full one -- 11 groups x 33 us instead of 10.67 (round 5: profiles/r05_experiments.txt).  The
+        // group index is uniform over the workgroup: a short group takes the instantiation for its own frame count.
+        if (NF == 3 && nf == 2)
+            warp_tile_shared<CPW, PROJ, 2>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                           g0, g0_stride, tabs);
+        else if (NF >= 2 && nf == 1)
+            warp_tile_shared<CPW, PROJ, 1>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                           g0, g0_stride, tabs);
+        else
+            warp_tile_shared<CPW, PROJ, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
+                                            g0, g0_stride, tabs);
+    } else
         warp_tile_direct<CPW, PROJ, false, NF>(T, f0, nf, (int)threadIdx.x, (int)(threadIdx.y + blockIdx.y * WARP_WY), views, n_views, src, src_rows, src_cols, mesh, stage, stage_stride,
                                                g0, g0_stride, tabs);
 }
@@ -1318,8 +1341,11 @@ __global__ void __launch_bounds__(WARP_BX * S1_BY) k_stage1_s(const WarpTile *__
     const WarpTile T = tiles[blockIdx.x];
     if (!(T.flags & 2) && *disp.p[T.view] <= disp.limit_bits) return;
     const int f0 = (int)blockIdx.z * S1_NF, nf = min(S1_NF, n_frames - f0);
-    if (T.flags & 8) stage1_tile_shared<PROJ, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
-    else stage1_tile<PROJ, false, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+    if (T.flags & 8) {
+        if (S1_NF == 3 && nf == 2) stage1_tile_shared<PROJ, 2>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);      // (a short last group: see k_warp_s)
+        else if (S1_NF >= 2 && nf == 1) stage1_tile_shared<PROJ, 1>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+        else stage1_tile_shared<PROJ, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
+    } else stage1_tile<PROJ, false, S1_NF>(T, f0, nf, views, n_views, src, srows, scols, stage, stage_stride);
 }
 
 // ---- pyrDown, tile list, DOWN_ROWS (4) rows x 4 cols per lane (block 32 x 8): 11 input rows for 4 output rows (2 rows per lane: 7 for 2, 16 % slower) ----
