@@ -370,7 +370,9 @@ MS_API int ms_get_result_mask(ms_ctx *ctx, ms_image *mask);
 /* Calibration tables as a blob (the reference re-runs stitch_calib at every start, APP/timed.cpp:553).  ms_save_tables writes what the static
  * tables of a ready context derive from -- configuration, per view K, R, gain and blend mask, blender kind -- into `buf` (buf == NULL: only *bytes_out, the size
  * needed).  ms_load_tables creates a context from such a blob and rebuilds every table (same library build => bit-identical tables, e.g. on every rank of a
- * multi-GPU run); CPW meshes are run-time state and are set afterwards (ms_set_meshes).  Corrupt / foreign blobs are MS_ERR_INVALID before the device is touched. */
+ * multi-GPU run); CPW meshes are run-time state and are set afterwards (ms_set_meshes).  Corrupt / foreign blobs are MS_ERR_INVALID before the device is touched: the FNV-1a
+ * checksum covers the whole blob, the embedded configuration included.  A blob replays its context's configuration verbatim, so a column / view SHARD does not save
+ * (MS_ERR_UNSUPPORTED): "one blob for every rank" is the blob of the unsharded context; shards are created from the same cameras / gains / masks. */
 MS_API int ms_save_tables(ms_ctx *ctx, void *buf, size_t cap, size_t *bytes_out);
 MS_API int ms_load_tables(const void *buf, size_t bytes, ms_ctx **out, ms_stream stream);
 /* Diagnostics of the band kernels' work classification (no reference counterpart: the reference runs the general arithmetic everywhere).  The 64 x 16 pixel cells

@@ -111,7 +111,7 @@ def test_load_tables_refuses_garbage_before_touching_the_device(ms):
     """ms_load_tables validates magic / layout / checksum on the host: MS_ERR_INVALID (not MS_ERR_NO_DEVICE) without a GPU"""
     lib = ms.load()
     out = C.c_void_p()
-    for blob in (b"", b"\0" * 40, b"MSTBL01\0" + b"\1" * 400):
+    for blob in (b"", b"\0" * 40, b"MSTBL01\0" + b"\1" * 400, b"MSTBL02\0" + b"\1" * 400):
         b = (C.c_uint8 * max(1, len(blob))).from_buffer_copy(blob.ljust(1, b"\0"))
         rc = lib.ms_load_tables(b, C.c_size_t(len(blob)), C.byref(out), None)
         assert rc == -1 and not out.value, (rc, len(blob))      # MS_ERR_INVALID

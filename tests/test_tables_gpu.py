@@ -451,3 +451,24 @@ def test_tables_blob_round_trip_rebuilds_identical_tables_and_frames(ms, cuda):
         ms.Compositor.from_tables(bytes(bad))
     with pytest.raises(ms.MsError):
         ms.Compositor.from_tables(blob[:-5])
+    # the checksum covers the HEADER too: a flipped bit inside the embedded ms_config -- here num_bands 3 -> 2 and out_width 640 -> 641, both of which
+    # pass ms_create's range checks and would silently build other tables -- is refused
+    import ctypes
+    cfg_off = 48      # magic[8], header_bytes, config_bytes, n_views, blender_kind, feather_sharpness, reserved, total_bytes (8), checksum (8); checked by the asserts below
+    assert int.from_bytes(blob[12:16], "little") == ctypes.sizeof(ms.Config) and int.from_bytes(blob[cfg_off:cfg_off + 4], "little") == ctypes.sizeof(ms.Config)
+    raw = ms.Config.from_buffer_copy(blob[cfg_off:cfg_off + ctypes.sizeof(ms.Config)])
+    assert raw.num_views == cfg["n"] and raw.num_bands == cfg["num_bands"] and raw.out_width == cfg["out_w"]
+    for field, flip in (("num_bands", 1), ("out_width", 1), ("projection", 1)):
+        off = cfg_off + getattr(ms.Config, field).offset
+        bad = bytearray(blob); bad[off] ^= flip
+        with pytest.raises(ms.MsError, match="checksum"):
+            ms.Compositor.from_tables(bytes(bad))
+    # a column / view shard does not save (its blob would hand every loader that shard's window)
+    shard = ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), num_bands=cfg["num_bands"], out_size=(cfg["out_w"], cfg["out_h"]),
+                          col_shards=2, col_shard_index=1)
+    for i in range(cfg["n"]):
+        shard.set_camera(i, *synth.camera(cfg["n"], cfg["w"], cfg["h"], cfg["hfov_deg"], i))
+    shard.build_maps(); shard.build_masks(1); shard.init_blender()
+    with pytest.raises(ms.MsError, match="shard"):
+        shard.save_tables()
+    shard.close()

@@ -3568,12 +3568,13 @@ int ms_get_result_mask(ms_ctx *c, ms_image *m)
 // blob.  CPW meshes are run-time state (ms_set_meshes) and are not part of it.
 namespace {
 struct TablesHeader {
-    char magic[8];            // "MSTBL01"
+    char magic[8];            // "MSTBL02" (round 5: the checksum covers the header too; blobs of sharded contexts are refused)
     unsigned header_bytes, config_bytes;
     int n_views, blender_kind; // 0 = multiband / plain masks (ms_init_blender), 1 = FeatherBlender weights (ms_init_feather)
     float feather_sharpness;
     unsigned reserved;
-    unsigned long long total_bytes, checksum;      // FNV-1a over everything behind the header
+    unsigned long long total_bytes, checksum;      // FNV-1a over the WHOLE blob with this field zero: a flipped bit in the embedded ms_config (projection, bands, out size ..)
+                                                   // would otherwise pass ms_create's range checks and silently build other tables
     ms_config cfg;
 };
 struct TablesView { float K[9], R[9]; double gain; int aw, ah, roi_x, roi_y; };
@@ -3589,6 +3590,9 @@ int ms_save_tables(ms_ctx *c, void *buf, size_t cap, size_t *bytes_out)
 {
     if (!c || !bytes_out) return fail(MS_ERR_INVALID, "ms_save_tables: null argument");
     if (!c->blender_ready) return fail(MS_ERR_STATE, "ms_save_tables: call ms_init_blender / ms_init_feather first");
+    // a blob replays its context's configuration verbatim: one of a column / view shard would give EVERY loader that shard's window.  The unsharded
+    // context is what "one blob for every rank" means; a rank that needs a shard creates it from the same K / R / gains / masks itself.
+    if (c->cfg.col_shards > 1 || c->cfg.view_shards > 1) return fail(MS_ERR_UNSUPPORTED, "ms_save_tables: this context is a column / view shard; save the tables of an unsharded context");
     size_t need = sizeof(TablesHeader);
     for (int v = 0; v < c->N; ++v) need += sizeof(TablesView) + (size_t)c->roi[v].width * c->roi[v].height;
     *bytes_out = need;
@@ -3597,7 +3601,7 @@ int ms_save_tables(ms_ctx *c, void *buf, size_t cap, size_t *bytes_out)
     std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);
     unsigned char *o = static_cast<unsigned char *>(buf);
     TablesHeader h{};
-    memcpy(h.magic, "MSTBL01", 8);
+    memcpy(h.magic, "MSTBL02", 8);
     h.header_bytes = (unsigned)sizeof(TablesHeader); h.config_bytes = (unsigned)sizeof(ms_config);
     h.n_views = c->N; h.blender_kind = c->feather_sharpness >= 0.f ? 1 : 0; h.feather_sharpness = c->feather_sharpness;
     h.total_bytes = need; h.cfg = c->cfg;
@@ -3611,7 +3615,9 @@ int ms_save_tables(ms_ctx *c, void *buf, size_t cap, size_t *bytes_out)
         MS_HIP(hipMemcpy(o + at, (const uint8_t *)c->masks.p + c->mask_off[v], (size_t)tv.aw * tv.ah, hipMemcpyDeviceToHost));
         at += (size_t)tv.aw * tv.ah;
     }
-    h.checksum = fnv1a(o + sizeof(TablesHeader), need - sizeof(TablesHeader));
+    h.checksum = 0;
+    memcpy(o, &h, sizeof(h));
+    h.checksum = fnv1a(o, need);
     memcpy(o, &h, sizeof(h));
     return MS_OK;
 }
@@ -3624,11 +3630,18 @@ int ms_load_tables(const void *buf, size_t bytes, ms_ctx **out, ms_stream stream
     TablesHeader h;
     MS_CHECK(bytes >= sizeof(h), "ms_load_tables: %zu bytes is not a table blob", bytes);
     memcpy(&h, in, sizeof(h));
-    MS_CHECK(memcmp(h.magic, "MSTBL01", 8) == 0, "ms_load_tables: not a table blob (bad magic)");
+    MS_CHECK(memcmp(h.magic, "MSTBL02", 8) == 0, "ms_load_tables: not a table blob of this library (bad magic / older format)");
     MS_CHECK(h.header_bytes == sizeof(TablesHeader) && h.config_bytes == sizeof(ms_config) && h.cfg.struct_size == sizeof(ms_config),
              "ms_load_tables: the blob was written by a library with another ms_config / header layout");
     MS_CHECK(h.total_bytes == bytes && h.n_views >= 1 && h.n_views <= MAX_VIEWS && h.n_views == h.cfg.num_views, "ms_load_tables: truncated or inconsistent blob");
-    MS_CHECK(fnv1a(in + sizeof(h), bytes - sizeof(h)) == h.checksum, "ms_load_tables: checksum mismatch (corrupt blob)");
+    {      // over the whole blob with the checksum field zero (header and embedded configuration included)
+        std::vector<unsigned char> tmp(in, in + bytes);
+        TablesHeader z = h;
+        z.checksum = 0;
+        memcpy(tmp.data(), &z, sizeof(z));
+        MS_CHECK(fnv1a(tmp.data(), bytes) == h.checksum, "ms_load_tables: checksum mismatch (corrupt blob)");
+    }
+    MS_CHECK(h.cfg.col_shards <= 1 && h.cfg.view_shards <= 1, "ms_load_tables: the blob describes a column / view shard");
     size_t at = sizeof(h);
     for (int v = 0; v < h.n_views; ++v) {            // structure check before anything touches the device
         TablesView tv;
