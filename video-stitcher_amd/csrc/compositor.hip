@@ -1910,7 +1910,10 @@ static int build_plan(ms_ctx *c)
         if (!windowed || !c->warp_tiled) c->needed_mask = 0xffffffffu;      // (the full-grid fallback kernels touch every view)
         // (chunks of 8 tiles dealt round-robin: measured, profiles/r04_warp_experiments.txt -- config 2 k_warp 402 -> 388 us per 32 frames, config 5 -2..-5 %; the CPW mesh remap
         //  of the shipped rig +1.5 %, so CPW contexts keep the eight long runs)
-        if (c->cfg.raster_tile_order == 0) xcd_order(tiles, dev_knob("MS_XCD_CHUNK_WARP", c->cfg.enable_cpw ? 0 : 8));
+        // round 5: chunks of 32 (about one tile row of an ordinary view) instead of 8 for the projection warp: with three frames per lane config 2's k_warp 360-370 -> 352-356 us per
+        // 32 frames and its FETCH 42.3 -> 39.5 MB per frame (fewer chunk seams inside a tile row: horizontal neighbours share 128-byte source lines), config 5's 714 -> 698 us; whole tile
+        // rows per XCD (unequal runs) and chunks of 60 are slower again (profiles/r05_experiments.txt)
+        if (c->cfg.raster_tile_order == 0) xcd_order(tiles, dev_knob("MS_XCD_CHUNK_WARP", c->cfg.enable_cpw ? 0 : 32));
         c->n_warp_tiles = (int)tiles.size();
         if (int e = c->warp_tiles.alloc(std::max<size_t>(1, tiles.size()) * sizeof(WarpTile))) return e;
         c->warp_lds_tiles = 0;
@@ -1977,7 +1980,7 @@ static int build_plan(ms_ctx *c)
             std::vector<WarpTile> a, b;
             for (const WarpTile &t : tiles) ((t.flags & 2) ? a : b).push_back(t);
             c->n_stage1_reachable = (int)a.size();
-            if (c->cfg.raster_tile_order == 0) { xcd_order(a, dev_knob("MS_XCD_CHUNK_S1", 8)); xcd_order(b, dev_knob("MS_XCD_CHUNK_S1", 8)); }
+            if (c->cfg.raster_tile_order == 0) { xcd_order(a, dev_knob("MS_XCD_CHUNK_S1", 32)); xcd_order(b, dev_knob("MS_XCD_CHUNK_S1", 32)); }
             tiles = a;
             tiles.insert(tiles.end(), b.begin(), b.end());
         }
@@ -3189,7 +3192,8 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         {
             // frames per lane of the first CPW remap: three where the source is sampled about 1 : 1 (VALU-bound), two otherwise (see k_stage1_t)
             static const int s1_env = dev_knob("MS_S1_NF", 0);
-            const int s1_nf = s1_env == 2 || s1_env == 3 ? s1_env : ((c->warp_minification > 0 && c->warp_minification < 1.5) ? 3 : 2);
+            // (round 5: the shared-offset form takes three wherever it runs -- config 3's first remap 406 -> 387-392 us per 32 frames, 385 -> 364 per 30; the per-frame form keeps the minification rule)
+            const int s1_nf = s1_env == 2 || s1_env == 3 ? s1_env : ((c->warp_aligned && src_shared) || (c->warp_minification > 0 && c->warp_minification < 1.5)) ? 3 : 2;
             static const int s1_lds = dev_knob("MS_S1_LDS", 0);      // occupancy A/B knob (dynamic LDS nobody touches)
 #define MS_S1_LAUNCH(AL, NF) MS_PROJ_AL_LAUNCH(k_stage1_t, AL, NF, (dim3(c->n_stage1_tiles, 1, div_up(F, NF)), dim3(WARP_BX, S1_BY), s1_lds, st), \
                     (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F)
