@@ -15,5 +15,8 @@ run app_refcalib ab/stitch_app_asan --reference-calib --frames 6
 run dist2 ab/stitch_dist_asan --gpus 2 --share-gpu --frames 64 --batch 4 $M
 run dist4 ab/stitch_dist_asan --gpus 4 --share-gpu --col-shards 2 --frames 32 --batch 4 $M --cpw --recalib-every 8
 run dist_tables ab/stitch_dist_asan --gpus 2 --share-gpu --frames 32 --batch 4 $M --tables-from-rank0
+export GPU_MAX_HW_QUEUES=32
+run dist2_rccl ab/stitch_dist_asan --gpus 2 --share-gpu --transport rccl --rccl-lib $PWD/ab/libfake_rccl_asan.so --frames 64 --batch 4 $M
+run dist4_rccl ab/stitch_dist_asan --gpus 4 --share-gpu --transport rccl --rccl-lib $PWD/ab/libfake_rccl_asan.so --col-shards 2 --frames 32 --batch 4 $M --cpw --recalib-every 8
 echo "--- first lines of every report:"
 for f in $O/*.err; do grep -E -A6 'ERROR: AddressSanitizer|runtime error' $f | head -40; done

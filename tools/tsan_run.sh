@@ -14,5 +14,9 @@ run app_consume ab/stitch_app_tsan $M --frames 40 --consume 512x256
 run app_nv12 ab/stitch_app_tsan $M --frames 40 --nv12-direct
 run dist2 ab/stitch_dist_tsan --gpus 2 --share-gpu --frames 64 --batch 4 $M
 run dist4 ab/stitch_dist_tsan --gpus 4 --share-gpu --col-shards 2 --frames 32 --batch 4 $M --cpw --recalib-every 8
+# round 5: the RCCL branch of csrc/dist.cpp over the loopback library (tests/fake_rccl.cpp, instrumented as well): rank threads, proxy threads, the shared-memory mailbox
+export GPU_MAX_HW_QUEUES=32
+run dist2_rccl ab/stitch_dist_tsan --gpus 2 --share-gpu --transport rccl --rccl-lib $PWD/ab/libfake_rccl_tsan.so --frames 64 --batch 4 $M
+run dist4_rccl ab/stitch_dist_tsan --gpus 4 --share-gpu --transport rccl --rccl-lib $PWD/ab/libfake_rccl_tsan.so --col-shards 2 --frames 32 --batch 4 $M --cpw --recalib-every 8
 echo "--- reports with this repository's code on top of an access:"
 for f in $O/*.err; do grep -E '^\s+#0 .*/root/repo/' $f | sed 's/(.*//' | awk -v f=$(basename $f) '{$1=""; print f ":" $0}' | sort | uniq -c; done
