@@ -138,3 +138,10 @@ def test_no_v_ashr_pk_u8_i32_in_the_device_code(tmp_path):
         n_inst += dis.count("\tv_")
         assert "v_ashr_pk_u8_i32" not in dis and "v_ashr_pk_i8_i32" not in dis, f
     assert n_inst > 10000      # (the disassembly really is the kernels)
+
+
+def test_diagnostic_entry_points_validate_their_arguments(ms):
+    """ms_get_plan_stats / ms_get_stitch_kernels (round 5): null arguments are MS_ERR_INVALID, a struct of another size is refused (struct_size convention of ms_config)"""
+    lib = ms.load()
+    assert lib.ms_get_plan_stats(None, None) == -1 and lib.ms_get_stitch_kernels(None, None, None) == -1
+    assert C.sizeof(ms.PlanStats) == 4 * (1 + 3 + 2 + 2 + 8 + 2 + 8)      # the layout include/ms_stitch.h declares

@@ -189,3 +189,32 @@ def test_host_transport_under_tsan(tmp_path):
         r = subprocess.run([exe, str(world), str(iters)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
         assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (world, r.returncode, r.stderr[-3000:])
         assert ("ok: %d ranks x %d iterations" % (world, iters)) in r.stdout
+
+
+def test_rccl_library_can_be_named_once_before_first_use():
+    """ms_dist_set_rccl_library: the file RCCL is loaded from is fixed before the first RCCL id / communicator; a file that does not load is a clear MS_ERR_COMM at that
+    first use, and naming another one afterwards is MS_ERR_STATE (process-global: checked in a fresh interpreter; no GPU needed, nothing is computed)."""
+    import subprocess
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import msdist, msstitch as ms
+msdist.set_rccl_library("/nonexistent/librccl.so.1")
+try:
+    msdist.unique_id(2, msdist.RCCL)
+    print("NO ERROR")
+except ms.MsError as e:
+    print("first use:", e)
+try:
+    msdist.set_rccl_library(None)
+    print("NO ERROR")
+except ms.MsError as e:
+    print("second call:", e)
+print("host still works:", msdist.id_transport(msdist.unique_id(2, msdist.HOST)) == msdist.HOST)
+''' % os.path.join(ROOT, "video-stitcher_amd")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    out = p.stdout
+    assert p.returncode == 0, p.stderr[-1500:]
+    assert "first use:" in out and "could not be loaded" in out, out
+    assert "second call:" in out and "already been resolved" in out, out
+    assert "host still works: True" in out, out
