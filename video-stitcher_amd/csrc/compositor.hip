@@ -736,6 +736,7 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                                                 const uint8_t *__restrict__ gl, long long gl_stride,
                                                 int16_t *__restrict__ cl, long long cl_stride, OutTable out, ShardArgs S)
 {
+    MS_PRIO_LOADS(MS_PRIO_BLEND);
     const BlendTile T = tiles[blockIdx.x];
     const int f = blockIdx.z;
     // A tile is 256 x 16 px = four 64 x 16 px cells (8 lanes x 8 lane-rows of 8 x 2 px), ONE WAVE PER WORKGROUP (blockIdx.y = the cell): the waves share
@@ -842,6 +843,7 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
         for (int c = 0; c < 3; ++c) {
             const int b = c & 1;
             if (c + 1 < 3) issue(c + 1, b ^ 1);
+            if (MS_PRIO_BLEND) { __builtin_amdgcn_sched_barrier(0); MS_PRIO_MATH(MS_PRIO_BLEND); }
             unsigned up[2][4];
             up_2x8_pk(craw[b], C.w, lx >> 1, up[0], up[1]);
             unsigned g[2][4];                 // same pixel order as up: (0,2) (1,3) (4,6) (5,7)
@@ -865,7 +867,9 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
                     const int t1 = (int)((float)((int)(d >> 16) - 256) * w[r][k1]);
                     accp[c][r][q] = add_pk_u16(accp[c][r][q], __builtin_amdgcn_perm((unsigned)t1, (unsigned)t0, 0x05040100u));
                 }
+            if (MS_PRIO_BLEND && c < 2) { __builtin_amdgcn_sched_barrier(0); MS_PRIO_LOADS(MS_PRIO_BLEND); }
         }
+        if (MS_PRIO_BLEND) { __builtin_amdgcn_sched_barrier(0); MS_PRIO_LOADS(MS_PRIO_BLEND); }
     }
 
     if (MODE == 1) {
@@ -907,7 +911,9 @@ __global__ void __launch_bounds__(64) MS_BLEND_OCC k_blend8(const BlendTile *__r
     up_rows_load(cc, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[0]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        MS_PRIO_LOADS(MS_PRIO_BLEND);
         if (c + 1 < 3) up_rows_load(cc + (c + 1) * cplane, P.qpitch[l + 1], P.qh[l + 1], y0 >> 1, x0 >> 1, ccraw[(c + 1) & 1]);
+        if (MS_PRIO_BLEND) { __builtin_amdgcn_sched_barrier(0); MS_PRIO_MATH(MS_PRIO_BLEND); }
         unsigned upq[2][4];               // pyrUp of the collapsed coarser band (its values fit int16: the reference's saturate_cast<short> is the identity)
         if (up_2x8_pkb(ccraw[c & 1], P.qw[l + 1], x0 >> 1, upq[0], upq[1])) {
 #pragma unroll

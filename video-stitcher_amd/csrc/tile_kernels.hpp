@@ -6,6 +6,31 @@
 // first use so a wave pays one memory round trip instead of one per tap/row.
 #pragma once
 #include "descs.hpp"
+// Wave priority around the two phases of a gather kernel (s_setprio; session 2 of round 5, profiles/r05_experiments.txt).  Mode 1: a wave that is building addresses and issuing its
+// reads runs at priority 3 and drops to 0 for the arithmetic on what came back, so that a new wave gets its reads out past the older waves' long blends instead of taking
+// turns with them (the SIMD's arbiter is oldest-first among equal priorities); 3: raised only until the first reads are out; 2: the opposite of 1; 0: no instruction.
+// Measured per kernel, same box, alternating: the projection warp 389 -> 376 us per 32 frames with 1 (378 with 3, 389 with 2) -- adopted; the CPW mesh remap +3.4 % and the
+// first CPW remap +0 % (config 3) / +3.8 % (shipped rig) SLOWER with 1 -- not bound by misses in flight, the raised waves only delay the stores of the older ones; the level-0
+// band kernel -0.8 %, the level-0 reduce +4 % (the scheduling barrier the switch needs splits its load clause), the NV12-sampling warp +2 %.  So: MS_PRIO_WARP applies to the
+// projection warp in its aligned shared-offset form alone (a second box: 362-368 -> 356-357 us).
+#ifndef MS_PRIO_WARP
+#define MS_PRIO_WARP 1
+#endif
+#ifndef MS_PRIO_CPW
+#define MS_PRIO_CPW 0
+#endif
+#ifndef MS_PRIO_S1
+#define MS_PRIO_S1 0
+#endif
+#ifndef MS_PRIO_NV12
+#define MS_PRIO_NV12 0
+#endif
+#ifndef MS_PRIO_BLEND
+#define MS_PRIO_BLEND 0
+#endif
+#define MS_PRIO_LOADS(K) do { if ((K) == 1 || (K) == 3) __builtin_amdgcn_s_setprio(3); else if ((K) == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define MS_PRIO_RELOADS(K) do { if ((K) == 1) __builtin_amdgcn_s_setprio(3); else if ((K) == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define MS_PRIO_MATH(K)  do { if ((K) == 1 || (K) == 3) __builtin_amdgcn_s_setprio(0); else if ((K) == 2) __builtin_amdgcn_s_setprio(3); } while (0)
 
 namespace ms {
 
@@ -554,6 +579,8 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
                                                  const uint8_t *__restrict__ stage, long long stage_stride,
                                                  uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
 {
+    constexpr int PRIO = CPW ? MS_PRIO_CPW : (AL ? MS_PRIO_WARP : 0);      // (the unaligned-read form of config 5: 705-710 us per 16 frames without, 709-714 with -- left alone)
+    MS_PRIO_LOADS(PRIO);
     const int v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * tx, y = T.y0 + ty;
@@ -629,6 +656,7 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
     __builtin_amdgcn_sched_barrier(0);      // frame 0's reads go out first
     if (NF > 1) issue(1);
     __builtin_amdgcn_sched_barrier(0);
+    MS_PRIO_MATH(PRIO);
     // ... and while they are in flight: the weights (frame-invariant)
     Taps t[4];
 #pragma unroll
@@ -682,7 +710,7 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
             *reinterpret_cast<unsigned *>(d + 2 * plane) = packed[2];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (fi + 2 < NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }      // (three frames per lane: the third frame's reads reuse frame 0's registers)
+        if (fi + 2 < NF) { MS_PRIO_RELOADS(PRIO); issue(fi + 2); __builtin_amdgcn_sched_barrier(0); MS_PRIO_MATH(PRIO); }      // (three frames per lane: the third frame's reads reuse frame 0's registers)
     }
 }
 
@@ -781,6 +809,8 @@ template <int PROJ, int NF, bool ALN, bool S1>
 __device__ __forceinline__ void nv12_tile(const WarpTile &T, int f0, int nf, int tx, int ty, const ViewDesc *__restrict__ views, int n_views,
                                           const SrcTable &src, int rows, int cols, uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
 {
+    constexpr int PRIO = S1 ? 0 : MS_PRIO_NV12;
+    MS_PRIO_LOADS(PRIO);
     const int v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * tx, y = T.y0 + ty;
@@ -852,6 +882,7 @@ __device__ __forceinline__ void nv12_tile(const WarpTile &T, int f0, int nf, int
     __builtin_amdgcn_sched_barrier(0);
     if (NF > 1) issue(1);
     __builtin_amdgcn_sched_barrier(0);
+    MS_PRIO_MATH(PRIO);
     Taps t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k] = make_taps(xc[k], yc[k], rows + 1, cols + 1);      // (weights only; `fast` of Taps is not used here: see `slow`)
@@ -910,7 +941,7 @@ __device__ __forceinline__ void nv12_tile(const WarpTile &T, int f0, int nf, int
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (fi + 2 < NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }
+        if (fi + 2 < NF) { MS_PRIO_RELOADS(PRIO); issue(fi + 2); __builtin_amdgcn_sched_barrier(0); MS_PRIO_MATH(PRIO); }
     }
 }
 template <int PROJ, int NF, bool ALN>
@@ -1242,6 +1273,7 @@ template <int PROJ, int S1_NF>
 __device__ __forceinline__ void stage1_tile_shared(const WarpTile &T, int f0, int nf, const ViewDesc *__restrict__ views, int n_views,
                                                    const SrcTable &src, int srows, int scols, uint8_t *__restrict__ stage, long long stage_stride)
 {
+    MS_PRIO_LOADS(MS_PRIO_S1);
     const int v = T.view;
     const ViewDesc &V = views[v];
     const int x = T.x0 + 4 * (int)threadIdx.x, y = T.y0 + (int)threadIdx.y;
@@ -1288,6 +1320,7 @@ __device__ __forceinline__ void stage1_tile_shared(const WarpTile &T, int f0, in
     __builtin_amdgcn_sched_barrier(0);
     if (S1_NF > 1) issue(1);
     __builtin_amdgcn_sched_barrier(0);
+    MS_PRIO_MATH(MS_PRIO_S1);
     Taps t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k] = make_taps(xc[k], yc[k], srows, scols);
@@ -1330,7 +1363,7 @@ __device__ __forceinline__ void stage1_tile_shared(const WarpTile &T, int f0, in
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (fi + 2 < S1_NF) { issue(fi + 2); __builtin_amdgcn_sched_barrier(0); }
+        if (fi + 2 < S1_NF) { MS_PRIO_RELOADS(MS_PRIO_S1); issue(fi + 2); __builtin_amdgcn_sched_barrier(0); MS_PRIO_MATH(MS_PRIO_S1); }
     }
 }
 
