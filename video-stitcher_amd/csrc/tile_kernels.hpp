@@ -642,6 +642,9 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (AL) {
+#ifdef MS_PROBE_TAPS      // request-path probe (WRONG pixels): only every MS_PROBE_TAPS-th pixel of a lane reads its taps, the others blend a copy -- same VALU, same stores, 1/n of the tap reads
+                if (CPW && (k % MS_PROBE_TAPS) != 0) { q1[AL ? fi & 1 : 0][AL ? k : 0] = q1[AL ? fi & 1 : 0][AL ? k - k % MS_PROBE_TAPS : 0]; q2[AL ? fi & 1 : 0][AL ? k : 0] = q2[AL ? fi & 1 : 0][AL ? k - k % MS_PROBE_TAPS : 0]; continue; }
+#endif
                 const ms_u32x3_a4 r1 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + va[k]);
                 const ms_u32x3_a4 r2 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + vb[k]);
                 q1[AL ? fi & 1 : 0][AL ? k : 0] = Px3{r1.x, r1.y, r1.z};
@@ -1310,6 +1313,9 @@ __device__ __forceinline__ void stage1_tile_shared(const WarpTile &T, int f0, in
     auto issue = [&](int fi) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#ifdef MS_PROBE_TAPS
+            if ((k % MS_PROBE_TAPS) != 0) { q1[fi & 1][k] = q1[fi & 1][k - k % MS_PROBE_TAPS]; q2[fi & 1][k] = q2[fi & 1][k - k % MS_PROBE_TAPS]; continue; }
+#endif
             const ms_u32x3_a4 r1 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + va[k]);
             const ms_u32x3_a4 r2 = *(const MS_GLOBAL_AS ms_u32x3_a4 *)(base[fi] + vb[k]);
             q1[fi & 1][k] = Px3{r1.x, r1.y, r1.z};
