@@ -510,6 +510,8 @@ def main():
                          "(BASELINE configs[2]: recalibrate every 60 f); 0 = never")
     ap.add_argument("--join-every", type=int, default=1, help="fork-join the streams around groups of this many passes (1 = every pass)")
     ap.add_argument("--independent-streams", action="store_true", help="do not fork-join the streams around every pass (A/B: 1 % slower than the joined default)")
+    ap.add_argument("--pad-kb", type=int, default=0, help="developer probe: allocate this many KiB of device memory before anything else (shifts the addresses of every later allocation: "
+                                                         "placement sensitivity of the kernels, tools/placement_probe.sh)")
     ap.add_argument("--streams", type=int, default=None,
                     help="contexts / HIP streams a step's frames are split over (default 3 x 16 frames: the small coarse-level kernels of one "
                          "batch overlap the large kernels of another: +13 % over one stream)")
@@ -598,6 +600,7 @@ def main():
             D, dist_info = None, {"transport": "torch.distributed (ms_dist did not come up on every rank: %s)" % (why or "another rank failed")}
         dd["D"], dd["info"] = D, dist_info
 
+    _pad = torch.empty(args.pad_kb * 1024, dtype=torch.uint8, device=dev) if args.pad_kb > 0 else None      # (kept alive for the whole run)
     shipped = args.config == "shipped"
     cpw = args.config in ("cfg3", "shipped")
     cfg = dict(synth.CONFIGS["cfg5" if args.config == "cfg5" else "cfg2"])
