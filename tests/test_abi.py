@@ -140,6 +140,31 @@ def test_no_v_ashr_pk_u8_i32_in_the_device_code(tmp_path):
     assert n_inst > 10000      # (the disassembly really is the kernels)
 
 
+def test_wave_priority_switch_only_in_the_projection_warp(tmp_path):
+    """s_setprio (tile_kernels.hpp MS_PRIO_*): measured faster for the projection warp in its aligned shared-offset form and SLOWER for the CPW remaps, the level-0 reduce and the
+    NV12 warp (profiles/r05_experiments.txt) -- the shipped code objects carry the instruction in k_warp_s<false, ., ., true> and nowhere else."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "video-stitcher_amd", "libmsstitch.so")
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, capture_output=True, check=True)
+    with_prio = set()
+    for f in [f for f in os.listdir(tmp_path) if "gfx950" in f]:
+        cur = None
+        for line in subprocess.run([objdump, "-d", "-C", f], cwd=tmp_path, capture_output=True, text=True, check=True).stdout.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+            elif "s_setprio" in line and cur:
+                with_prio.add(cur.split("(")[0])
+    assert with_prio, "no s_setprio in the shipped kernels: MS_PRIO_WARP lost?"
+    assert all(re.match(r"^(void )?ms::k_warp_s<false, \d+, \d+, true>$", k) for k in with_prio), sorted(with_prio)
+
+
 def test_diagnostic_entry_points_validate_their_arguments(ms):
     """ms_get_plan_stats / ms_get_stitch_kernels (round 5): null arguments are MS_ERR_INVALID, a struct of another size is refused (struct_size convention of ms_config)"""
     lib = ms.load()
