@@ -12,7 +12,7 @@
 // Measured per kernel, same box, alternating: the projection warp 389 -> 376 us per 32 frames with 1 (378 with 3, 389 with 2) -- adopted; the CPW mesh remap +3.4 % and the
 // first CPW remap +0 % (config 3) / +3.8 % (shipped rig) SLOWER with 1 -- not bound by misses in flight, the raised waves only delay the stores of the older ones; the level-0
 // band kernel -0.8 %, the level-0 reduce +4 % (the scheduling barrier the switch needs splits its load clause), the NV12-sampling warp +2 %.  So: MS_PRIO_WARP applies to the
-// projection warp in its aligned shared-offset form alone (a second box: 362-368 -> 356-357 us).
+// projection warp in its aligned shared-offset form alone (a second box: 362-368 -> 356-357 us; config 5's stronger minification: neutral).
 #ifndef MS_PRIO_WARP
 #define MS_PRIO_WARP 1
 #endif
@@ -579,7 +579,8 @@ __device__ __forceinline__ void warp_tile_shared(const WarpTile &T, int f0, int 
                                                  const uint8_t *__restrict__ stage, long long stage_stride,
                                                  uint8_t *__restrict__ g0, long long g0_stride, const float2 *__restrict__ tabs)
 {
-    constexpr int PRIO = CPW ? MS_PRIO_CPW : (AL ? MS_PRIO_WARP : 0);      // (the unaligned-read form of config 5: 705-710 us per 16 frames without, 709-714 with -- left alone)
+    constexpr int PRIO = CPW ? MS_PRIO_CPW : (AL ? MS_PRIO_WARP : 0);      // (config 5 -- 2.7 x minification -- runs this aligned form too: 705-710 us per 16 frames without the switch, 709-714 with: neutral there;
+                                                                           //  the unaligned-read form, taken only when the frames of a view differ in alignment, is left alone)
     MS_PRIO_LOADS(PRIO);
     const int v = T.view;
     const ViewDesc &V = views[v];
