@@ -1478,7 +1478,9 @@ __global__ void __launch_bounds__(256) k_mesh_expand_scatter_all(MeshJobs T, int
 }
 // second half (meshwarper.cpp:870-883): mean (0/0 -> NaN hole) + custom_resize back to the view size for both maps, and the largest
 // displacement of the new maps (see k_mesh_disp)
-constexpr int MESH_FW = 72, MESH_FH = 8;       // LDS footprint (cells) of a 64 x 4 output block: <= 64 * (hw - 1) / aw + 2 columns, likewise rows
+constexpr int MESH_TR = 4;                      // output rows per lane: a workgroup step is a 64 x 16 pixel tile (64 x 4 until round 5: the straddling view's 9 420 tiles were 18 serial
+                                                // steps -- each a chain of cell loads, two barriers, stores -- for each of its 512 workgroups: 54 us; four times fewer, fatter steps)
+constexpr int MESH_FW = 72, MESH_FH = 4 * MESH_TR / 2 + 4;       // LDS footprint (cells) of a 64 x 16 output block: <= 64 * (hw - 1) / aw + 2 columns, likewise rows
 __device__ __forceinline__ void mesh_mean_resize_blocks(const MeshJob &J, int first_tile, int tile_stride)
 {
     const unsigned long long *__restrict__ ax = J.ax, *__restrict__ ay = J.ay;
@@ -1490,13 +1492,13 @@ __device__ __forceinline__ void mesh_mean_resize_blocks(const MeshJob &J, int fi
     const bool ex = resize_axis_exact(hw, aw), ey = resize_axis_exact(hh, ah);
     constexpr unsigned long long SUM = (1ull << 40) - 1;
     float d = 0.f;
-    // a workgroup walks 64 x 4 output tiles grid-stride: one atomic on the displacement word per workgroup, not per tile (thousands of
+    // a workgroup walks 64 x 16 output tiles grid-stride: one atomic on the displacement word per workgroup, not per tile (thousands of
     // same-address atomics serialise: they were most of this kernel's time)
     for (int tile = first_tile; tile < n_tiles; tile += tile_stride) {
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int x = txi * 64 + threadIdx.x, y = tyi * 4 + threadIdx.y;
+        const int x = txi * 64 + threadIdx.x;
         // footprint of the tile in the half-resolution maps
-        const int bx0 = txi * 64, by0 = tyi * 4, bx1 = min(bx0 + 63, aw - 1), by1 = min(by0 + 3, ah - 1);
+        const int bx0 = txi * 64, by0 = tyi * (4 * MESH_TR), bx1 = min(bx0 + 63, aw - 1), by1 = min(by0 + 4 * MESH_TR - 1, ah - 1);
         int c0, c1, r0, r1;
         float t;
         resize_axis(bx0, hw, aw, ex, c0, t); resize_axis(bx1, hw, aw, ex, c1, t);
@@ -1517,6 +1519,9 @@ __device__ __forceinline__ void mesh_mean_resize_blocks(const MeshJob &J, int fi
             }
             __syncthreads();
         }
+#pragma unroll
+        for (int tr = 0; tr < MESH_TR; ++tr) {
+        const int y = by0 + 4 * tr + (int)threadIdx.y;
         if (x < aw && y < ah) {
             int left, top;
             float uu, vv;
@@ -1538,6 +1543,7 @@ __device__ __forceinline__ void mesh_mean_resize_blocks(const MeshJob &J, int fi
             dy[(size_t)y * pitch + x] = my;
             const float a = fabsf(mx - (float)x), b = fabsf(my - (float)y);
             d = fmaxf(d, fmaxf(a == a ? a : 0.f, b == b ? b : 0.f));
+        }
         }
         __syncthreads();                                                 // the staging arrays are rewritten by the next tile
     }
@@ -1683,8 +1689,15 @@ struct ms_ctx {
     // its stream wait for it; `mesh_chain` orders updates among themselves (they share the scratch and the staging buffers)
     hipEvent_t mesh_ready[MAX_VIEWS] = {}, mesh_chain = nullptr;
     bool mesh_wait[MAX_VIEWS] = {}, mesh_chain_set = false;
-    float *mesh_stage = nullptr;       // pinned host staging of the vertex meshes
-    size_t mesh_stage_floats = 0;
+    // ms_set_meshes updates every view behind ONE event: a view whose last update was part of such a call is ready when `mesh_chain` is (a later record of mesh_chain is a later
+    // point of the same chain of updates).  Twelve event records and as many stream waits per recalibration were 50 us of idle GPU between its kernels and the next stitch.
+    bool mesh_ready_via_chain[MAX_VIEWS] = {};
+    float *mesh_stage = nullptr;       // pinned host staging of the vertex meshes: a ring of MESH_STAGE_GENS generations of MAX_VIEWS slots (ms_set_mesh uses generation 0;
+    size_t mesh_stage_floats = 0;      // ms_set_meshes walks the ring: the host waits for the COPY of the update a whole ring back -- `mesh_stage_ev` --, never for the update before this one)
+    static constexpr int MESH_STAGE_GENS = 8;
+    int mesh_stage_gen = 0;
+    hipEvent_t mesh_stage_ev[MESH_STAGE_GENS] = {};
+    bool mesh_stage_ev_set[MESH_STAGE_GENS] = {};
     int canvas_x = 0, canvas_y = 0;
     // view sharding (ms_config.view_shards = shard count S, view_shard_index = this shard's index): contiguous blocks of views per shard
     unsigned own_mask = 0xffffffffu;
@@ -2119,6 +2132,7 @@ void ms_destroy(ms_ctx *c)
     if (c->mesh_chain) (void)hipEventDestroy(c->mesh_chain);
     if (c->tab_ready) (void)hipEventDestroy(c->tab_ready);
     if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
+    for (hipEvent_t e : c->mesh_stage_ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -2688,7 +2702,8 @@ static ms_image mesh_image(const ms_ctx *c, int buf, int v, int which)
 
 // Callers hold mesh_update_mu (one update at a time).  mesh_mu is taken here only around the bookkeeping ms_stitch shares: ms_stitch holds it from
 // picking the active buffers up to recording last_stitch, so `last_stitch` seen here covers every stitch that may still read the inactive buffer.
-static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st)
+static hipEvent_t mesh_ready_event(ms_ctx *c, int view) { return c->mesh_ready_via_chain[view] ? c->mesh_chain : c->mesh_ready[view]; }      // (caller holds mesh_mu or is the only updater)
+static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st, bool enqueue_waits = true)
 {
     if (!c->blender_ready || !c->cfg.enable_cpw) return fail(MS_ERR_STATE, "mesh update needs enable_cpw and ms_init_blender");
     std::lock_guard<std::mutex> lk(c->mesh_mu);
@@ -2697,16 +2712,20 @@ static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st)
     if (!c->mesh_chain) MS_HIP(hipEventCreateWithFlags(&c->mesh_chain, hipEventDisableTiming));
     // the inactive buffer may still be read by a stitch enqueued before the previous swap: the update waits for it ON THE GPU
     // (the reference releases its mutex before the async remap finishes, timed.cpp:98-103); no host synchronisation anywhere
-    if (c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
-    if (c->mesh_chain_set) MS_HIP(hipStreamWaitEvent(st, c->mesh_chain, 0));
+    if (enqueue_waits) {      // (ms_set_meshes: once for all views of the call)
+        if (c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
+        if (c->mesh_chain_set) MS_HIP(hipStreamWaitEvent(st, c->mesh_chain, 0));
+    }
     return MS_OK;
 }
-static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st, bool measure = true)
+// batch = 0: one view's update (its own event + the chain); 1: a view of an ms_set_meshes call (no record); 2: the last view of such a call (the chain, once)
+static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st, bool measure = true, int batch = 0)
 {
     if (measure) if (int e = measure_mesh_disp(c, view, tgt, st)) return e;
     std::lock_guard<std::mutex> lk(c->mesh_mu);
-    MS_HIP(hipEventRecord(c->mesh_ready[view], st));
-    MS_HIP(hipEventRecord(c->mesh_chain, st));
+    if (batch == 0) MS_HIP(hipEventRecord(c->mesh_ready[view], st));
+    if (batch != 1) MS_HIP(hipEventRecord(c->mesh_chain, st));
+    c->mesh_ready_via_chain[view] = batch != 0;
     c->mesh_chain_set = true;
     c->mesh_wait[view] = true;
     c->mesh_active[view] = tgt;
@@ -2754,7 +2773,9 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
             c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
-            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, 2 * n_small * sizeof(float) * MAX_VIEWS, hipHostMallocDefault));
+            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, ms_ctx::MESH_STAGE_GENS * (2 * n_small * sizeof(float) * MAX_VIEWS), hipHostMallocDefault));      // (MESH_STAGE_GENS generations)
+            for (bool &b_ : c->mesh_stage_ev_set) b_ = false;
+            c->mesh_stage_gen = 0;
             c->mesh_stage_floats = 2 * n_small;
         }
     }
@@ -2770,8 +2791,9 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     // the caller's arrays may be freed right after return: stage them in pinned memory (one slot per view; a slot is reused only by
     // the next update of the same view, whose copy of the previous one finished long before -- checked on its event)
     bool slot_busy;
-    { std::lock_guard<std::mutex> mk(c->mesh_mu); slot_busy = c->mesh_ready[view] && (c->mesh_wait[view] || c->mesh_set[view]); }
-    if (slot_busy) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    hipEvent_t busy_ev = nullptr;
+    { std::lock_guard<std::mutex> mk(c->mesh_mu); slot_busy = c->mesh_ready[view] && (c->mesh_wait[view] || c->mesh_set[view]); if (slot_busy) busy_ev = mesh_ready_event(c, view); }
+    if (slot_busy && busy_ev) MS_HIP(hipEventSynchronize(busy_ev));
     float *stg = c->mesh_stage + (size_t)view * c->mesh_stage_floats;
     memcpy(stg, mesh_x, n_small * 4);
     memcpy(stg + n_small, mesh_y, n_small * 4);
@@ -2781,7 +2803,7 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     k_mesh_expand_scatter<<<dim3(div_up(aw, 64), div_up(ah, 4 * MESH_SR)), blk, 0, st>>>(sm_x, sm_y, N, M, aw, ah, ax, ay, hw, hh, other, c->mesh_dirty, word);        // meshwarper.cpp:838-869
     MS_LAUNCH_CHECK();
     ms_image dx = mesh_image(c, tgt, view, 0), dy = mesh_image(c, tgt, view, 1);
-    const int tiles_x = div_up(aw, 64), n_tiles = tiles_x * div_up(ah, 4);
+    const int tiles_x = div_up(aw, 64), n_tiles = tiles_x * div_up(ah, 4 * MESH_TR);
     k_mesh_mean_resize<<<std::min(n_tiles, 1024), blk, 0, st>>>(ax, ay, hw, hh, (float *)dx.data, (float *)dy.data, c->map_pitch[view], aw, ah, tiles_x, n_tiles, word);   // :870-883
     MS_LAUNCH_CHECK();
     c->mesh_dirty = 2 * n_half;
@@ -2810,7 +2832,7 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
         MS_CHECK((long long)aw * ah < (1ll << 24) && aw < 65536 && ah < 65536, "ms_set_meshes: view %dx%d exceeds the scatter accumulators ([count:24 | sum:40])", aw, ah);
         acc_off[v + 1] = acc_off[v] + 4 * (size_t)hw * hh;
         max_aw = std::max(max_aw, aw); max_ah = std::max(max_ah, ah);
-        max_tiles = std::max(max_tiles, div_up(aw, 64) * div_up(ah, 4));
+        max_tiles = std::max(max_tiles, div_up(aw, 64) * div_up(ah, 4 * MESH_TR));
     }
     const size_t sm_floats = 2 * n_small * NV, sm_bytes = (sm_floats * sizeof(float) + 15) & ~(size_t)15;
     if (!c->mesh_all.p || c->mesh_all_small != n_small || c->mesh_stage_floats < 2 * n_small) {      // first call or another mesh size: drain earlier updates, (re)allocate
@@ -2822,7 +2844,9 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
             c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
-            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, 2 * n_small * sizeof(float) * MAX_VIEWS, hipHostMallocDefault));
+            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, ms_ctx::MESH_STAGE_GENS * (2 * n_small * sizeof(float) * MAX_VIEWS), hipHostMallocDefault));      // (MESH_STAGE_GENS generations)
+            for (bool &b_ : c->mesh_stage_ev_set) b_ = false;
+            c->mesh_stage_gen = 0;
             c->mesh_stage_floats = 2 * n_small;
         }
     }
@@ -2831,17 +2855,23 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
         MS_HIP(hipMemsetAsync(c->disp_dev.p, 0xff, 2 * MAX_VIEWS * sizeof(unsigned), st));
     }
     int tgt[MAX_VIEWS];
-    for (int v = 0; v < NV; ++v) if (int e = mesh_begin_update(c, v, &tgt[v], st)) return e;
+    for (int v = 0; v < NV; ++v) if (int e = mesh_begin_update(c, v, &tgt[v], st, v == 0)) return e;
     // stage the caller's arrays in pinned memory (the view's slot is free once its previous update's copy has run: checked on its event), one copy for all views
     float *sm = (float *)c->mesh_all.p;
     unsigned long long *acc0 = (unsigned long long *)((char *)c->mesh_all.p + sm_bytes);
     MeshJobs T{};
     const int p = c->mesh_all_parity;
+    // the staging generation this call fills: free once the copy of the call a ring ago has run (its own event, recorded right behind that copy).  Until round 5 the host waited
+    // here for the PREVIOUS update, twelve events were recorded and as many waits enqueued per call: a recalibration every 60 frames cost config 3 10.5 % of its frame rate with
+    // 4 % of GPU work in it; now 4.5 % (same-box A/B 22.8 k -> 24.3 k frames/s, profiles/r05_experiments.txt)
+    const int gen = c->mesh_stage_gen;
+    if (c->mesh_stage_ev_set[gen]) MS_HIP(hipEventSynchronize(c->mesh_stage_ev[gen]));      // (blocks only when the caller is a whole ring of updates ahead of the GPU)
+    float *stage_gen = c->mesh_stage + (size_t)gen * MAX_VIEWS * c->mesh_stage_floats;
     for (int v = 0; v < NV; ++v) {
-        bool slot_busy;
-        { std::lock_guard<std::mutex> mk(c->mesh_mu); slot_busy = c->mesh_ready[v] && (c->mesh_wait[v] || c->mesh_set[v]); }
-        if (slot_busy) MS_HIP(hipEventSynchronize(c->mesh_ready[v]));
-        float *stg = c->mesh_stage + (size_t)v * c->mesh_stage_floats;
+        hipEvent_t busy = nullptr;      // a single-view update (ms_set_mesh) of this view may still hold slot v of generation 0
+        { std::lock_guard<std::mutex> mk(c->mesh_mu); if (gen == 0 && c->mesh_ready[v] && !c->mesh_ready_via_chain[v] && (c->mesh_wait[v] || c->mesh_set[v])) busy = c->mesh_ready[v]; }
+        if (busy) MS_HIP(hipEventSynchronize(busy));
+        float *stg = stage_gen + (size_t)v * c->mesh_stage_floats;
         memcpy(stg, mesh_x + (size_t)v * n_small, n_small * 4);
         memcpy(stg + n_small, mesh_y + (size_t)v * n_small, n_small * 4);
         const int aw = c->roi[v].width, ah = c->roi[v].height, hw = aw / 2, hh = ah / 2;
@@ -2855,13 +2885,17 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
         J.disp_word = (unsigned *)c->disp_dev.p + 2 * v + tgt[v];
         J.dx = (float *)dx.data; J.dy = (float *)dy.data;
         J.aw = aw; J.ah = ah; J.hw = hw; J.hh = hh; J.pitch = c->map_pitch[v];
-        J.tiles_x = div_up(aw, 64); J.n_tiles = J.tiles_x * div_up(ah, 4);
+        J.tiles_x = div_up(aw, 64); J.n_tiles = J.tiles_x * div_up(ah, 4 * MESH_TR);
     }
     if (c->mesh_stage_floats == 2 * n_small)
-        MS_HIP(hipMemcpyAsync(sm, c->mesh_stage, sm_floats * sizeof(float), hipMemcpyHostToDevice, st));        // the slots are back to back
+        MS_HIP(hipMemcpyAsync(sm, stage_gen, sm_floats * sizeof(float), hipMemcpyHostToDevice, st));        // the slots are back to back
     else
         for (int v = 0; v < NV; ++v)
-            MS_HIP(hipMemcpyAsync(sm + (size_t)v * 2 * n_small, c->mesh_stage + (size_t)v * c->mesh_stage_floats, 2 * n_small * sizeof(float), hipMemcpyHostToDevice, st));
+            MS_HIP(hipMemcpyAsync(sm + (size_t)v * 2 * n_small, stage_gen + (size_t)v * c->mesh_stage_floats, 2 * n_small * sizeof(float), hipMemcpyHostToDevice, st));
+    if (!c->mesh_stage_ev[gen]) MS_HIP(hipEventCreateWithFlags(&c->mesh_stage_ev[gen], hipEventDisableTiming));
+    MS_HIP(hipEventRecord(c->mesh_stage_ev[gen], st));
+    c->mesh_stage_ev_set[gen] = true;
+    c->mesh_stage_gen = (gen + 1) % ms_ctx::MESH_STAGE_GENS;
     const dim3 blk(64, 4);
     k_mesh_expand_scatter_all<<<dim3(div_up(max_aw, 64), div_up(max_ah, 4 * MESH_SR), NV), blk, 0, st>>>(T, N, M);         // meshwarper.cpp:838-869, every view
     MS_LAUNCH_CHECK();
@@ -2869,7 +2903,7 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
     MS_LAUNCH_CHECK();
     c->mesh_all_dirty = true;
     c->mesh_all_parity ^= 1;
-    for (int v = 0; v < NV; ++v) if (int e = mesh_end_update(c, v, tgt[v], st, false)) return e;
+    for (int v = 0; v < NV; ++v) if (int e = mesh_end_update(c, v, tgt[v], st, false, v == NV - 1 ? 2 : 1)) return e;
     return MS_OK;
 }
 
@@ -2899,7 +2933,7 @@ static int update_mask_async(ms_ctx *c, int view, hipStream_t st)
         std::lock_guard<std::mutex> mk(c->mesh_mu);
         from = c->tab_active; mesh_idx = c->mesh_active[view];
         if (c->stitch_pending) MS_HIP(hipStreamWaitEvent(st, c->last_stitch, 0));
-        if (c->mesh_ready[view]) MS_HIP(hipStreamWaitEvent(st, c->mesh_ready[view], 0));
+        if (c->mesh_ready[view] && !c->mesh_ready_via_chain[view]) MS_HIP(hipStreamWaitEvent(st, c->mesh_ready[view], 0));
         if (c->mesh_chain_set) MS_HIP(hipStreamWaitEvent(st, c->mesh_chain, 0));
         if (c->tab_wait) MS_HIP(hipStreamWaitEvent(st, c->tab_ready, 0));
     }
@@ -2979,7 +3013,7 @@ int ms_update_mask(ms_ctx *c, int view, ms_stream stream)
     if (c->cfg.update_mask_margin > 0) return update_mask_async(c, view, st);
     std::lock_guard<std::recursive_mutex> tables_lk(c->tables_mu);      // synchronous form: safe against a concurrent ms_stitch, which blocks for the rebuild
     if (c->stitch_pending) MS_HIP(hipEventSynchronize(c->last_stitch));
-    if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    if (c->mesh_ready[view]) { hipEvent_t rdy_; { std::lock_guard<std::mutex> mk_(c->mesh_mu); rdy_ = mesh_ready_event(c, view); } if (rdy_) MS_HIP(hipEventSynchronize(rdy_)); }
     if (c->masks_eff.bytes != c->masks.bytes || !c->masks_eff.p) {
         if (int e = c->masks_eff.alloc(c->masks.bytes)) return e;
         MS_HIP(hipMemcpyAsync(c->masks_eff.p, c->masks.p, c->masks.bytes, hipMemcpyDeviceToDevice, st));
@@ -3002,7 +3036,7 @@ int ms_get_mesh_displacement(ms_ctx *c, int view, float *out_px)
     MS_CHECK(out_px != nullptr, "ms_get_mesh_displacement: null output");
     std::lock_guard<std::mutex> lk(c->mesh_update_mu);       // no update in flight while we look; ms_stitch is not blocked by this lock
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view] || !c->disp_dev.p) return fail(MS_ERR_STATE, "ms_get_mesh_displacement: no mesh set for view %d", view);
-    if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));
+    if (c->mesh_ready[view]) { hipEvent_t rdy_; { std::lock_guard<std::mutex> mk_(c->mesh_mu); rdy_ = mesh_ready_event(c, view); } if (rdy_) MS_HIP(hipEventSynchronize(rdy_)); }
     float *h = (float *)pinned_scratch().get(sizeof(float));          // pinned landing zone: see PinnedScratch (common.hpp)
     if (!h) return fail(MS_ERR_NOMEM, "ms_get_mesh_displacement: no pinned staging memory");
     MS_HIP(hipMemcpy(h, (const unsigned *)c->disp_dev.p + 2 * view + c->mesh_active[view], sizeof(float), hipMemcpyDeviceToHost));
@@ -3115,10 +3149,15 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     std::unique_lock<std::mutex> mesh_lk(c->mesh_mu, std::defer_lock);
     if (cpw) {
         mesh_lk.lock();
+        hipEvent_t mesh_waited = nullptr;
         for (int v = 0; v < N; ++v) {
             if (!c->mesh_set[v]) return fail(MS_ERR_STATE, "ms_stitch: enable_cpw is set but view %d has no mesh", v);
             disp.p[v] = (const unsigned *)c->disp_dev.p + 2 * v + c->mesh_active[v];
-            if (c->mesh_wait[v]) { MS_HIP(hipStreamWaitEvent(st, c->mesh_ready[v], 0)); c->mesh_wait[v] = false; }
+            if (c->mesh_wait[v]) {
+                hipEvent_t e = mesh_ready_event(c, v);
+                if (e != mesh_waited) { MS_HIP(hipStreamWaitEvent(st, e, 0)); mesh_waited = e; }      // (the views of one ms_set_meshes call share their event: one wait)
+                c->mesh_wait[v] = false;
+            }
             ms_image mx = mesh_image(c, c->mesh_active[v], v, 0), my = mesh_image(c, c->mesh_active[v], v, 1);
             mesh.x[v] = (const float *)mx.data; mesh.y[v] = (const float *)my.data; mesh.pitch[v] = c->map_pitch[v];
         }
@@ -3553,7 +3592,7 @@ int ms_get_mesh_maps(const ms_ctx *c, int view, ms_image *xm, ms_image *ym)
 {
     if (int e = ctx_check_view(c, view)) return e;
     if (!c->blender_ready || !c->cfg.enable_cpw || !c->mesh_set[view]) return fail(MS_ERR_STATE, "ms_get_mesh_maps: no mesh set for view %d", view);
-    if (c->mesh_ready[view]) MS_HIP(hipEventSynchronize(c->mesh_ready[view]));       // updates are asynchronous: the maps are final after this
+    if (c->mesh_ready[view]) { ms_ctx *mc_ = const_cast<ms_ctx *>(c); hipEvent_t rdy_; { std::lock_guard<std::mutex> mk_(mc_->mesh_mu); rdy_ = mesh_ready_event(mc_, view); } if (rdy_) MS_HIP(hipEventSynchronize(rdy_)); }       // updates are asynchronous: the maps are final after this
     if (xm) *xm = mesh_image(c, c->mesh_active[view], view, 0);
     if (ym) *ym = mesh_image(c, c->mesh_active[view], view, 1);
     return MS_OK;
