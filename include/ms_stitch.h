@@ -332,7 +332,8 @@ MS_API int ms_update_mask(ms_ctx *ctx, int view, ms_stream stream);
 MS_API int ms_set_mesh(ms_ctx *ctx, int view, const float *mesh_x, const float *mesh_y, int N, int M,
                        ms_stream stream);
 /* The same for ALL views of the context in one call -- convertMeshesToMap as the reference calls it (it loops over the images, meshwarper.cpp:823-886):
- * mesh_x / mesh_y = num_views meshes of N x M back to back (HOST).  Two launches per recalibration instead of two per view; bit-identical maps. */
+ * mesh_x / mesh_y = num_views meshes of N x M back to back (HOST).  Two launches and ONE completion event per recalibration instead of two of each per view; bit-identical maps.
+ * The caller's arrays are copied into pinned staging before the call returns (a ring of eight generations: the call blocks only if the caller is eight updates ahead of the GPU). */
 MS_API int ms_set_meshes(ms_ctx *ctx, const float *mesh_x, const float *mesh_y, int N, int M, ms_stream stream);
 /* Or supply the dense maps directly (x_mesh[i], y_mesh[i] GpuMats, APP/timed.cpp:100). DEVICE 32FC1. */
 MS_API int ms_set_mesh_maps(ms_ctx *ctx, int view, const ms_image *x_mesh, const ms_image *y_mesh, ms_stream stream);
