@@ -301,6 +301,61 @@ def test_mesh_double_buffering(ms, cuda):
     comp.close()
 
 
+def test_set_meshes_concurrent_with_stitch_never_tears_a_frame(ms, cuda):
+    """The documented recalibration-thread use (timed.cpp:414-463; shim convertMeshesToMap): ms_set_meshes on its own thread and stream while another thread
+    stitches.  Every stitched frame must be the frame of ONE complete mesh set -- set A or set B for every view -- never a mix of views and never a buffer the
+    expansion kernels are still writing.  ADVICE r05: the batched call published its views one by one and recorded the chain's event only behind the last one, so
+    a stitch that took the mutex in between waited for the PREVIOUS update's record and read the new buffer half written.  cfg2-sized views make the expansion
+    long enough (tens of microseconds per launch) for a stitch to land inside it."""
+    import threading
+    comp, cfg, _ = make_rig(ms, "cfg2", enable_cpw=True)
+    n = cfg["n"]
+    rois = [comp.view_geom(i).roi for i in range(n)]
+    sets = [[synth.mesh(rois[i].width, rois[i].height, 40, 40, phase=0.3 * i + 1.7 * k, amp=9.0) for i in range(n)] for k in range(2)]
+    frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, 0)) for i in range(n)]]
+    pg = comp.pano_geom()
+    shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
+    want = []
+    for k in range(2):
+        comp.set_meshes(sets[k])
+        o = torch.zeros(shape, dtype=torch.int16, device=cuda)
+        comp.stitch(frames, out16s=[o]); torch.cuda.synchronize()
+        want.append(o)
+    assert not torch.equal(want[0], want[1])
+    n_stitch, stop, errs = 150, threading.Event(), []
+
+    def recalibrate():
+        try:
+            torch.cuda.set_device(cuda)
+            side = torch.cuda.Stream()
+            k = 0
+            with torch.cuda.stream(side):
+                while not stop.is_set():
+                    comp.set_meshes(sets[k & 1]); k += 1
+            side.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = threading.Thread(target=recalibrate)
+    th.start()
+    outs = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(n_stitch)]
+    main = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(main):
+            for j in range(n_stitch):
+                comp.stitch(frames, out16s=[outs[j]])
+        main.synchronize()
+    finally:
+        stop.set(); th.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    seen = [0, 0]
+    for j, o in enumerate(outs):
+        a, b = torch.equal(o, want[0]), torch.equal(o, want[1])
+        assert a or b, "frame %d is neither the frame of mesh set A nor of mesh set B: a torn or half-written mesh" % j
+        seen[0 if a else 1] += 1
+    comp.close()
+
+
 @pytest.mark.parametrize("dilate", [False, True])
 def test_seam_scale_calibration_pipeline(ms, cuda, oracle, dilate):
     """stitch_calib's own mask/gain pipeline (APP/calibration.cpp:92-135, 224-237) through ms_calibrate_seam vs the same sequence

@@ -1692,7 +1692,7 @@ struct ms_ctx {
     // ms_set_meshes updates every view behind ONE event: a view whose last update was part of such a call is ready when `mesh_chain` is (a later record of mesh_chain is a later
     // point of the same chain of updates).  Twelve event records and as many stream waits per recalibration were 50 us of idle GPU between its kernels and the next stitch.
     bool mesh_ready_via_chain[MAX_VIEWS] = {};
-    float *mesh_stage = nullptr;       // pinned host staging of the vertex meshes: a ring of MESH_STAGE_GENS generations of MAX_VIEWS slots (ms_set_mesh uses generation 0;
+    float *mesh_stage = nullptr;       // pinned host staging of the vertex meshes: a ring of MESH_STAGE_GENS generations of MAX_VIEWS slots + one generation of ms_set_mesh's own behind it (
     size_t mesh_stage_floats = 0;      // ms_set_meshes walks the ring: the host waits for the COPY of the update a whole ring back -- `mesh_stage_ev` --, never for the update before this one)
     static constexpr int MESH_STAGE_GENS = 8;
     int mesh_stage_gen = 0;
@@ -2718,14 +2718,14 @@ static int mesh_begin_update(ms_ctx *c, int view, int *target, hipStream_t st, b
     }
     return MS_OK;
 }
-// batch = 0: one view's update (its own event + the chain); 1: a view of an ms_set_meshes call (no record); 2: the last view of such a call (the chain, once)
-static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st, bool measure = true, int batch = 0)
+// one view's update: its own event + the chain, both recorded BEFORE the view is published (ms_set_meshes publishes all its views itself, behind one record of the chain)
+static int mesh_end_update(ms_ctx *c, int view, int tgt, hipStream_t st, bool measure = true)
 {
     if (measure) if (int e = measure_mesh_disp(c, view, tgt, st)) return e;
     std::lock_guard<std::mutex> lk(c->mesh_mu);
-    if (batch == 0) MS_HIP(hipEventRecord(c->mesh_ready[view], st));
-    if (batch != 1) MS_HIP(hipEventRecord(c->mesh_chain, st));
-    c->mesh_ready_via_chain[view] = batch != 0;
+    MS_HIP(hipEventRecord(c->mesh_ready[view], st));
+    MS_HIP(hipEventRecord(c->mesh_chain, st));
+    c->mesh_ready_via_chain[view] = false;
     c->mesh_chain_set = true;
     c->mesh_wait[view] = true;
     c->mesh_active[view] = tgt;
@@ -2773,7 +2773,7 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
             c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
-            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, ms_ctx::MESH_STAGE_GENS * (2 * n_small * sizeof(float) * MAX_VIEWS), hipHostMallocDefault));      // (MESH_STAGE_GENS generations)
+            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, (ms_ctx::MESH_STAGE_GENS + 1) * (2 * n_small * sizeof(float) * MAX_VIEWS), hipHostMallocDefault));      // (the ring + ms_set_mesh's own generation behind it)
             for (bool &b_ : c->mesh_stage_ev_set) b_ = false;
             c->mesh_stage_gen = 0;
             c->mesh_stage_floats = 2 * n_small;
@@ -2794,7 +2794,8 @@ int ms_set_mesh(ms_ctx *c, int view, const float *mesh_x, const float *mesh_y, i
     hipEvent_t busy_ev = nullptr;
     { std::lock_guard<std::mutex> mk(c->mesh_mu); slot_busy = c->mesh_ready[view] && (c->mesh_wait[view] || c->mesh_set[view]); if (slot_busy) busy_ev = mesh_ready_event(c, view); }
     if (slot_busy && busy_ev) MS_HIP(hipEventSynchronize(busy_ev));
-    float *stg = c->mesh_stage + (size_t)view * c->mesh_stage_floats;
+    // (generation MESH_STAGE_GENS, outside the ring ms_set_meshes walks: a batched call can never overwrite a slot whose single-view copy has not run yet -- ADVICE r05)
+    float *stg = c->mesh_stage + ((size_t)ms_ctx::MESH_STAGE_GENS * MAX_VIEWS + view) * c->mesh_stage_floats;
     memcpy(stg, mesh_x, n_small * 4);
     memcpy(stg + n_small, mesh_y, n_small * 4);
     MS_HIP(hipMemcpyAsync(sm_x, stg, 2 * n_small * 4, hipMemcpyHostToDevice, st));
@@ -2844,7 +2845,7 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
         if (c->mesh_stage_floats < 2 * n_small) {
             if (c->mesh_stage) (void)hipHostFree(c->mesh_stage);
             c->mesh_stage = nullptr; c->mesh_stage_floats = 0;
-            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, ms_ctx::MESH_STAGE_GENS * (2 * n_small * sizeof(float) * MAX_VIEWS), hipHostMallocDefault));      // (MESH_STAGE_GENS generations)
+            MS_HIP(hipHostMalloc((void **)&c->mesh_stage, (ms_ctx::MESH_STAGE_GENS + 1) * (2 * n_small * sizeof(float) * MAX_VIEWS), hipHostMallocDefault));      // (the ring + ms_set_mesh's own generation behind it)
             for (bool &b_ : c->mesh_stage_ev_set) b_ = false;
             c->mesh_stage_gen = 0;
             c->mesh_stage_floats = 2 * n_small;
@@ -2868,9 +2869,6 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
     if (c->mesh_stage_ev_set[gen]) MS_HIP(hipEventSynchronize(c->mesh_stage_ev[gen]));      // (blocks only when the caller is a whole ring of updates ahead of the GPU)
     float *stage_gen = c->mesh_stage + (size_t)gen * MAX_VIEWS * c->mesh_stage_floats;
     for (int v = 0; v < NV; ++v) {
-        hipEvent_t busy = nullptr;      // a single-view update (ms_set_mesh) of this view may still hold slot v of generation 0
-        { std::lock_guard<std::mutex> mk(c->mesh_mu); if (gen == 0 && c->mesh_ready[v] && !c->mesh_ready_via_chain[v] && (c->mesh_wait[v] || c->mesh_set[v])) busy = c->mesh_ready[v]; }
-        if (busy) MS_HIP(hipEventSynchronize(busy));
         float *stg = stage_gen + (size_t)v * c->mesh_stage_floats;
         memcpy(stg, mesh_x + (size_t)v * n_small, n_small * 4);
         memcpy(stg + n_small, mesh_y + (size_t)v * n_small, n_small * 4);
@@ -2903,7 +2901,20 @@ int ms_set_meshes(ms_ctx *c, const float *mesh_x, const float *mesh_y, int N, in
     MS_LAUNCH_CHECK();
     c->mesh_all_dirty = true;
     c->mesh_all_parity ^= 1;
-    for (int v = 0; v < NV; ++v) if (int e = mesh_end_update(c, v, tgt[v], st, false, v == NV - 1 ? 2 : 1)) return e;
+    // Publish every view in ONE mesh_mu critical section, the chain's record FIRST: a stitch on another thread that takes mesh_mu between two views of a
+    // per-view publication saw mesh_wait[v] set while mesh_chain still held the PREVIOUS update's record (or none), waited for that, cleared the flag and read the
+    // buffer k_mesh_mean_resize_all was still writing.  A stitch now sees either none of this call's views or all of them, behind this call's record.
+    {
+        std::lock_guard<std::mutex> mk(c->mesh_mu);
+        MS_HIP(hipEventRecord(c->mesh_chain, st));
+        c->mesh_chain_set = true;
+        for (int v = 0; v < NV; ++v) {
+            c->mesh_ready_via_chain[v] = true;
+            c->mesh_wait[v] = true;
+            c->mesh_active[v] = tgt[v];
+            c->mesh_set[v] = true;
+        }
+    }
     return MS_OK;
 }
 
