@@ -46,6 +46,9 @@ typedef struct ms_dist_info {
  * implementation of the same entry points (tests/fake_rccl.cpp) -- names the file here, once per process, BEFORE the first RCCL id / communicator
  * (MS_ERR_STATE afterwards; NULL or "" restores the default).  The library reads no environment variable for this. */
 MS_API int ms_dist_set_rccl_library(const char *path);
+/* The file the RCCL entry points resolved from (realpath of dladdr(ncclCommInitRank)), NUL-terminated into out[cap]; resolves RCCL on first use.  bench.py --gpus N and
+ * stitch_dist print it before their first timed region: with PyTorch in the process two copies of librccl exist on a ROCm box, and the record should say which one ran. */
+MS_API int ms_dist_rccl_library_path(char *out, size_t cap);
 
 /* Rank 0 calls this once and hands the bytes to every rank (file, pipe, torch.distributed store, a shared variable between threads).
  * transport AUTO: RCCL when this process sees at least `nranks` devices, else HOST. */

@@ -9,6 +9,25 @@ for p in (os.path.join(ROOT, "video-stitcher_amd"), os.path.join(ROOT, "oracle")
         sys.path.insert(0, p)
 
 
+def _memoise_synth_frames():
+    """synth.frame is pure numpy in fp64: 0.2 s for a 1080p frame, about a second for a 4K one -- a dozen cfg5 tests regenerated the same 12 x 4K frames (5 - 8 s each, most of
+    their run time).  Same bytes, generated once per session; the tests only read them (to_dev copies to the device; none edits a frame in place)."""
+    import functools
+    import synth
+    orig = synth.frame
+
+    @functools.lru_cache(maxsize=160)
+    def cached(w, h, i, t, noise):
+        return orig(w, h, i, t, noise)
+
+    def frame(w, h, i, t, noise=True):
+        if w * h < 1280 * 720:
+            return orig(w, h, i, t, noise)
+        return cached(w, h, i, t, noise)
+    synth.frame = frame
+
+
+_memoise_synth_frames()
 os.environ.setdefault("MS_CHECK_DIVIDE", "1")      # ms_init_blender checks the shared-reciprocal division over the context's own denominators
 
 try:        # hypothesis suites: a fresh seed per calendar day (printed in the header, reproducible with MS_TEST_SEED=n), not the same examples forever;

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -267,6 +268,7 @@ FR_API ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
 FR_API ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank)
 {
     if (!out || nranks < 1 || nranks > 16 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    if (const char *h = getenv("FAKE_RCCL_HANG_S")) sleep((unsigned)atoi(h));
     ncclComm *c = new ncclComm();
     c->rank = rank; c->nranks = nranks;
     (void)hipGetDevice(&c->device);
@@ -329,7 +331,16 @@ FR_API ncclResult_t ncclCommDestroy(ncclComm_t c)
     return ncclSuccess;
 }
 
-FR_API ncclResult_t ncclCommCount(const ncclComm_t c, int *n) { if (!c || !n) return ncclInvalidArgument; *n = c->nranks; return ncclSuccess; }
+// Two fault injections for the bench's fail-loudly paths (tests/test_bench_gpu.py), read from the environment of THIS test library only:
+//   FAKE_RCCL_COUNT_DELTA=d   ncclCommCount reports nranks + d (a communicator that did not form over all ranks)
+//   FAKE_RCCL_HANG_S=s        ncclCommInitRank sleeps s seconds before it does anything (a bring-up that hangs: the bench's watchdog must end the run)
+FR_API ncclResult_t ncclCommCount(const ncclComm_t c, int *n)
+{
+    if (!c || !n) return ncclInvalidArgument;
+    const char *d = getenv("FAKE_RCCL_COUNT_DELTA");
+    *n = c->nranks + (d ? atoi(d) : 0);
+    return ncclSuccess;
+}
 
 FR_API ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s)
 {

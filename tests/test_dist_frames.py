@@ -75,3 +75,25 @@ def test_single_rank_gather_is_identity():
     slab = torch.arange(24, dtype=torch.uint8).reshape(1, 2, 4, 3)
     work, gl = df.gather_slabs(slab, 0, 1)
     assert work is None and gl[0] is slab
+
+
+def test_bench_plumbing_verdict_rules():
+    """The fail-loudly rules of `bench.py --gpus N` (benchlib/dist_run.py::plumbing_verdict; VERDICT r05 item 5a) as a pure function: a multi-rank run stops BEFORE its first
+    timed region -- one JSON line with `failed` / `incomplete`, exit code 2 -- when two ranks drive one GPU without MS_BENCH_SHARE_GPU, when RCCL's own communicator does
+    not count N ranks, or when RCCL's all-gather of the bus ids shows a duplicate; nothing else stops it."""
+    import types
+    sys.path.insert(0, ROOT)
+    from benchlib import dist_run as DR
+    ranks = lambda ids: {"ranks": [{"pci_bus_id": i} for i in ids], "duplicate_bus_ids": DR.duplicate_bus_ids(ids)}
+    ok_info = {"transport": "rccl", "comm_nranks": 2, "pci_bus_ids": ["0000:05:00.0", "0000:15:00.0"]}
+    assert DR.duplicate_bus_ids(["a", "b"]) is False and DR.duplicate_bus_ids(["a", "a"]) is True and DR.duplicate_bus_ids(["?", "?"]) is False
+    assert DR.plumbing_verdict(ranks(["a", "b"]), ok_info, 2, False) is None
+    assert "same GPU" in DR.plumbing_verdict(ranks(["a", "a"]), None, 2, False)
+    assert DR.plumbing_verdict(ranks(["a", "a"]), {"transport": "host", "comm_nranks": 0}, 2, True) is None          # the declared debug mode: ranks share cuda:0 on purpose
+    assert "counts 1 ranks" in DR.plumbing_verdict(ranks(["a", "b"]), dict(ok_info, comm_nranks=1), 2, False)
+    assert "all-gather" in DR.plumbing_verdict(ranks(["a", "b"]), dict(ok_info, pci_bus_ids=["x", "x"]), 2, False)
+    line = DR.fail_line(types.SimpleNamespace(steps=3, warmup=1, config="cfg2"), 2, "why", ok_info)
+    assert line["value"] is None and line["failed"] is True and line["incomplete"] == "why" and line["n_gpus"] == 2 and line["dist"] == ok_info
+    for k in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line
+    assert DR.watchdog_seconds() <= 120.0 or "MS_BENCH_WATCHDOG_S" in os.environ      # a hang must leave a line inside a 1 800 s lease with three regions

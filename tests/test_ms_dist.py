@@ -218,3 +218,16 @@ print("host still works:", msdist.id_transport(msdist.unique_id(2, msdist.HOST))
     assert "first use:" in out and "could not be loaded" in out, out
     assert "second call:" in out and "already been resolved" in out, out
     assert "host still works: True" in out, out
+
+
+def test_one_rccl_per_process_next_to_torch():
+    """With PyTorch in the process a ROCm box holds two copies of librccl (torch/lib/librccl.so and /opt/rocm/lib/librccl.so.1, same soname).  The product must resolve
+    RCCL's entry points from the copy that is ALREADY mapped (RTLD_NOLOAD first), so that one process runs one RCCL; ms_dist_rccl_library_path reports which file that is
+    (bench.py --gpus N prints it before its first timed region).  No GPU needed: resolving the library creates no communicator."""
+    import torch  # noqa: F401  (maps torch's own librccl)
+    import msdist
+    path = msdist.rccl_library_path()
+    if path is None:
+        pytest.skip("no librccl on this machine")
+    mapped = sorted({os.path.realpath(l.split()[-1]) for l in open("/proc/self/maps") if "librccl" in l})
+    assert mapped == [path], (mapped, path)

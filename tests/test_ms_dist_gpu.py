@@ -192,6 +192,10 @@ with torch.cuda.stream(side):
 side.synchronize()
 dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
 assert torch.equal(a, b) and float(t[0]) == 1.0 and info["transport"] == "rccl" and info["comm_nranks"] == 1
+# ONE RCCL per process (VERDICT r05 item 5b): the file the product resolved its entry points from is the very librccl torch's initialised NCCL process group runs on
+# (PyTorch ships its own copy under the same soname; a second copy beside it would mean two sets of RCCL globals / proxy threads in one process)
+mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+assert len(mapped) == 1 and os.path.realpath(mapped[0]) == info["librccl_path"] == msdist.rccl_library_path(), (mapped, info["librccl_path"])
 d.close(); dist.destroy_process_group()
 print("OK", info["rccl_version"])
 ''' % ROOT

@@ -36,13 +36,9 @@ def csrc_sha16(root):      # same hash as bench.py's: the line flags a summary w
     return h.hexdigest()[:16]
 
 
-def main(out, tag, cfg, frames):
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prof = os.path.join(root, "profiles")
-    os.makedirs(prof, exist_ok=True)
-    rocpd_stats.main(os.path.join(out, "trace", "trace_results.db"), os.path.join(prof, "%s_kernel_trace.txt" % tag))
-    fetch = counters(os.path.join(out, "fetch", "fetch_results.db"), "FETCH_SIZE")
-    write = counters(os.path.join(out, "write", "write_results.db"), "WRITE_SIZE")
+def build_summary(fetch, write, tag, cfg, frames, root):
+    """fetch / write: {kernel name: (mean counter value in KB, launches, mean ns)} of the FETCH_SIZE / WRITE_SIZE passes -> the summary dict (per-kernel HBM bytes per launch,
+    calibrated on the 1 GiB k_calib_copy of the same run).  Used by this script (profiles/) and by bench.py's in-run PMC pass (benchlib/pmc.py)."""
     GiB = float(1 << 30)
     cal_r = [v for k, v in fetch.items() if "k_calib_copy" in k]
     cal_w = [v for k, v in write.items() if "k_calib_copy" in k]
@@ -98,6 +94,17 @@ def main(out, tag, cfg, frames):
     res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()
                                         if (k.startswith(per_frame) or k == "k_down") and k not in alias))
     res["calls"] = steps
+    return res
+
+
+def main(out, tag, cfg, frames):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    rocpd_stats.main(os.path.join(out, "trace", "trace_results.db"), os.path.join(prof, "%s_kernel_trace.txt" % tag))
+    fetch = counters(os.path.join(out, "fetch", "fetch_results.db"), "FETCH_SIZE")
+    write = counters(os.path.join(out, "write", "write_results.db"), "WRITE_SIZE")
+    res = build_summary(fetch, write, tag, cfg, frames, root)
     path = os.path.join(prof, "%s_traffic.json" % tag)
     json.dump(res, open(path, "w"), indent=1, sort_keys=True)
     shutil.copyfile(path, os.path.join(prof, "traffic_%s.json" % cfg))

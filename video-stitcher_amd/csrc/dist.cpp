@@ -17,6 +17,7 @@
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -392,6 +393,22 @@ int p2p(ms_dist *d, bool send, void *buf, size_t bytes, int peer, int mem, hipSt
 using namespace ms;
 
 extern "C" {
+
+// The file the RCCL entry points were resolved from (dladdr of ncclCommInitRank): what a first multi-GPU run prints BEFORE its timed regions, so that "which librccl
+// did the product load next to PyTorch's own copy" is a fact of the record, not a guess.  Resolves RCCL if that has not happened yet; "" (MS_ERR_COMM) when none loads.
+int ms_dist_rccl_library_path(char *out, size_t cap)
+{
+    if (!out || cap == 0) return fail(MS_ERR_INVALID, "ms_dist_rccl_library_path: null buffer");
+    out[0] = 0;
+    Rccl &R = rccl();
+    if (!R.ok) return fail(MS_ERR_COMM, "RCCL is not available: %s", R.why);
+    Dl_info di{};
+    if (!dladdr(reinterpret_cast<void *>(R.CommInitRank), &di) || !di.dli_fname) return fail(MS_ERR_COMM, "dladdr found no file for ncclCommInitRank");
+    char real[4096];
+    const char *name = realpath(di.dli_fname, real) ? real : di.dli_fname;
+    snprintf(out, cap, "%s", name);
+    return MS_OK;
+}
 
 int ms_dist_set_rccl_library(const char *path)
 {

@@ -15,7 +15,7 @@ MAX_RANKS = 16
 EXPORTS = [
     "ms_dist_unique_id", "ms_dist_create", "ms_dist_destroy", "ms_dist_get_info", "ms_dist_send", "ms_dist_recv", "ms_dist_group_begin",
     "ms_dist_group_end", "ms_dist_broadcast", "ms_dist_barrier", "ms_dist_gather_slabs", "ms_dist_mesh_exchange", "ms_dist_apply_meshes",
-    "ms_dist_set_rccl_library",
+    "ms_dist_set_rccl_library", "ms_dist_rccl_library_path",
 ]
 
 
@@ -32,6 +32,14 @@ class MeshUpdate(C.Structure):
 def set_rccl_library(path):
     """Name the RCCL library file (before the first RCCL id / communicator of the process); None restores the default search."""
     ms._chk(ms.load().ms_dist_set_rccl_library(None if path is None else str(path).encode()))
+
+
+def rccl_library_path():
+    """The file the product resolved RCCL's entry points from (realpath), or None when no RCCL loads."""
+    buf = C.create_string_buffer(4096)
+    if ms.load().ms_dist_rccl_library_path(buf, C.c_size_t(4096)) != 0:
+        return None
+    return buf.value.decode() or None
 
 
 def unique_id(nranks, transport=AUTO):
@@ -84,7 +92,8 @@ class Dist:
         ms._chk(ms.load().ms_dist_get_info(self._h, C.byref(i)))
         return {"rank": i.rank, "nranks": i.nranks, "transport": {RCCL: "rccl", HOST: "host"}.get(i.transport, "?"), "rccl_version": i.rccl_version,
                 "comm_nranks": i.comm_nranks, "devices": [i.device[r] for r in range(i.nranks)],
-                "pci_bus_ids": [bytes(i.pci_bus_id[r]).split(b"\0")[0].decode() for r in range(i.nranks)]}
+                "pci_bus_ids": [bytes(i.pci_bus_id[r]).split(b"\0")[0].decode() for r in range(i.nranks)],
+                "librccl_path": (rccl_library_path() if i.transport == RCCL else None)}
 
     def send(self, buf, peer):
         p, n, mem = _ptr_bytes(buf)
