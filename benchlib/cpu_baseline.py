@@ -56,7 +56,7 @@ def _physical_cores_of_one_socket():
         return max(1, ncpu // 2)
 
 
-def cpu_baseline(cfg, gains, comp, frames=None, resize=None, budget_s=12.0):
+def cpu_baseline(cfg, gains, comp, frames=None, resize=None, budget_s=None):
     """Time the reference's CPU pipeline as the oracle restates it (oracle/ms_oracle_cpu.c + ms_oracle_prims.c: "port"): per view [cv::resize by
     compose_scale,] cv::remap in its fixed-point CPU arithmetic -> convertTo(gain) -> convertTo(16S) -> CPU MultiBandBlender::feed (Laplacian pyramid
     with cv::pyrDown / pyrUp's (x + 128) >> 8 / (x + 32) >> 6 rounding, weight pyramid rebuilt on every call: blenders.cpp:585-696), then blend
@@ -66,6 +66,8 @@ def cpu_baseline(cfg, gains, comp, frames=None, resize=None, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     import synth
+    if budget_s is None:      # ~12 s of CPU work by default; MS_BENCH_CPU_BUDGET_S shortens the sample (the test suite does: the sample's length is not what it tests)
+        budget_s = float(os.environ.get("MS_BENCH_CPU_BUDGET_S", "12"))
     ncpu, nphys = os.cpu_count() or 1, _physical_cores_of_one_socket()
     rois = [comp.view_geom(i).roi.tuple() for i in range(cfg["n"])]
     b = O.Blender([r[:2] for r in rois], [r[2:] for r in rois], comp.pano_geom().num_bands, cpu_flavour=True)

@@ -35,7 +35,7 @@ def measure(config, frames_per_call, distinct=8, frame_source="numpy", timeout_s
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", config, "--frames", str(frames_per_call), "--streams", "1", "--steps", "3", "--warmup", "1",
-             "--passes", "1", "--distinct", str(distinct), "--frame-source", frame_source, "--calib"]      # (the SAME number of distinct frame sets as the timed region: frames of one launch that share a set hit in L2)
+             "--passes", "1", "--distinct", str(distinct), "--frame-source", "device", "--calib"]      # (frames generated on the device: the counters see addresses, not content, and 48 numpy frames cost the child 5 s)      # (the SAME number of distinct frame sets as the timed region: frames of one launch that share a set hit in L2)
     got = {}
     try:
         for ctr, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -49,6 +49,9 @@ def measure(config, frames_per_call, distinct=8, frame_source="numpy", timeout_s
             got[tag] = _counters(db, ctr)
         res = st.build_summary(got["fetch"], got["write"], "in-run", config, frames_per_call, ROOT)
         res["seconds"] = round(time.perf_counter() - t0, 1)
+        if os.environ.get("MS_PMC_DUMP"):      # developer aid: the whole per-kernel summary of the in-run passes
+            import json
+            json.dump(res, open(os.environ["MS_PMC_DUMP"], "w"), indent=1, sort_keys=True)
         return res, None
     except (subprocess.TimeoutExpired, sqlite3.Error, OSError, KeyError, IndexError, ZeroDivisionError) as e:
         return None, "%s: %s" % (type(e).__name__, str(e)[:200])

@@ -19,7 +19,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 APP = os.path.join(ROOT, "video-stitcher_amd", "stitch_dist")
 
 
+_REF_RUNS = {}      # single-rank reference runs are pure functions of their arguments: a dozen tests ask for the same ones
+
+
 def run(*args, rig="mini6", timeout=600, env=None):
+    key = (tuple(str(a) for a in args), rig)
+    if env is None and len(args) >= 2 and str(args[0]) == "--gpus" and str(args[1]) == "1":
+        if key not in _REF_RUNS:
+            _REF_RUNS[key] = _run(*args, rig=rig, timeout=timeout, env=None)
+        return _REF_RUNS[key]
+    return _run(*args, rig=rig, timeout=timeout, env=env)
+
+
+def _run(*args, rig="mini6", timeout=600, env=None):
     cfg = synth.CONFIGS[rig]
     base = ["--views", cfg["n"], "--size", "%dx%d" % (cfg["w"], cfg["h"]), "--out", "%dx%d" % (cfg["out_w"], cfg["out_h"]), "--hfov", cfg["hfov_deg"], "--bands", cfg["num_bands"]]
     out = subprocess.run([APP] + [str(a) for a in base + list(args)], capture_output=True, timeout=timeout, env=env)
@@ -357,6 +369,6 @@ def _make_fake_id(world, fake_lib, q):
 
 def test_rccl_branch_full_size_config2_over_the_loopback_library(cuda):
     """BASELINE configs[3]'s shape at full size: 6 x 1080p -> 3840 x 1920, 4 frame-parallel ranks, 3.6 MB I420 slabs per frame through ncclSend / ncclRecv."""
-    one = run("--gpus", 1, "--frames", 16, "--batch", 4, rig="cfg2")
-    res = run(*fake(4), "--frames", 16, "--batch", 2, rig="cfg2", env=FAKE_ENV)
+    one = run("--gpus", 1, "--frames", 8, "--batch", 2, rig="cfg2")
+    res = run(*fake(4), "--frames", 8, "--batch", 1, rig="cfg2", env=FAKE_ENV)
     assert _is_fake_rccl(res, 4) and res["checksum_all"] == one["checksum_all"]

@@ -14,7 +14,7 @@ for cfg in ${AB_CFGS:-cfg2}; do
       MSSTITCH_LIB=$PWD/$lib python bench.py --config $cfg --no-cpu-baseline --steps 40 --warmup 5 --passes 2 --no-live --no-pcie --no-verify --no-distinct --streams 1 --frames ${AB_FRAMES:-32} --recalib-every 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_call']; print(round(d['value']), {a: round(b*1e3,1) for a,b in k.items() if b > 0.03})"
       if [ "$cfg" = cfg2 ] && [ -z "${AB_NO3:-}" ]; then
         echo -n "[$r] $cfg $ent 3x32: "
-        MSSTITCH_LIB=$PWD/$lib python bench.py --no-cpu-baseline --steps 20 --warmup 5 --no-live --no-pcie --no-verify --no-distinct 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']))"
+        MSSTITCH_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-others --no-pmc --steps 20 --warmup 5 --no-live --no-pcie --no-verify --no-distinct 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']))"
       fi
       [ -n "$kv" ] && unset "${kv%%=*}"
     done

@@ -88,9 +88,10 @@ def build_summary(fetch, write, tag, cfg, frames, root):
             alias["k_down_l0"] = v
     res["kernels"].update(alias)
     # HBM bytes of one ms_stitch call (all per-frame kernels): what bench.py's frame_roofline.frac_traffic divides by the GPU time
-    per_frame = ("k_resize_linear3", "k_warp_t", "k_warp_s", "k_stage1_s", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
+    per_frame = ("k_resize_linear3", "k_warp_t<", "k_warp_s<", "k_stage1_s", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
                  "k_blend<", "k_blend_top", "k_single_band")
-    steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t", "k_warp_s", "k_warp_a", "k_warp<"))] or [1])
+    # (the "<" matters: k_warp_tabs is a calibration kernel, launched once per view -- 12 times for the 12 x 4K rig, more often than a short collection launches the warp)
+    steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t<", "k_warp_s<", "k_warp_a", "k_warp<"))] or [1])
     res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()
                                         if (k.startswith(per_frame) or k == "k_down") and k not in alias))
     res["calls"] = steps
