@@ -236,7 +236,8 @@ FAKE_ENV = dict(os.environ, GPU_MAX_HW_QUEUES="32")
 
 def _is_fake_rccl(res, ranks):
     d = res["dist"]
-    return d["transport"] == "rccl" and d["nranks"] == ranks and d["comm_nranks"] == ranks and d["rccl_version"] == 29999
+    return (d["transport"] == "rccl" and d["nranks"] == ranks and d["comm_nranks"] == ranks and d["rccl_version"] == 29999
+            and os.path.realpath(d["librccl_path"]) == os.path.realpath(FAKE_RCCL))      # (stitch_dist prints the file the entry points were resolved from)
 
 
 @pytest.mark.parametrize("ranks,batch", [(2, 4), (4, 2), (4, 1)])

@@ -456,13 +456,15 @@ int main(int argc, char **argv)
     }
     times += "]";
     const long long frames_done = o.checksum ? (long long)sh.frame_sums.size() : o.frames;
+    char rccl_path[1024] = "";      // the file the RCCL entry points were resolved from (host transport: never resolved, stays empty)
+    if (sh.info.transport == MS_DIST_RCCL) (void)ms_dist_rccl_library_path(rccl_path, sizeof rccl_path);
     printf("{\"app\": \"stitch_dist\", \"gpus\": %d, \"col_shards\": %d, \"groups\": %d, \"share_gpu\": %s, \"views\": %d, \"src\": \"%dx%d\", \"out\": \"%dx%d\", \"bands\": %d, "
            "\"cpw\": %s, \"recalib_every\": %d, \"recalibrations_applied\": %d, \"batch\": %d, \"frames\": %lld, \"seconds\": %.4f, \"frames_per_s\": %.1f, "
-           "\"dist\": {\"transport\": \"%s\", \"nranks\": %d, \"comm_nranks\": %d, \"rccl_version\": %d, \"devices\": %s, \"pci_bus_ids\": %s}, "
+           "\"dist\": {\"transport\": \"%s\", \"nranks\": %d, \"comm_nranks\": %d, \"rccl_version\": %d, \"librccl_path\": \"%s\", \"devices\": %s, \"pci_bus_ids\": %s}, "
            "\"views_read_per_rank\": %s, \"per_rank\": %s, \"i420_rows\": %d, \"first_frame_checksum\": \"%016llx\", \"last_frame_checksum\": \"%016llx\", \"checksum_all\": \"%016llx\"}\n",
            o.gpus, o.col_shards, o.gpus / o.col_shards, o.share_gpu ? "true" : "false", o.views, o.w, o.h, o.out_w, o.out_h, sh.bands,
            o.cpw ? "true" : "false", o.recalib_every, sh.recalibrations, o.batch, frames_done, sh.seconds, frames_done / sh.seconds,
-           sh.info.transport == MS_DIST_RCCL ? "rccl" : "host", sh.info.nranks, sh.info.comm_nranks, sh.info.rccl_version, devs.c_str(), pcis.c_str(),
+           sh.info.transport == MS_DIST_RCCL ? "rccl" : "host", sh.info.nranks, sh.info.comm_nranks, sh.info.rccl_version, rccl_path, devs.c_str(), pcis.c_str(),
            reads.c_str(), times.c_str(), sh.i_rows, sh.frame_sums.empty() ? 0ull : sh.frame_sums.front(), sh.frame_sums.empty() ? 0ull : sh.frame_sums.back(), all);
     return 0;
 }
