@@ -87,6 +87,11 @@ def parse_args():
         args.no_others = True
         if not args.pmc_child and (args.calib or args.emulate_gather or args.gpus > 1 or args.streams not in (None, 1)):
             args.no_pmc = True
+    # ... and neither does a run that is itself being profiled (tools/*.sh wrap bench.py in rocprofv3: no profiler inside a profiler)
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY", "HSA_TOOLS_LIB")):
+        args.no_pmc = True
+        if not args.pmc_child:
+            args.no_others = True
     if args.pmc_child:
         args.no_live = args.no_pcie = args.no_verify = args.no_cpu_baseline = args.no_distinct = args.no_others = args.no_pmc = True
     if args.view_shards > 1 or args.col_shards > 1:          # one context per shard, no stream splitting

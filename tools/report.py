@@ -62,8 +62,10 @@ def main(tag):
             "%.2f" % busy if busy is not None else "-", "%.1f" % occ if occ is not None else "-"))
     r = bench["roofline"]
     lines += ["", "bench.py: **%.0f frames/s** (%s); dominant kernel `%s`: %.0f MB of PMC-measured HBM traffic / %.1f µs = %.0f GB/s = **%.3f of 8 TB/s** (physical; %s); "
-              "by SURVEY 8(d)'s algorithmic bytes (%.0f MB per launch) %.3f." % (bench["value"], bench["config"]["workload"], r["kernel"], (r["traffic"] or 0) / 1e6, r["mean_launch_ms"] * 1e3,
-                                                                                   r["achieved"], r["frac"], r.get("basis", "?"), r["alg_bytes_per_launch"] / 1e6, r.get("frac_contract", 0.0)),
+              "model ratio on SURVEY 8(d)'s algorithmic bytes (%.0f MB per launch): %.3f." % (bench["value"], bench["config"]["workload"], r["kernel"], (r["traffic"] or 0) / 1e6, r["mean_launch_ms"] * 1e3,
+                                                                                   r["achieved"] or 0.0, r["frac"] or 0.0, r.get("basis", "?"),
+                                                                                   (bench.get("model", {}).get("kernel_alg_bytes_per_launch") or r.get("alg_bytes_per_launch", 0)) / 1e6,
+                                                                                   bench.get("model", {}).get("ratio_kernel_alg_bytes_over_peak", r.get("frac_contract", 0.0))),
               "ceiling measured in the same run: tuned copy %.2f TB/s, read %.2f TB/s." % (bench["ceiling"]["copy_TBps"], bench["ceiling"]["read_TBps"]) if bench.get("ceiling") and "copy_TBps" in bench["ceiling"] else "",
               "cpu_baseline: %.1f frames/s on %d threads of %s (%s)." % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["cores"],
                                                                           bench["cpu_baseline"].get("cpu", "?"), bench["cpu_baseline"]["kind"]) if "cpu_baseline" in bench else ""]
