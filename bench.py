@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gather-every", type=int, default=0, help="N>1: the main timed region gathers the slabs of every k-th pass (default 0: the live rate of BASELINE configs[3], about 30 batches per second "
                     "and rank; 1: EVERY frame of every rank reaches the sink inside the timed region -- then `value` is the conservative every-frame figure)")
-    ap.add_argument("--frames", type=int, default=None, help="frames per pass, split evenly over --streams contexts (default 96 = 3 x 32; cfg3 / shipped: 32 on one context; cfg5: 48 = 3 x 16; 1 = live mode)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per pass, split evenly over --streams contexts (default 96 = 3 x 32; cfg3: 32, shipped: 64 on one context; cfg5: 48 = 3 x 16; 1 = live mode; at most 64 per context)")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5", "shipped"],
                     help="cfg2 / cfg3 / cfg5 = BASELINE configs[1] / [2] / [4] geometry; shipped = the configuration the reference ships (defs.h:25-27,51-55,65-66, "
                          "calibration.cpp:100,147-194): cylindrical warper, COMPOSE_MEGAPIX 1.4 (every frame through cuda::resize INSIDE the timed region), "

@@ -44,8 +44,8 @@ class Opt:
         self.__dict__.update(kw)
         if self.streams is None:      # cfg3 / shipped re-expand the CPW meshes on every context: one context there, three elsewhere
             self.streams = 1 if self.config in ("cfg3", "shipped") else 3
-        if self.frames is None:       # 32 frames per ms_stitch call (the ABI's per-call limit; cfg5: 16): profiles/r03_batch_sweep.txt
-            self.frames = {"cfg5": 16}.get(self.config, 32) * self.streams
+        if self.frames is None:       # frames per ms_stitch call: 32 (16 for the 12 x 4K geometry), 64 -- the ABI's limit since round 6 -- for the shipped rig, the one configuration that
+            self.frames = {"cfg5": 16, "shipped": 64}.get(self.config, 32) * self.streams      # gains from it (+1.9 ... 3.2 %; profiles/r06_batch_sweep.txt, r03_batch_sweep.txt)
 
 
 class Workload:

@@ -245,7 +245,7 @@ typedef struct ms_config {
     int num_bands;          /* MultiBandBlender num_bands (blenders.hpp:129 default 5; calibration.cpp:193) */
     int enable_cpw;         /* enable_local (APP/defs.h:27): second remap through the mesh maps       */
     int out_width, out_height;   /* equirect canvas (0,0 = emit the pano ROI only)                     */
-    int max_frames;         /* frames batched per ms_stitch call (1 = live; >1 amortises launches)    */
+    int max_frames;         /* frames batched per ms_stitch call (1 = live; >1 amortises launches; <= 64) */
     int view_shards;        /* 0 / 1 = this context composites whole frames; S = 2..4: it owns one shard of the views (ms_stitch_partial) */
     int view_shard_index;   /* which shard, 0 .. S-1                                                   */
     int cpu_flavour_remap;  /* != 0: the projection warp uses cv::remap's CPU arithmetic (1/32-px coordinates, 15-bit weights): the

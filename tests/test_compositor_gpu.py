@@ -240,16 +240,24 @@ def test_synchronous_update_mask_is_safe_beside_a_stitching_thread(ms, cuda):
     comp.close()
 
 
-@pytest.mark.parametrize("nf", [3, 32])        # 32 frames x 6 views = the per-call limits of the ABI (MS_MAX_FRAMES, 192 sources)
-def test_batched_frames_equal_single_frames(ms, cuda, nf):
-    comp, cfg, gains = make_rig(ms, "mini6", max_frames=nf)
+@pytest.mark.parametrize("nf,rig,cpw", [(3, "mini6", False), (32, "mini6", False), (64, "mini6", False), (40, "mini6", True), (64, "mini4", True)])
+def test_batched_frames_equal_single_frames(ms, cuda, nf, rig, cpw):
+    """Frames per ms_stitch call up to the ABI's limit (64 since round 6).  The kernels that read the callers' frames take their pointers in a by-value table of 192 entries, so a
+    call of more frames than 192 / views (32 for six views, 48 for four) sends those launches out in CHUNKS -- each with its own table, the per-frame buffers offset by the chunk's
+    first frame -- while the reduce and band chains cover all frames at once: 64 and 40 frames (a full chunk + a short one) must equal the same frames stitched one per call,
+    without and with CPW (the first remap and the mesh remap are both chunked)."""
+    comp, cfg, gains = make_rig(ms, rig, max_frames=nf, enable_cpw=cpw)
+    if cpw:
+        for i in range(cfg["n"]):
+            r = comp.view_geom(i).roi
+            comp.set_mesh(i, *synth.mesh(r.width, r.height, 9, 11, phase=0.3 * i, amp=5.0))
     pg = comp.pano_geom()
     shape = (pg.dst_roi_final.height, pg.dst_roi_final.width, 3)
     frames = [[to_dev(synth.frame(cfg["w"], cfg["h"], i, t)) for i in range(cfg["n"])] for t in range(nf)]
     batch = [torch.zeros(shape, dtype=torch.int16, device=cuda) for _ in range(nf)]
     comp.stitch(frames, out16s=batch)
     with pytest.raises(ms.MsError):
-        ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), max_frames=33)
+        ms.Compositor(cfg["n"], (cfg["w"], cfg["h"]), ms.PROJ_SPHERICAL, synth.warp_scale(cfg["out_w"]), max_frames=65)
     for t in range(nf):
         single = torch.zeros(shape, dtype=torch.int16, device=cuda)
         comp.stitch([frames[t]], out16s=[single])

@@ -19,10 +19,10 @@ bash tools/profile_counters.sh ${TAG}_cfg3 cfg3 32 > $PO/counters_cfg3.log 2>&1
 cp gpurun_out/counters_${TAG}_cfg3.txt profiles/${TAG}_cfg3_counters.txt
 bash tools/profile_traffic.sh ${TAG}_cfg3 cfg3 32 > $PO/traffic_cfg3.log 2>&1
 bash tools/profile_traffic.sh ${TAG}_cfg5 cfg5 16 > $PO/traffic_cfg5.log 2>&1
-bash tools/profile_traffic.sh ${TAG}_shipped shipped 32 > $PO/traffic_shipped.log 2>&1
+bash tools/profile_traffic.sh ${TAG}_shipped shipped 64 > $PO/traffic_shipped.log 2>&1
 bash tools/profile_counters.sh ${TAG}_cfg5 cfg5 16 > $PO/counters_cfg5.log 2>&1
 cp gpurun_out/counters_${TAG}_cfg5.txt profiles/${TAG}_cfg5_counters.txt
-bash tools/profile_counters.sh ${TAG}_shipped shipped 32 > $PO/counters_shipped.log 2>&1
+bash tools/profile_counters.sh ${TAG}_shipped shipped 64 > $PO/counters_shipped.log 2>&1
 cp gpurun_out/counters_${TAG}_shipped.txt profiles/${TAG}_shipped_counters.txt
 bash tools/profile_traffic.sh $TAG cfg2 32 > $PO/traffic.log 2>&1
 python tools/report.py $TAG > $PO/report.log 2>&1

@@ -2090,7 +2090,7 @@ int ms_create(const ms_config *cfg, ms_ctx **out)
     MS_CHECK(cfg->warp_scale > 0.f, "ms_create: warp_scale must be positive");
     MS_CHECK(cfg->num_bands >= 0 && cfg->num_bands < MAX_LEVELS, "ms_create: num_bands %d not in [0,%d)", cfg->num_bands, MAX_LEVELS);
     const int F = cfg->max_frames > 0 ? cfg->max_frames : 1;
-    MS_CHECK(F <= MAX_FRAMES && F * cfg->num_views <= MAX_SRC, "ms_create: max_frames %d (x %d views) exceeds the per-call limits %d / %d", F, cfg->num_views, MAX_FRAMES, MAX_SRC);
+    MS_CHECK(F <= MAX_FRAMES && cfg->num_views <= MAX_SRC, "ms_create: max_frames %d exceeds the per-call limit %d", F, MAX_FRAMES);
     ms_ctx *c = new (std::nothrow) ms_ctx();
     if (!c) return fail(MS_ERR_NOMEM, "ms_create: out of host memory");
     c->cfg = *cfg;
@@ -3103,7 +3103,13 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     S.pstride = c->pacc_stride;
     MS_CHECK(S.mode == 2 || views != nullptr, "ms_stitch: null views");
     PanoDesc P = c->pano;              // (the pointers of the active copy of the tables are filled in under the lock below)
-    SrcTable src{};
+    // Frames per call: up to MAX_FRAMES (64 since round 6).  The kernels that read the callers' frames take their pointers in a by-value table of MAX_SRC entries (a kernel's
+    // arguments are limited to 4 KiB): those launches -- the projection warp, the first CPW remap, the mesh remap -- go out in chunks of f_chunk = MAX_SRC / views frames (32 for six
+    // views, 16 for twelve), each chunk with its own table and the per-frame buffers offset by its first frame; they are the frame's large, bandwidth-bound launches and lose
+    // nothing by it.  Every other kernel of the call (the reduce chain, the tails, the band chain: latency-bound launches whose fixed cost a longer batch amortises) covers all frames.
+    const int F_all = F, f_chunk = std::min(F, std::max(1, MAX_SRC / N));
+    SrcAll src{};
+    auto src_chunk = [&](int f0, int nf) { SrcTable t{}; for (int i = 0; i < nf * N; ++i) { t.p[i] = src.p[f0 * N + i]; t.step[i] = src.step[f0 * N + i]; } return t; };
     for (int i = 0; i < F * N && S.mode != 2; ++i) {
         if (!((c->own_mask >> (i % N)) & 1u)) continue;       // another shard's view: not read
         if (!((c->needed_mask >> (i % N)) & 1u)) continue;    // column sharding: no pixel of this view reaches the window
@@ -3230,14 +3236,19 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
     static const char *blend_names[MAX_LEVELS] = {"k_blend_l0", "k_blend_l1", "k_blend_l2", "k_blend_l3", "k_blend_l4", "k_blend_l5", "k_blend_l6", "k_blend_l7"};
     if (S.mode != 2) {       // (finish mode starts from the partial sums: no warp, no pyramids)
     if (cpw) {
+        for (int fc0 = 0; fc0 < F_all; fc0 += f_chunk) {      // (source-table chunks: see f_chunk above)
+            const int F = std::min(f_chunk, F_all - fc0);
+            const SrcTable src = src_chunk(fc0, F);
+            uint8_t *const stage_w = (uint8_t *)c->stage.p + (size_t)fc0 * c->stage_stride, *const g0_w = (uint8_t *)c->g0.p + (size_t)fc0 * c->g0_stride;
+            (void)stage_w; (void)g0_w;
         if (nv12) {        // CPW stage 1 straight from the cameras' NV12 planes (k_stage1_nv12)
             const dim3 b_(WARP_BX, S1_BY_NV);
 #define MS_S1NV_LAUNCH(NF_, ALN_)                                                                                                                                     \
     do {                                                                                                                                                              \
         const dim3 g_(c->n_stage1_tiles, 1, div_up(F, NF_));                                                                                                          \
-        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_stage1_nv12<MS_PROJ_SPHERICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
-        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
-        else k_stage1_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_stage1_nv12<MS_PROJ_SPHERICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F); \
+        else k_stage1_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F); \
     } while (0)
             c->last_stage1_kernel = MS_WARP_KERNEL_NV12;
             if (nv_al) { if (F == 1) MS_S1NV_LAUNCH(1, true); else MS_S1NV_LAUNCH(2, true); }
@@ -3252,13 +3263,13 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             const int s1_nf = s1_env == 2 || s1_env == 3 ? s1_env : ((c->warp_aligned && src_shared) || (c->warp_minification > 0 && c->warp_minification < 1.5)) ? 3 : 2;
             static const int s1_lds = dev_knob("MS_S1_LDS", 0);      // occupancy A/B knob (dynamic LDS nobody touches)
 #define MS_S1_LAUNCH(AL, NF) MS_PROJ_AL_LAUNCH(k_stage1_t, AL, NF, (dim3(c->n_stage1_tiles, 1, div_up(F, NF)), dim3(WARP_BX, S1_BY), s1_lds, st), \
-                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F)
+                    (const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F)
 #define MS_S1S_LAUNCH(NF)                                                                                                                                     \
     do {                                                                                                                                                      \
         const dim3 g_(c->n_stage1_tiles, 1, div_up(F, NF)), b_(WARP_BX, S1_BY);                                                                               \
-        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_stage1_s<MS_PROJ_SPHERICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
-        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_s<MS_PROJ_CYLINDRICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
-        else k_stage1_s<MS_PROJ_PLANE, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride, disp, F); \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_stage1_s<MS_PROJ_SPHERICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_stage1_s<MS_PROJ_CYLINDRICAL, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F); \
+        else k_stage1_s<MS_PROJ_PLANE, NF><<<g_, b_, s1_lds, st>>>((const WarpTile *)c->stage1_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride, disp, F); \
     } while (0)
             if (c->warp_aligned && src_shared) { c->last_stage1_kernel = MS_WARP_KERNEL_SHARED_ALIGNED; if (s1_nf == 3) MS_S1S_LAUNCH(3); else MS_S1S_LAUNCH(2); }
             else if (c->warp_aligned) { c->last_stage1_kernel = MS_WARP_KERNEL_PER_FRAME_ALIGNED; if (s1_nf == 3) MS_S1_LAUNCH(true, 3); else MS_S1_LAUNCH(true, 2); }
@@ -3269,27 +3280,40 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
         else {
             c->last_stage1_kernel = MS_WARP_KERNEL_SIMPLE;
             k_remap_gain<<<dim3(div_up(c->max_aw, 64), div_up(c->max_ah, 4), F * N), blk, 0, st>>>(
-                vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->stage.p, c->stage_stride);
+                vt, N, src, c->cfg.src_height, c->cfg.src_width, stage_w, c->stage_stride);
+        }
         }
         MS_LAUNCH_CHECK();
         if (int e = mark("k_remap_gain")) return e;
+        for (int fc0 = 0; fc0 < F_all; fc0 += f_chunk) {      // (source-table chunks: see f_chunk above)
+            const int F = std::min(f_chunk, F_all - fc0);
+            const SrcTable src = src_chunk(fc0, F);
+            uint8_t *const stage_w = (uint8_t *)c->stage.p + (size_t)fc0 * c->stage_stride, *const g0_w = (uint8_t *)c->g0.p + (size_t)fc0 * c->g0_stride;
+            (void)stage_w; (void)g0_w;
         // the stage images of a view have the same pitch and the same address modulo 4 in every frame BY CONSTRUCTION (stage_stride is a multiple of 256): the mesh remap
         // always takes the shared-offset form.  Its unshared twin (k_warp_t<CPW>) was unreachable in the shipped library and untested: dev-knob builds only.
         if (c->warp_tiled && c->cfg.debug_simple_kernels == 0 && warp_shared_knob) {
             MS_CHECK((c->stage_stride & 3) == 0, "internal: stage image stride %lld not a multiple of 4", c->stage_stride);
             c->last_warp_kernel = MS_WARP_KERNEL_SHARED_ALIGNED;
-            MS_WARP_S_LAUNCH(true, warp_nf(true), warp_lds, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            MS_WARP_S_LAUNCH(true, warp_nf(true), warp_lds, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)stage_w, c->stage_stride, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
         }
 #ifdef MS_DEV_KNOBS
         else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0) {
             c->last_warp_kernel = MS_WARP_KERNEL_PER_FRAME_ALIGNED;
-            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, warp_nf(true))), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            MS_PROJ_LAUNCH(k_warp_t, (true, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, warp_nf(true))), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)stage_w, c->stage_stride, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
         }
 #endif
         else
             k_warp<true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
-                vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)c->stage.p, c->stage_stride, (uint8_t *)c->g0.p, c->g0_stride);
-    } else if (c->warp_tiled && c->cfg.debug_simple_kernels == 0) {
+                vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, (const uint8_t *)stage_w, c->stage_stride, g0_w, c->g0_stride);
+        }
+    } else {
+        for (int fc0 = 0; fc0 < F_all; fc0 += f_chunk) {      // (source-table chunks: see f_chunk above)
+            const int F = std::min(f_chunk, F_all - fc0);
+            const SrcTable src = src_chunk(fc0, F);
+            uint8_t *const stage_w = (uint8_t *)c->stage.p + (size_t)fc0 * c->stage_stride, *const g0_w = (uint8_t *)c->g0.p + (size_t)fc0 * c->g0_stride;
+            (void)stage_w; (void)g0_w;
+        if (c->warp_tiled && c->cfg.debug_simple_kernels == 0) {
         // opt-in (ms_config.warp_lds_stage = 1; MS_WARP_ASYNC=1 in a dev-knob build): source tiles staged in LDS by asynchronous LDS-DMA, persistent waves (k_warp_a) -- bit-identical,
         // measured slower than the direct gathers on config 2 (353 vs 242 us per 16 frames: at its 1.6-2.1 x minification only 54 % of the tiles' source
         // boxes fit a staging buffer and 10 waves per CU cannot hide what 20 do; profiles/r02_warp_probes.txt)
@@ -3301,9 +3325,9 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
 #define MS_NV12_LAUNCH(NF_, ALN_)                                                                                                                                     \
     do {                                                                                                                                                              \
         const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, NF_));                                                                                            \
-        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_nv12<MS_PROJ_SPHERICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
-        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
-        else k_warp_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_nv12<MS_PROJ_SPHERICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_nv12<MS_PROJ_CYLINDRICAL, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F); \
+        else k_warp_nv12<MS_PROJ_PLANE, NF_, ALN_><<<g_, b_, 0, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F); \
     } while (0)
             c->last_warp_kernel = MS_WARP_KERNEL_NV12;
             if (nv_al) { if (F == 1) MS_NV12_LAUNCH(1, true); else MS_NV12_LAUNCH(2, true); }
@@ -3313,7 +3337,7 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             c->last_warp_kernel = MS_WARP_KERNEL_LDS_STAGED;
             const long long items = (long long)c->n_warp_tiles * F;
             const int grid = (int)std::min<long long>(items, (long long)c->n_cus * (160 * 1024 / (2 * WA_BUF_BYTES)));
-            MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+            MS_PROJ_LAUNCH(k_warp_a, (), (dim3(grid), dim3(64), 2 * WA_BUF_BYTES, st), (const WarpTile *)c->warp_tiles.p, c->n_warp_tiles, vt, N, src, c->cfg.src_height, c->cfg.src_width, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
         } else
         {
             // (with shared offsets the aligned form wins at every minification measured: config 5 -- 2.7 x, k_warp_t's unaligned territory -- 757 -> 730 / 738 -> 699 us per 16 frames;
@@ -3322,23 +3346,25 @@ static int stitch_impl(ms_ctx *c, int n_frames, const ms_image *views, ms_image 
             c->last_warp_kernel = ((c->warp_aligned || force_al != 0) && src_shared) ? MS_WARP_KERNEL_SHARED_ALIGNED : c->warp_aligned ? MS_WARP_KERNEL_PER_FRAME_ALIGNED
                                   : (src_steps_equal && F > 1 && dev_knob("MS_WARP_SHARED_U", 1)) ? MS_WARP_KERNEL_SHARED_UNALIGNED : MS_WARP_KERNEL_PER_FRAME_UNALIGNED;
             if ((c->warp_aligned || force_al != 0) && src_shared)
-                MS_WARP_S_LAUNCH(false, WARP_NF_S, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                MS_WARP_S_LAUNCH(false, WARP_NF_S, warp_lds_al, (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (c->warp_aligned)
-                MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                MS_PROJ_LAUNCH(k_warp_t, (false, true,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds_al, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
             else if (src_steps_equal && F > 1 && dev_knob("MS_WARP_SHARED_U", 1)) {      // the unaligned-read form with shared offsets (config 5): only the row step has to agree
                 const dim3 g_(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), b_(WARP_BX, WARP_WY);
-                if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_s<false, MS_PROJ_SPHERICAL, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
-                else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_s<false, MS_PROJ_CYLINDRICAL, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
-                else k_warp_s<false, MS_PROJ_PLANE, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                if (c->cfg.projection == MS_PROJ_SPHERICAL) k_warp_s<false, MS_PROJ_SPHERICAL, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
+                else if (c->cfg.projection == MS_PROJ_CYLINDRICAL) k_warp_s<false, MS_PROJ_CYLINDRICAL, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
+                else k_warp_s<false, MS_PROJ_PLANE, WARP_NF, false><<<g_, b_, warp_lds, st>>>((const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
             } else
-                MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride, (const float2 *)c->tabs.p, F);
+                MS_PROJ_LAUNCH(k_warp_t, (false, false,), (dim3(c->n_warp_tiles, WARP_BY / WARP_WY, div_up(F, WARP_NF)), dim3(WARP_BX, WARP_WY), warp_lds, st), (const WarpTile *)c->warp_tiles.p, vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride, (const float2 *)c->tabs.p, F);
         }
     } else if (c->cfg.cpu_flavour_remap != 0) {
         k_warp<false, true><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
-            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
+            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride);
     } else {
         k_warp<false><<<dim3(div_up(c->max_pw, 64), div_up(c->max_ph, 4), F * N), blk, 0, st>>>(
-            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, (uint8_t *)c->g0.p, c->g0_stride);
+            vt, N, src, c->cfg.src_height, c->cfg.src_width, mesh, nullptr, 0, g0_w, c->g0_stride);
+    }
+        }
     }
     MS_LAUNCH_CHECK();
     if (int e = mark("k_warp")) return e;

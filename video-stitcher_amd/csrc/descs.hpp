@@ -6,8 +6,8 @@ namespace ms {
 
 constexpr int MAX_LEVELS = 8;     // num_bands <= 7
 constexpr int MAX_VIEWS = 16;
-constexpr int MAX_SRC = 192;      // frames * views per ms_stitch call
-constexpr int MAX_FRAMES = 32;    // frames per ms_stitch call
+constexpr int MAX_SRC = 192;      // frames * views of ONE by-value source table (a launch of the kernels that read the callers' frames: stitch_impl sends them out in chunks)
+constexpr int MAX_FRAMES = 64;    // frames per ms_stitch call
 
 struct LevelDesc {
     int w, h, pitch;              // level size; pitch in elements
@@ -62,6 +62,7 @@ struct ShardArgs {
     long long pstride;            // elements per frame in a partial buffer
 };
 struct SrcTable { const uint8_t *p[MAX_SRC]; unsigned step[MAX_SRC]; };
+struct SrcAll { const uint8_t *p[MAX_FRAMES * MAX_VIEWS]; unsigned step[MAX_FRAMES * MAX_VIEWS]; };      // host side: every frame of a call
 struct MeshTable { const float *x[MAX_VIEWS]; const float *y[MAX_VIEWS]; int pitch[MAX_VIEWS]; };
 // max |mesh map - identity| of the active mesh of each view, as float bits in device memory (written by ms_set_mesh), and the bound
 // under which CPW stage 1 may skip the tiles stage 2 cannot reach (WarpTile::flags bit 1 = reachable within that bound)
