@@ -174,7 +174,7 @@ def main():
     if args.view_shards > 1 or args.col_shards > 1:
         cfg = dict(synth.CONFIGS["cfg5" if args.config == "cfg5" else "cfg2"])
         fn = shards.run_view_shards if args.view_shards > 1 else shards.run_col_shards
-        line = fn(args, cfg, synth.gains(cfg["n"]), rank, world, dev, share, frame_source="device" if args.config == "cfg5" else "numpy")
+        line = fn(args, cfg, synth.gains(cfg["n"]), rank, world, dev, share, frame_source=args.frame_source or ("device" if args.config == "cfg5" else "numpy"))
         if rank == 0:
             print(json.dumps(line), flush=True)
         return

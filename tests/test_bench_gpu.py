@@ -106,7 +106,7 @@ def test_default_line_is_the_drivers_record():
 def test_committed_traffic_summary_is_the_fallback():
     """--no-pmc: roofline.traffic comes from profiles/traffic_cfg2.json, says so in `traffic_source` and `traffic_measured_in_this_run`, and `traffic_stale` compares the hash of
     csrc/ the summary recorded with the sources that ran."""
-    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--passes", "4", "--no-pmc", "--no-others", "--no-cpu-baseline", "--no-live", "--no-pcie", "--no-distinct"],
+    p = subprocess.run([sys.executable, "bench.py", "--frame-source", "device", "--steps", "2", "--warmup", "1", "--passes", "4", "--no-pmc", "--no-others", "--no-cpu-baseline", "--no-live", "--no-pcie", "--no-distinct"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     r = last_json(p.stdout)["roofline"]
@@ -120,7 +120,7 @@ FAKE_RCCL = os.path.join(ROOT, "tests", "_fake_rccl", "libfake_rccl.so")
 def test_two_ranks_sharing_the_gpu_run_the_multi_rank_path():
     env = dict(os.environ, MS_BENCH_SHARE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-                        "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--gather-every", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "bench.py", "--frame-source", "device", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--gather-every", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
@@ -139,7 +139,7 @@ def test_plain_invocation_spawns_ranks():
     gathered), the compute-only and the every-frame-to-one-sink rates beside it."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MS_BENCH_SHARE_GPU"] = "1"
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--passes", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run([sys.executable, "bench.py", "--frame-source", "device", "--gpus", "2", "--steps", "4", "--warmup", "1", "--passes", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1, p.stdout[-2000:]
     d = last_json(p.stdout)
@@ -160,11 +160,11 @@ def test_scale_shaped_dry_run_and_what_is_printed_before_the_first_timed_region(
     twice, a rank idle) would show as a factor of two.  And before any timed region the N = 2 run has printed, on stderr, the preamble (every rank's device and bus id as
     torch.distributed sees them) and `dist: {librccl_path, rccl_version, comm_nranks, pci_bus_ids, transport}`."""
     assert os.path.isfile(FAKE_RCCL), "tests/_fake_rccl/libfake_rccl.so is built by __graft_entry__.build()"
-    common = ["--steps", "3", "--warmup", "1", "--passes", "3", "--no-cpu-baseline", "--no-live", "--no-pcie", "--no-distinct"]
-    p1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--no-others", "--no-pmc", "--no-verify"] + common, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    common = ["--steps", "3", "--warmup", "1", "--passes", "3", "--no-cpu-baseline", "--no-live", "--no-pcie", "--no-distinct"]      # (frames generated on the device: 48 numpy frames cost every rank of every run 5 s)
+    p1 = subprocess.run([sys.executable, "bench.py", "--frame-source", "device", "--gpus", "1", "--no-others", "--no-pmc", "--no-verify"] + common, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p1.returncode == 0, p1.stderr[-2000:]
     v1 = last_json(p1.stdout)["value"]
-    p2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, cwd=ROOT, env=_fake_env(MS_BENCH_CHECK_GATHERED="1"), capture_output=True, text=True, timeout=900)
+    p2 = subprocess.run([sys.executable, "bench.py", "--frame-source", "device", "--gpus", "2"] + common, cwd=ROOT, env=_fake_env(MS_BENCH_CHECK_GATHERED="1"), capture_output=True, text=True, timeout=900)
     assert p2.returncode == 0, (p2.stdout + p2.stderr)[-3000:]
     d = last_json(p2.stdout)
     assert 0.85 < d["value_no_gather"] / v1 < 1.15, (d["value_no_gather"], v1)
@@ -187,7 +187,7 @@ def test_scale_shaped_dry_run_and_what_is_printed_before_the_first_timed_region(
 def test_a_communicator_of_the_wrong_size_fails_loudly():
     """RCCL's own count of the communicator (ncclCommCount) differs from the number of ranks the launcher started: the run stops BEFORE its first timed region with one JSON
     line (`value` null, `failed`, `incomplete` says why, `dist` shows what the communicator saw) and a non-zero exit code (the loopback library's fault injection)."""
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline", "--no-live"], cwd=ROOT,
+    p = subprocess.run([sys.executable, "bench.py", "--frame-source", "device", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline", "--no-live"], cwd=ROOT,
                        env=_fake_env(FAKE_RCCL_COUNT_DELTA="1"), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0, p.stdout[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -199,7 +199,7 @@ def test_a_communicator_of_the_wrong_size_fails_loudly():
 def test_a_hanging_bring_up_is_ended_by_the_watchdog_with_a_failed_line():
     """A transport that hangs in ncclCommInitRank (first real N-GPU run: RCCL has never formed an N > 1 communicator here): the per-stage watchdog (120 s by default; 4 s here)
     prints the one JSON line -- `failed`, `value` null, the stage in `incomplete` -- and ends every rank with a NON-ZERO exit code (a hang used to exit 0)."""
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline", "--no-live"], cwd=ROOT,
+    p = subprocess.run([sys.executable, "bench.py", "--frame-source", "device", "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "2", "--no-cpu-baseline", "--no-live"], cwd=ROOT,
                        env=_fake_env(FAKE_RCCL_HANG_S="60", MS_BENCH_WATCHDOG_S="4"), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0, p.stdout[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -216,7 +216,7 @@ def test_view_sharded_ranks_exchange_partials_and_match_the_unsharded_frame():
     two = torch.cuda.device_count() >= 2
     env = dict(os.environ) if two else dict(os.environ, MS_BENCH_SHARE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29537",
-                        "bench.py", "--gpus", "2", "--view-shards", "2", "--frames", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                        "bench.py", "--frame-source", "device", "--gpus", "2", "--view-shards", "2", "--frames", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)
@@ -232,7 +232,7 @@ def test_column_sharded_ranks_exchange_slabs_and_match_the_unsharded_frame():
     two = torch.cuda.device_count() >= 2
     env = dict(os.environ) if two else dict(os.environ, MS_BENCH_SHARE_GPU="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-                        "bench.py", "--gpus", "2", "--col-shards", "2", "--frames", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                        "bench.py", "--frame-source", "device", "--gpus", "2", "--col-shards", "2", "--frames", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = last_json(p.stdout)
