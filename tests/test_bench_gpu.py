@@ -94,6 +94,12 @@ def test_default_line_is_the_drivers_record():
         ro = o["roofline"]
         assert ro["kernel"] in o["kernels_ms_per_call"] and ro["traffic_stale"] in (True, False, None)
         assert ro["frac"] is None or 0.1 < ro["frac"] < 1.0, (name, ro)
+    # the bytes per frame of every configuration, collected in this run, are the ones four rounds of committed summaries show (+- 10 %): a summary that miscounts the launches of a
+    # call (k_warp_tabs taken for a warp launch: 9 / 12 of cfg5's bytes; the chunked launches of a 64-frame call counted as calls: half of the shipped rig's) cannot pass
+    for name, mb in (("cfg3", 158.4), ("cfg5", 431.3), ("shipped", 340.5)):
+        got = oc[name]["frame"]["hbm_bytes_per_frame"] / 1e6
+        assert 0.9 * mb < got < 1.1 * mb, (name, got)
+    assert 0.9 * 123.0 < fr["hbm_bytes_per_frame"] / 1e6 < 1.1 * 123.0
     assert "on (40x40 mesh)" in oc["cfg3"]["workload"] and "re-expanded every 60 frames" in oc["cfg3"]["workload"] and "k_remap_gain" in oc["cfg3"]["kernels_ms_per_call"]
     assert "12x3840x2160" in oc["cfg5"]["workload"] and "7680x3840" in oc["cfg5"]["workload"]
     assert oc["cfg5"]["col_shards_2"]["equals_unsharded"] is True and oc["cfg5"]["view_shards_2"]["equals_unsharded"] is True

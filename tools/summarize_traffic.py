@@ -86,12 +86,22 @@ def build_summary(fetch, write, tag, cfg, frames, root):
             alias["k_warp"] = v                # CPW contexts: the level-0 kernel is the mesh remap of the stage image
         if k.startswith("k_down_t<unsigned char>") or k.startswith("k_down_t<true>"):
             alias["k_down_l0"] = v
+    # ms_stitch calls of the collection = launches of a kernel that goes out exactly ONCE per call (the level-0 reduce, the two tails, the level-0 band kernel).  The kernels that read
+    # the callers' frames go out in chunks of 192 / views frames since round 6 (64 frames of six views: two launches per call): bench.py times all chunk launches of a call under one
+    # name, so the aliases it reads carry the bytes of ALL of them (`launches_per_call`).
+    once = [v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_down_t<true>", "k_down_tail", "k_blend_tail", "k_blend8<true")) and v["launches"] > 0]
+    calls = min(once) if once else max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t<", "k_warp_s<", "k_warp_a", "k_warp<"))] or [1])
+    for name in ("k_warp", "k_remap_gain"):
+        if name in alias:
+            per_call = max(1, int(round(alias[name]["launches"] / float(calls))))
+            alias[name] = dict(alias[name], launches_per_call=per_call, hbm_bytes_per_launch=alias[name]["hbm_bytes_per_launch"] * per_call,
+                               note="bytes of the %d chunk launch(es) of one ms_stitch call" % per_call)
     res["kernels"].update(alias)
     # HBM bytes of one ms_stitch call (all per-frame kernels): what bench.py's frame_roofline.frac_traffic divides by the GPU time
     per_frame = ("k_resize_linear3", "k_warp_t<", "k_warp_s<", "k_stage1_s", "k_warp_a", "k_warp<", "k_stage1_t", "k_remap_gain", "k_down_t", "k_down_tail", "k_down<", "k_blend8", "k_blend_tail",
                  "k_blend<", "k_blend_top", "k_single_band")
     # (the "<" matters: k_warp_tabs is a calibration kernel, launched once per view -- 12 times for the 12 x 4K rig, more often than a short collection launches the warp)
-    steps = max([v["launches"] for k, v in res["kernels"].items() if k.startswith(("k_warp_t<", "k_warp_s<", "k_warp_a", "k_warp<"))] or [1])
+    steps = calls
     res["hbm_bytes_per_call"] = int(sum(v["hbm_bytes_per_launch"] * v["launches"] / steps for k, v in res["kernels"].items()
                                         if (k.startswith(per_frame) or k == "k_down") and k not in alias))
     res["calls"] = steps
