@@ -240,12 +240,12 @@ def test_synchronous_update_mask_is_safe_beside_a_stitching_thread(ms, cuda):
     comp.close()
 
 
-@pytest.mark.parametrize("nf,rig,cpw", [(3, "mini6", False), (32, "mini6", False), (64, "mini6", False), (40, "mini6", True), (64, "mini4", True)])
+@pytest.mark.parametrize("nf,rig,cpw", [(3, "mini6", False), (32, "mini6", False), (64, "mini6", False), (40, "mini6", True), (64, "mini4", True), (49, "mini4", False), (33, "mini6", True)])
 def test_batched_frames_equal_single_frames(ms, cuda, nf, rig, cpw):
     """Frames per ms_stitch call up to the ABI's limit (64 since round 6).  The kernels that read the callers' frames take their pointers in a by-value table of 192 entries, so a
     call of more frames than 192 / views (32 for six views, 48 for four) sends those launches out in CHUNKS -- each with its own table, the per-frame buffers offset by the chunk's
-    first frame -- while the reduce and band chains cover all frames at once: 64 and 40 frames (a full chunk + a short one) must equal the same frames stitched one per call,
-    without and with CPW (the first remap and the mesh remap are both chunked)."""
+    first frame -- while the reduce and band chains cover all frames at once: 64 and 40 frames (a full chunk + a short one), 49 and 33 (a full chunk + ONE frame: the one-frame
+    instantiation of the kernels) must equal the same frames stitched one per call, without and with CPW (the first remap and the mesh remap are both chunked)."""
     comp, cfg, gains = make_rig(ms, rig, max_frames=nf, enable_cpw=cpw)
     if cpw:
         for i in range(cfg["n"]):
